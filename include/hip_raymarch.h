@@ -1,0 +1,288 @@
+/*
+ * hip_raymarch.h -- C ABI of libhip_raymarch.so
+ *
+ * MI355X (gfx950) implementation of the one hot path of
+ * radian628/raymarching-engine: the per-pixel sphere-tracing fragment shader
+ *   client/public/shader/raymarcher.frag            (kernel, 387 lines of GLSL)
+ * behind the boundary the reference's host crosses for every sample,
+ *   client/src/renderer/RenderJobExecutor.tsx:195-326 (bind prev, set uniforms, draw, blit).
+ *
+ * Every entry point cites the reference interface it replaces.  The ABI is
+ * plain C: pointers, sizes and POD structs of fp32/int32 only, no C++ or
+ * torch types.  Error convention (the reference returns errors as values,
+ * RenderJobExecutor.tsx:56-68,112-136; ShaderCache.tsx:4-11): every call
+ * returns an int status, RM_OK == 0, and the text for the last failure is
+ * kept per context (rm_last_error).  Nothing throws across the ABI.
+ *
+ * Threading: one caller per rm_ctx (the reference is single threaded,
+ * index.tsx:120); launches are asynchronous on the context's HIP stream and
+ * rm_sync() is the completion point.  One rm_ctx per GPU.
+ */
+#ifndef HIP_RAYMARCH_H
+#define HIP_RAYMARCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RM_ABI_VERSION 1
+
+#define RM_MAX_BOUNCES 10 /* raymarchingStepCountsArray[10], raymarcher.frag:31 */
+#define RM_MAX_LIGHTS 10  /* lightPositions[10],             raymarcher.frag:37-39 */
+#define RM_MAX_PRIMS 256  /* primitive table rows staged in LDS (32 B each) */
+
+/* status codes */
+enum {
+  RM_OK = 0,
+  RM_ERR_INVALID = 1,  /* bad argument / failed validation (the "compile error" of a scene) */
+  RM_ERR_DEVICE = 2,   /* HIP runtime error */
+  RM_ERR_NO_DEVICE = 3 /* no usable GPU: the library has NO CPU fallback */
+};
+
+/* ---- uniforms ---------------------------------------------------------- */
+
+/*
+ * Exactly the uniform block of raymarcher.frag:6-42, as assembled per sample
+ * at RenderJobExecutor.tsx:212-297.  `rotation` is column-major like
+ * gl.uniformMatrix4fv(..., false, m) (RenderJobExecutor.tsx:293-297).
+ * The three sampler uniforms are the framebuffer handle; textureSize() is the
+ * framebuffer's full image size.  `reflections` is a float in the reference
+ * (loop bound, raymarcher.frag:21,252).  `raymarchingSteps` and
+ * `indirectLightingRaymarchingSteps` are set by the reference but never read
+ * by the shader (raymarcher.frag:22-23): accepted, unused.
+ */
+typedef struct RmUniforms {
+  float blendWithPreviousFactor;
+  float randNoise[2];
+  float position[3];
+  float rotation[16];
+  float dofAmount;
+  float dofFocalPlaneDistance;
+  int32_t cameraMode; /* 0 perspective, 1 orthographic, 2 panoramic (RenderJobExecutor.tsx:228-232) */
+  float fov;          /* fov | orthographic size | 1 (RenderJobExecutor.tsx:233-239) */
+  float reflections;
+  float raymarchingSteps;
+  float indirectLightingRaymarchingSteps;
+  float aspect;
+  float fogDensity;
+  float exposure; /* render.exposure / samplesPerPixel (RenderJobExecutor.tsx:254-256) */
+  float raymarchingStepCountsArray[RM_MAX_BOUNCES];
+  int32_t blendMode;  /* 1 additive, 0 mix (RenderJobExecutor.tsx:258) */
+  int32_t renderMode; /* 1 preview, 0 full (RenderJobExecutor.tsx:259) */
+  float lightPositions[RM_MAX_LIGHTS][3];
+  float lightColors[RM_MAX_LIGHTS][3];
+  float lightSizes[RM_MAX_LIGHTS];
+  int32_t lightCount;
+  int32_t showDofFocalPlane;
+} RmUniforms;
+
+/* ---- scene ------------------------------------------------------------- */
+
+/*
+ * The reference's scene is GLSL text defining sdf() and up to seven material
+ * functions, spliced into the shader and compiled by the GL driver
+ * (RenderJobExecutor.tsx:121-127, Validate.tsx:8-57).  A HIP kernel cannot
+ * take GLSL, so the scene crosses this ABI as data: a scene kind (the
+ * kernel is specialised per kind), its parameters (the scene's "custom
+ * uniforms", RenderJobExecutor.tsx:266), an optional primitive table, and a
+ * material block holding the constants of the seven material functions.
+ */
+enum {
+  RM_SCENE_TABLE = 0,          /* fold of primitives with CSG operators; sdfSphere raymarcher.frag:74, sdBox :108, opSmoothUnion examples/smooth-tree.glsl:20-22 */
+  RM_SCENE_MANDELBULB = 1,     /* power-n Mandelbulb distance estimator (authored by this project; BASELINE.json configs[2]) */
+  RM_SCENE_SPHERE_GRID = 2,    /* examples/guide.glsl:91-102, examples/fractal1.glsl:23-34 */
+  RM_SCENE_SPHERE_LATTICE = 3, /* dist/examples/sphere-grid.glsl:42-49 */
+  RM_SCENE_MENGER = 4,         /* examples/menger-sponge.glsl:6-23 */
+  RM_SCENE_KIFS_TREE = 5,      /* examples/tree.glsl:16-36, examples/smooth-tree.glsl:30-56 */
+  RM_SCENE_KIFS_BOX = 6,       /* examples/rotation-fractal.glsl:16-35 */
+  RM_SCENE_KIND_COUNT = 7
+};
+
+enum { RM_PRIM_SPHERE = 0, RM_PRIM_BOX = 1 };
+enum { RM_OP_UNION = 0, RM_OP_SMOOTH_UNION = 1, RM_OP_SUBTRACT = 2, RM_OP_INTERSECT = 3 };
+
+/* One row of the primitive table, 32 bytes.  The scene distance is the left
+ * fold  d = prim[0];  d = op_i(d, prim[i])  for i = 1..n-1. */
+typedef struct RmPrim {
+  int32_t type; /* RM_PRIM_* in bits 0..7, RM_OP_* in bits 8..15 */
+  float k;      /* smooth-union radius */
+  float center[3];
+  float size[3]; /* sphere: size[0] = radius; box: half extents */
+} RmPrim;
+
+/* parameter slots of RmSceneDesc.params per kind */
+enum {
+  /* RM_SCENE_MANDELBULB */
+  RM_P_BULB_POWER = 0, RM_P_BULB_ITERATIONS = 1, RM_P_BULB_BAILOUT = 2,
+  /* RM_SCENE_SPHERE_GRID: bigSphereSize, fractalIterations, gridScaleFactor, bigSphereCenter.xyz */
+  RM_P_GRID_BIG_SIZE = 0, RM_P_GRID_ITERATIONS = 1, RM_P_GRID_SCALE = 2, RM_P_GRID_CENTER = 3,
+  /* RM_SCENE_SPHERE_LATTICE: period, radius */
+  RM_P_LATTICE_PERIOD = 0, RM_P_LATTICE_RADIUS = 1,
+  /* RM_SCENE_MENGER: fractalIterations */
+  RM_P_MENGER_ITERATIONS = 0,
+  /* RM_SCENE_KIFS_TREE / RM_SCENE_KIFS_BOX: fractalIterations, scaleFactor, angles.xyz, offset, smoothen */
+  RM_P_KIFS_ITERATIONS = 0, RM_P_KIFS_SCALE = 1, RM_P_KIFS_ANGLES = 2, RM_P_KIFS_OFFSET = 5, RM_P_KIFS_SMOOTH = 6
+};
+
+/* Constants of the seven material functions (Validate.tsx:18-51 are the
+ * defaults; examples override some).  colour = value inside `*_cutoff`,
+ * 0 outside (length(position) > cutoff). */
+typedef struct RmMaterial {
+  float diffuse[3];
+  float diffuse_cutoff;
+  float specular[3];
+  float specular_cutoff;
+  float roughness;
+  float subsurface;
+  float subsurface_color[3];
+  float ior;
+  /* emission = sky_color * max(normalize(p)[sky_axis], sky_floor) * sky_scale  where length(p) > sky_radius, else 0 */
+  float sky_color[3];
+  float sky_floor;
+  float sky_scale;
+  float sky_radius;
+  int32_t sky_axis;
+  int32_t reserved;
+} RmMaterial;
+
+typedef struct RmSceneDesc {
+  int32_t kind;
+  int32_t nprims;
+  const RmPrim* prims; /* host pointer, nprims rows (RM_SCENE_TABLE only) */
+  float params[16];
+  RmMaterial material;
+} RmSceneDesc;
+
+/* Fills *m with the reference defaults of Validate.tsx:18-51. */
+void rm_material_default(RmMaterial* m);
+
+/* ---- handles ----------------------------------------------------------- */
+
+typedef struct rm_ctx rm_ctx;
+typedef struct rm_scene rm_scene;
+typedef struct rm_fb rm_fb;
+
+typedef struct RmRect {
+  int32_t x, y, w, h; /* pixels, origin bottom-left like gl.scissor */
+} RmRect;
+
+/* render flags */
+enum {
+  RM_RENDER_STRICT = 0,      /* fixed step counts, IEEE division/sqrt, no contraction: the parity build */
+  RM_RENDER_FAST = 1,        /* wave-ballot early retire + hardware-rate math; results within the documented tolerance */
+  RM_RENDER_COLOR_ONLY = 2   /* do not read/write the two G-buffer planes (benchmark "single colour frame" mode) */
+};
+
+enum { RM_PLANE_COLOR = 0, RM_PLANE_NORMAL_DOF = 1, RM_PLANE_ALBEDO_DEPTH = 2 };
+
+/* ---- context ----------------------------------------------------------- */
+
+/* Replaces loadRenderJobContext(gl) (LoadRenderJobContext.tsx:268-287): binds
+ * a device, creates the stream the launches go to.  Fails with
+ * RM_ERR_NO_DEVICE when there is no GPU -- there is no CPU path. */
+int rm_ctx_create(int device, rm_ctx** out);
+void rm_ctx_destroy(rm_ctx* ctx);
+/* Text of the last error on this context ("" if none); ctx may be NULL for
+ * errors of rm_ctx_create itself.  Replaces ShaderError.infoLog. */
+const char* rm_last_error(const rm_ctx* ctx);
+/* Use an externally owned hipStream_t (e.g. torch's current stream) for all
+ * later launches; NULL restores the context's own stream. */
+int rm_ctx_set_stream(rm_ctx* ctx, void* hip_stream);
+/* Completion point: the reference's generator yield / present cadence
+ * (RenderJobExecutor.tsx:163-166) maps to "enqueue samples, rm_sync, present". */
+int rm_sync(rm_ctx* ctx);
+int rm_abi_version(void);
+
+/* ---- scene ------------------------------------------------------------- */
+
+/* Replaces programCache.getProgram(vert, frag-with-scene)
+ * (RenderJobExecutor.tsx:121-127, ShaderCache.tsx:91-119): validates the
+ * description (the analogue of a GLSL compile) and uploads the primitive
+ * table.  On failure returns RM_ERR_INVALID and rm_last_error() is the
+ * "info log". */
+int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out);
+void rm_scene_destroy(rm_scene* scene);
+
+/* ---- framebuffers ------------------------------------------------------ */
+
+/* Replaces context.fbo.create(w, h, frameid) (LoadRenderJobContext.tsx:186-223):
+ * three accumulation planes of float4 per pixel (color RGBA, normal+dofRadius,
+ * albedo+depth; raymarcher.frag:70-72).  The reference ping-pongs prev/curr
+ * and copies curr->prev after every draw (RenderJobExecutor.tsx:301-326);
+ * here each pixel is read and written by the one thread that owns it, so a
+ * single in-place set is the same result.  The frame may be a window of rows
+ * [row_begin, row_begin+row_count) of a width x height image (row sharding
+ * across GPUs): pixel coordinates, texcoord and aspect stay global.
+ * Planes are zero-initialised.  Row 0 is the BOTTOM row (GL convention). */
+int rm_fb_create(rm_ctx* ctx, int width, int height, int row_begin, int row_count, rm_fb** out);
+/* Same, but over caller-owned device memory (e.g. torch tensors): each plane
+ * pointer addresses row_count*width float4; normal_dof/albedo_depth may be
+ * NULL (then only RM_RENDER_COLOR_ONLY renders are accepted). */
+int rm_fb_wrap(rm_ctx* ctx, int width, int height, int row_begin, int row_count,
+               void* color, void* normal_dof, void* albedo_depth, rm_fb** out);
+/* The clear-on-new-frameid of LoadRenderJobContext.tsx:196-208. */
+int rm_fb_clear(rm_fb* fb);
+void rm_fb_destroy(rm_fb* fb);
+/* Copies one plane (row_count*width*4 floats) to / from host memory; synchronous. */
+int rm_fb_download(rm_fb* fb, int plane, float* host);
+int rm_fb_upload(rm_fb* fb, int plane, const float* host);
+/* Device address of a plane (for collectives / zero-copy wrapping). */
+void* rm_fb_device_ptr(rm_fb* fb, int plane);
+
+/* ---- the hot path ------------------------------------------------------ */
+
+/* One sample of every pixel of `tile` (clipped to the framebuffer's rows):
+ * replaces  bind prev -> setUniforms -> gl.drawArrays -> blit
+ * (RenderJobExecutor.tsx:195-326) = one run of raymarcher.frag main()
+ * (raymarcher.frag:178-388) per pixel.  tile == NULL means the whole window.
+ * Asynchronous on the context's stream. */
+int rm_render_sample(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* uniforms,
+                     const RmRect* tile, int flags);
+
+/* `count` samples back to back, sample i using randNoise[i] (pairs); every
+ * other uniform as given.  Same as `count` calls of rm_render_sample. */
+int rm_render_samples(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* uniforms,
+                      const float* rand_noise_pairs, int count, const RmRect* tile, int flags);
+
+/* Like rm_render_samples with one fixed randNoise, but brackets the `count`
+ * launches with HIP events on the context's stream and returns the average
+ * kernel time per launch in *ms_per_launch (synchronous). */
+int rm_render_timed(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* uniforms,
+                    int count, const RmRect* tile, int flags, float* ms_per_launch);
+
+/* ---- probes (RNG-free building blocks of the path) --------------------- */
+
+/* The reference's own functions evaluated on caller-supplied inputs, the
+ * device analogue of the harness main() used to generate the goldens.
+ * All buffers are HOST pointers; synchronous.
+ *   RM_PROBE_SDF      in: n x float3 p                  out: n x float   sdf(p)            (scene text / examples)
+ *   RM_PROBE_CAST_RAY in: n x (float3 p, float3 dir)    out: n x float3  castRay(p,dir,steps)   raymarcher.frag:163-170
+ *   RM_PROBE_NORMAL   in: n x float3 p                  out: n x float3  sceneNormal(p, delta)  raymarcher.frag:153-160
+ *   RM_PROBE_MATERIAL in: n x float3 p                  out: n x 12 floats diffuse,specular,emission,(roughness,subsurface,ior)
+ */
+enum { RM_PROBE_SDF = 0, RM_PROBE_CAST_RAY = 1, RM_PROBE_NORMAL = 2, RM_PROBE_MATERIAL = 3 };
+int rm_probe(rm_ctx* ctx, rm_scene* scene, int what, const float* in, int n, float param,
+             int flags, float* out);
+
+/* Camera block of main() without jitter or depth of field
+ * (raymarcher.frag:186-205 with randomDirectionOffset = dofOffset = 0):
+ * out = height*width x 8 floats (origin.xyz, deltaZ, dir.xyz, 0), HOST pointer. */
+int rm_probe_camera(rm_ctx* ctx, const RmUniforms* uniforms, int width, int height, float* out);
+
+/* The per-pixel random stream (raymarcher.frag:46-49,78-101): for each pixel
+ * of a width x height image the first `count` values of uniformSample().
+ * out = height*width*count floats, HOST pointer. */
+int rm_probe_rng(rm_ctx* ctx, const RmUniforms* uniforms, int width, int height, int count, float* out);
+
+/* ---- present ----------------------------------------------------------- */
+
+/* Tone map of display.frag:20-64 (next-row N1): out = row_count*width RGBA8,
+ * HOST pointer: colour * (1/samples), DoF-radius driven Gaussian blur, gamma 1/2.2. */
+int rm_present(rm_ctx* ctx, rm_fb* fb, int samples, uint8_t* out_rgba8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIP_RAYMARCH_H */

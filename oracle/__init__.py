@@ -1,0 +1,4 @@
+"""CPU oracle of the hot path -- TEST INFRASTRUCTURE ONLY (see rm_oracle.c).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this package; the product (raymarching-engine_amd/) never does."""

@@ -1,0 +1,431 @@
+"""Scene-definition / SDF-composition API.
+
+The reference's scene is GLSL text (``sdfShaderSource``) defining ``sdf()`` and
+optional material functions (client/src/settings/shader-editor/Validate.tsx:8-57).
+A composed scene here has two back ends built from ONE description:
+
+* ``desc()``  -> ``RmSceneDesc`` for the HIP kernel (kind + parameters +
+  primitive table + material constants, include/hip_raymarch.h);
+* ``glsl()``  -> scene text satisfying the reference's scene contract, so the
+  same scene can be fed to the reference's GLSL path (``sdfShaderSource`` keeps
+  working, and it is what the golden generator renders).
+
+Helper SDFs the emitted GLSL calls (``sdfSphere``, ``sdBox``) are the ones the
+reference's shader already provides above its splice point
+(raymarcher.frag:74-76,108-112).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+from . import abi
+
+
+def _f(x: float) -> str:
+    """GLSL float literal that round-trips the fp32 value."""
+    import numpy as np
+
+    v = float(np.float32(x))
+    s = repr(v)
+    if "e" in s or "E" in s:
+        m, e = s.lower().split("e")
+        if "." not in m:
+            m += ".0"
+        return f"{m}e{int(e)}"
+    if "." not in s and "inf" not in s and "nan" not in s:
+        s += ".0"
+    return s
+
+
+def _v3(v: Sequence[float]) -> str:
+    return f"vec3({_f(v[0])}, {_f(v[1])}, {_f(v[2])})"
+
+
+@dataclass
+class Material:
+    """Constants of the seven material functions; defaults = Validate.tsx:18-51."""
+
+    diffuse: Sequence[float] = (0.6, 0.6, 0.6)
+    diffuse_cutoff: float = 35.0
+    specular: Sequence[float] = (0.6, 0.6, 0.6)
+    specular_cutoff: float = 35.0
+    roughness: float = 0.2
+    subsurface: float = 11111115.0
+    subsurface_color: Sequence[float] = (1.0, 1.0, 1.0)
+    ior: float = 100.0
+    sky_color: Sequence[float] = (0.7, 0.8, 1.0)
+    sky_floor: float = 0.2
+    sky_scale: float = 2.0
+    sky_radius: float = 36.0
+    sky_axis: int = 1
+
+    def is_default(self) -> bool:
+        return self == Material()
+
+    def to_c(self) -> abi.RmMaterial:
+        m = abi.RmMaterial()
+        m.diffuse[:] = list(self.diffuse)
+        m.diffuse_cutoff = self.diffuse_cutoff
+        m.specular[:] = list(self.specular)
+        m.specular_cutoff = self.specular_cutoff
+        m.roughness = self.roughness
+        m.subsurface = self.subsurface
+        m.subsurface_color[:] = list(self.subsurface_color)
+        m.ior = self.ior
+        m.sky_color[:] = list(self.sky_color)
+        m.sky_floor = self.sky_floor
+        m.sky_scale = self.sky_scale
+        m.sky_radius = self.sky_radius
+        m.sky_axis = self.sky_axis
+        return m
+
+    def glsl(self) -> str:
+        """Material functions as scene text; empty for the defaults (the
+        reference then appends its own, Validate.tsx:18-51)."""
+        if self.is_default():
+            return ""
+        ax = "xyz"[self.sky_axis]
+        return "\n".join(
+            [
+                f"vec3 sceneDiffuseColor(vec3 position) {{ if (length(position) > {_f(self.diffuse_cutoff)}) return vec3(0.0); return {_v3(self.diffuse)}; }}",
+                f"vec3 sceneSpecularColor(vec3 position) {{ if (length(position) > {_f(self.specular_cutoff)}) return vec3(0.0); return {_v3(self.specular)}; }}",
+                f"float sceneSpecularRoughness(vec3 position) {{ return {_f(self.roughness)}; }}",
+                f"float sceneSubsurfaceScattering(vec3 position) {{ return {_f(self.subsurface)}; }}",
+                f"vec3 sceneSubsurfaceScatteringColor(vec3 position) {{ return {_v3(self.subsurface_color)}; }}",
+                f"float sceneIOR(vec3 position) {{ return {_f(self.ior)}; }}",
+                "vec3 sceneEmission(vec3 position) {"
+                f" float d = max(normalize(position).{ax}, {_f(self.sky_floor)});"
+                f" vec3 brightColor = {_v3(self.sky_color)} * d * 1.0;"
+                f" return (length(position) > {_f(self.sky_radius)}) ? (brightColor * {_f(self.sky_scale)}) : vec3(0.0); }}",
+            ]
+        )
+
+
+class Scene:
+    """Base: a scene kind with parameters and a material."""
+
+    kind: int = -1
+    material: Material
+
+    def params(self) -> List[float]:
+        return []
+
+    def prims(self) -> List[abi.RmPrim]:
+        return []
+
+    def sdf_glsl(self) -> str:
+        raise NotImplementedError
+
+    def glsl(self) -> str:
+        mat = self.material.glsl()
+        return self.sdf_glsl() + ("\n" + mat if mat else "") + "\n"
+
+    def custom_shader_parameters(self) -> dict:
+        """``customShaderParameters`` of the RenderJobSchema for this scene (the
+        emitted GLSL bakes its parameters as literals, so: none)."""
+        return {}
+
+    def desc(self) -> abi.RmSceneDesc:
+        d = abi.RmSceneDesc()
+        d.kind = self.kind
+        prims = self.prims()
+        d.nprims = len(prims)
+        if prims:
+            arr = (abi.RmPrim * len(prims))(*prims)
+            d.prims = C.cast(arr, C.POINTER(abi.RmPrim))
+            d._keepalive = arr  # the desc borrows the table
+        p = self.params()
+        for i, v in enumerate(p):
+            d.params[i] = v
+        d.material = self.material.to_c()
+        return d
+
+
+# ---- primitive table (CSG fold) -------------------------------------------
+
+
+@dataclass
+class _Node:
+    prim: int
+    op: int
+    k: float
+    center: Sequence[float]
+    size: Sequence[float]
+
+
+class CsgScene(Scene):
+    """Left fold of primitives: ``d = prim0; d = op_i(d, prim_i)``.
+
+    ``sphere``/``box`` start or extend the fold with the current operator
+    (``union`` by default); ``smooth_union(k)``, ``subtract()``,
+    ``intersect()``, ``union()`` select the operator for the primitives that
+    follow.  The smooth union is the polynomial smooth-min of
+    examples/smooth-tree.glsl:20-22.
+    """
+
+    kind = abi.RM_SCENE_TABLE
+
+    def __init__(self, material: Optional[Material] = None):
+        self.material = material or Material()
+        self._nodes: List[_Node] = []
+        self._op = abi.RM_OP_UNION
+        self._k = 0.0
+
+    def union(self):
+        self._op, self._k = abi.RM_OP_UNION, 0.0
+        return self
+
+    def smooth_union(self, k: float):
+        self._op, self._k = abi.RM_OP_SMOOTH_UNION, float(k)
+        return self
+
+    def subtract(self):
+        self._op, self._k = abi.RM_OP_SUBTRACT, 0.0
+        return self
+
+    def intersect(self):
+        self._op, self._k = abi.RM_OP_INTERSECT, 0.0
+        return self
+
+    def sphere(self, center: Sequence[float], radius: float):
+        self._nodes.append(_Node(abi.RM_PRIM_SPHERE, self._op, self._k, tuple(center), (radius, 0.0, 0.0)))
+        return self
+
+    def box(self, center: Sequence[float], half_extents: Sequence[float]):
+        self._nodes.append(_Node(abi.RM_PRIM_BOX, self._op, self._k, tuple(center), tuple(half_extents)))
+        return self
+
+    def prims(self) -> List[abi.RmPrim]:
+        out = []
+        for n in self._nodes:
+            p = abi.RmPrim()
+            p.type = n.prim | (n.op << 8)
+            p.k = n.k
+            p.center[:] = list(n.center)
+            p.size[:] = list(n.size)
+            out.append(p)
+        return out
+
+    def sdf_glsl(self) -> str:
+        if not self._nodes:
+            raise ValueError("empty CSG scene")
+        lines = []
+        if any(n.op == abi.RM_OP_SMOOTH_UNION for n in self._nodes[1:]):
+            lines.append(
+                "float rmSmoothUnion(float d1, float d2, float k) {"
+                " float h = clamp(0.5 + 0.5 * (d2 - d1) / k, 0.0, 1.0);"
+                " return mix(d2, d1, h) - k * h * (1.0 - h); }"
+            )
+        lines.append("float sdf(vec3 p) {")
+        for i, n in enumerate(self._nodes):
+            if n.prim == abi.RM_PRIM_SPHERE:
+                e = f"sdfSphere(p, {_v3(n.center)}, {_f(n.size[0])})"
+            else:
+                e = f"sdBox(p - {_v3(n.center)}, {_v3(n.size)})"
+            if i == 0:
+                lines.append(f"  float d = {e};")
+            elif n.op == abi.RM_OP_UNION:
+                lines.append(f"  d = min(d, {e});")
+            elif n.op == abi.RM_OP_SMOOTH_UNION:
+                lines.append(f"  d = rmSmoothUnion(d, {e}, {_f(n.k)});")
+            elif n.op == abi.RM_OP_SUBTRACT:
+                lines.append(f"  d = max(d, -{e});")
+            else:
+                lines.append(f"  d = max(d, {e});")
+        lines.append("  return d;")
+        lines.append("}")
+        return "\n".join(lines)
+
+
+def single_sphere(center=(0.0, 0.0, 0.0), radius=1.0, material: Optional[Material] = None) -> CsgScene:
+    """BASELINE.json configs[0]/[1]: ``sdf = sdfSphere(p, 0, 1)``."""
+    return CsgScene(material).sphere(center, radius)
+
+
+def csg64(material: Optional[Material] = None) -> CsgScene:
+    """BASELINE.json configs[3]: 64 spheres on a jittered 4x4x4 lattice
+    (spacing 0.9, radii 0.25-0.45, fixed LCG seed 1) folded with smooth unions
+    k = 0.2."""
+    sc = CsgScene(material).smooth_union(0.2)
+    state = 1
+
+    def lcg():
+        nonlocal state
+        state = (state * 1664525 + 1013904223) & 0xFFFFFFFF
+        return (state >> 8) / float(1 << 24)
+
+    for iz in range(4):
+        for iy in range(4):
+            for ix in range(4):
+                c = [(ix - 1.5) * 0.9 + (lcg() - 0.5) * 0.3,
+                     (iy - 1.5) * 0.9 + (lcg() - 0.5) * 0.3,
+                     (iz - 1.5) * 0.9 + (lcg() - 0.5) * 0.3]
+                r = 0.25 + 0.2 * lcg()
+                sc.sphere(c, r)
+    return sc
+
+
+# ---- specialised kinds -----------------------------------------------------
+
+
+class Mandelbulb(Scene):
+    """Power-n Mandelbulb, spherical-coordinate distance estimator
+    ``0.5*log(r)*r/dr`` (BASELINE.json configs[2]).  The
+    reference has no such scene; this text is the definition both back ends
+    implement."""
+
+    kind = abi.RM_SCENE_MANDELBULB
+
+    def __init__(self, power: float = 8.0, iterations: int = 8, bailout: float = 2.0, material: Optional[Material] = None):
+        self.power, self.iterations, self.bailout = float(power), int(iterations), float(bailout)
+        self.material = material or Material()
+
+    def params(self):
+        return [self.power, float(self.iterations), self.bailout]
+
+    def sdf_glsl(self) -> str:
+        return f"""float sdf(vec3 pos) {{
+  vec3 z = pos;
+  float dr = 1.0;
+  float r = 0.0;
+  for (int i = 0; i < {self.iterations}; i++) {{
+    r = length(z);
+    if (r > {_f(self.bailout)}) break;
+    float theta = acos(z.z / r);
+    float phi = atan(z.y, z.x);
+    dr = pow(r, {_f(self.power)} - 1.0) * {_f(self.power)} * dr + 1.0;
+    float zr = pow(r, {_f(self.power)});
+    theta = theta * {_f(self.power)};
+    phi = phi * {_f(self.power)};
+    z = zr * vec3(sin(theta) * cos(phi), sin(phi) * sin(theta), cos(theta));
+    z += pos;
+  }}
+  return 0.5 * log(r) * r / dr;
+}}"""
+
+
+class _ReferenceExample(Scene):
+    """A scene kind that restates one of the reference's example scenes; its
+    GLSL back end is the reference's own example text plus uniform values
+    (``customShaderParameters``), so ``glsl()`` needs the example file name."""
+
+    example: str = ""
+
+    def sdf_glsl(self) -> str:
+        raise NotImplementedError(
+            f"the GLSL of this kind is the reference's examples/{self.example}; pass that text as sdfShaderSource"
+        )
+
+
+class SphereGridFractal(_ReferenceExample):
+    """examples/guide.glsl:91-102 == examples/fractal1.glsl:23-34 (defaults from their //@default)."""
+
+    kind = abi.RM_SCENE_SPHERE_GRID
+    example = "fractal1.glsl"
+
+    def __init__(self, big_sphere_size=4.0, iterations=8.0, grid_scale=0.33333333333, big_sphere_center=(0.0, 0.0, 10.0), material=None):
+        self.big, self.iterations, self.scale, self.center = float(big_sphere_size), float(iterations), float(grid_scale), tuple(big_sphere_center)
+        self.material = material or Material()
+
+    def params(self):
+        return [self.big, self.iterations, self.scale, *self.center]
+
+    def custom_shader_parameters(self):
+        return {
+            "bigSphereSize": {"type": "f", "count": 1, "data": [self.big]},
+            "fractalIterations": {"type": "f", "count": 1, "data": [self.iterations]},
+            "gridScaleFactor": {"type": "f", "count": 1, "data": [self.scale]},
+            "bigSphereCenter": {"type": "f", "count": 3, "data": list(self.center)},
+        }
+
+
+class SphereLattice(Scene):
+    """dist/examples/sphere-grid.glsl:42-49: infinite lattice of spheres."""
+
+    kind = abi.RM_SCENE_SPHERE_LATTICE
+
+    def __init__(self, period=2.0, radius=0.4, material=None):
+        self.period, self.radius = float(period), float(radius)
+        self.material = material or Material()
+
+    def params(self):
+        return [self.period, self.radius]
+
+    def sdf_glsl(self) -> str:
+        h = self.period * 0.5
+        return (
+            f"float sdf(vec3 p) {{ vec3 rep = mod(p + {_f(h)}, vec3({_f(self.period)})) - {_f(h)};"
+            f" return length(rep - vec3(0.0)) - {_f(self.radius)}; }}"
+        )
+
+
+def sphere_lattice_example() -> SphereLattice:
+    """The reference's sphere-grid example with its own material functions
+    (dist/examples/sphere-grid.glsl:1-40)."""
+    return SphereLattice(2.0, 0.4, Material(diffuse=(0.5, 0.5, 0.5), specular=(0.9, 0.9, 0.9), roughness=0.01, sky_axis=0, sky_floor=0.0))
+
+
+class MengerSponge(_ReferenceExample):
+    """examples/menger-sponge.glsl:6-23."""
+
+    kind = abi.RM_SCENE_MENGER
+    example = "menger-sponge.glsl"
+
+    def __init__(self, iterations=8.0, material=None):
+        self.iterations = float(iterations)
+        self.material = material or Material()
+
+    def params(self):
+        return [self.iterations]
+
+    def custom_shader_parameters(self):
+        return {"fractalIterations": {"type": "f", "count": 1, "data": [self.iterations]}}
+
+
+class KifsTree(_ReferenceExample):
+    """examples/tree.glsl:16-36 (smoothen=False) / examples/smooth-tree.glsl:30-56 (smoothen=True)."""
+
+    kind = abi.RM_SCENE_KIFS_TREE
+
+    def __init__(self, iterations=8.0, scale=0.7, angles=(2.9, -0.8, 0.4), offset=1.2, smoothen=False, material=None):
+        self.iterations, self.scale, self.angles, self.offset, self.smoothen = float(iterations), float(scale), tuple(angles), float(offset), bool(smoothen)
+        self.example = "smooth-tree.glsl" if smoothen else "tree.glsl"
+        self.material = material or Material()
+
+    def params(self):
+        return [self.iterations, self.scale, *self.angles, self.offset, 1.0 if self.smoothen else 0.0]
+
+    def custom_shader_parameters(self):
+        p = {
+            "fractalIterations": {"type": "f", "count": 1, "data": [self.iterations]},
+            "scaleFactor": {"type": "f", "count": 1, "data": [self.scale]},
+            "angles": {"type": "f", "count": 3, "data": list(self.angles)},
+            "offset": {"type": "f", "count": 1, "data": [self.offset]},
+        }
+        if self.smoothen:
+            p["smoothen"] = {"type": "i", "count": 1, "data": [1]}
+        return p
+
+
+class KifsBox(_ReferenceExample):
+    """examples/rotation-fractal.glsl:16-35."""
+
+    kind = abi.RM_SCENE_KIFS_BOX
+    example = "rotation-fractal.glsl"
+
+    def __init__(self, iterations=14.0, scale=0.5, angles=(0.4, 0.4, 0.4), offset=1.2, material=None):
+        self.iterations, self.scale, self.angles, self.offset = float(iterations), float(scale), tuple(angles), float(offset)
+        self.material = material or Material()
+
+    def params(self):
+        return [self.iterations, self.scale, *self.angles, self.offset, 0.0]
+
+    def custom_shader_parameters(self):
+        return {
+            "fractalIterations": {"type": "f", "count": 1, "data": [self.iterations]},
+            "scaleFactor": {"type": "f", "count": 1, "data": [self.scale]},
+            "angles": {"type": "f", "count": 3, "data": list(self.angles)},
+            "offset": {"type": "f", "count": 1, "data": [self.offset]},
+        }

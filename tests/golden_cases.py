@@ -1,0 +1,120 @@
+"""Case table shared by the golden generator (oracle/gl/gen_golden.py, runs the
+reference's GLSL under software GL in the build container) and by the tests
+(which only read tests/golden/*.npz).  A case is data: a scene built with the
+composition API plus render-job parameters."""
+from __future__ import annotations
+
+import numpy as np
+
+from raymarching_engine_amd import job as J
+from raymarching_engine_amd import scene as S
+
+LIGHT = [J.point_light((2.0, 3.0, -4.0))]
+SOFT_LIGHT = [J.point_light((2.0, 3.0, -4.0), size=0.3)]
+
+# rotation about y by 0.4 rad then x by -0.25 rad, column-major like gl-matrix
+def _rot():
+    cy, sy = np.cos(0.4), np.sin(0.4)
+    cx, sx = np.cos(-0.25), np.sin(-0.25)
+    ry = np.array([[cy, 0, sy, 0], [0, 1, 0, 0], [-sy, 0, cy, 0], [0, 0, 0, 1]])
+    rx = np.array([[1, 0, 0, 0], [0, cx, -sx, 0], [0, sx, cx, 0], [0, 0, 0, 1]])
+    m = (ry @ rx).astype(np.float32)
+    return [float(v) for v in m.T.reshape(-1)]  # column-major
+
+
+ROT = _rot()
+
+# name -> (scene factory, reference example file or None)
+SCENES = {
+    "sphere": (lambda: S.single_sphere(), None),
+    "csg64": (lambda: S.csg64(), None),
+    "csg_mixed": (
+        lambda: S.CsgScene().box((0, 0, 0), (1.0, 0.6, 0.8)).subtract().sphere((0.4, 0.3, -0.6), 0.7)
+        .union().sphere((-1.2, 0.2, 0.0), 0.5).smooth_union(0.3).box((0.9, -0.7, 0.2), (0.3, 0.3, 0.9))
+        .intersect().sphere((0, 0, 0), 1.6),
+        None,
+    ),
+    "mandelbulb": (lambda: S.Mandelbulb(), None),
+    "lattice": (lambda: S.sphere_lattice_example(), None),
+    "fractal1": (lambda: S.SphereGridFractal(), "fractal1.glsl"),
+    "menger": (lambda: S.MengerSponge(), "menger-sponge.glsl"),
+    "tree": (lambda: S.KifsTree(), "tree.glsl"),
+    "smooth_tree": (lambda: S.KifsTree(iterations=14.0, smoothen=True), "smooth-tree.glsl"),
+    "rotation_fractal": (lambda: S.KifsBox(), "rotation-fractal.glsl"),
+}
+
+# scenes whose SDF the oracle reproduces bit for bit (only + - * / sqrt floor
+# abs min max); the others go through sin/cos/acos/atan/pow/log where
+# SwiftShader and libm differ in the last bits (or much more: see test tolerances)
+SDF_BIT_EXACT = ("sphere", "csg64", "csg_mixed", "lattice", "fractal1")
+
+IMG_W, IMG_H = 64, 32
+
+# whole-main() image cases: name -> (scene name, samples, make_schema kwargs)
+IMAGES = {
+    "sphere_preview": ("sphere", 1, dict(render_mode="preview")),
+    "sphere_preview_rot": ("sphere", 1, dict(render_mode="preview", rotation=ROT, position=(1.0, 0.6, -2.7))),
+    "sphere_preview_focal": ("sphere", 1, dict(render_mode="preview", show_focused_area=True, dof_distance=2.2)),
+    "sphere_ortho": ("sphere", 1, dict(render_mode="preview", camera="orthographic", fov=3.0)),
+    "sphere_pano": ("sphere", 1, dict(render_mode="preview", camera="panoramic")),
+    "sphere_full": ("sphere", 1, dict(render_mode="full")),
+    "sphere_full_light": ("sphere", 1, dict(render_mode="full", lights=LIGHT)),
+    "sphere_full_3b_soft_4spp": ("sphere", 4, dict(render_mode="full", counts=(64, 32, 32), lights=SOFT_LIGHT)),
+    "sphere_full_dof_fog": ("sphere", 1, dict(render_mode="full", counts=(64, 32), dof_amount=0.05, dof_distance=2.0, fog_density=0.1, lights=LIGHT)),
+    "sphere_full_mix_2spp": ("sphere", 2, dict(render_mode="full", blend_mode="mix", lights=LIGHT)),
+    "sphere_preview_mix_2spp": ("sphere", 2, dict(render_mode="preview", blend_mode="mix", blend_factor=0.75)),
+    "csg64_full_light": ("csg64", 1, dict(render_mode="full", position=(0, 0, -5.0), counts=(48,), lights=LIGHT)),
+    "csg_mixed_full_2b": ("csg_mixed", 1, dict(render_mode="full", position=(0.3, 0.2, -4.0), counts=(48, 24), lights=LIGHT)),
+    "lattice_full_2b": ("lattice", 1, dict(render_mode="full", position=(0, 0, 0), counts=(64, 32))),
+    "fractal1_preview": ("fractal1", 1, dict(render_mode="preview", position=(0, 0, 0), counts=(64,))),
+    "fractal1_full_2b": ("fractal1", 1, dict(render_mode="full", position=(0, 0, 0), counts=(48, 24), lights=[J.point_light((0.0, 0.0, 4.0))])),
+    "mandelbulb_preview": ("mandelbulb", 1, dict(render_mode="preview", position=(0, 0, -2.5), counts=(64,))),
+    "mandelbulb_full_light": ("mandelbulb", 1, dict(render_mode="full", position=(0, 0, -2.5), counts=(64,), lights=LIGHT)),
+    "menger_preview": ("menger", 1, dict(render_mode="preview", position=(0.5, 0.5, -2.0), counts=(48,))),
+    "tree_preview": ("tree", 1, dict(render_mode="preview", position=(0, 0, -6.0), counts=(48,))),
+}
+
+# cast-ray goldens: scene -> (camera position, steps)
+CAST = {
+    "sphere": ((0, 0, -3.0), 128.0),
+    "csg64": ((0, 0, -5.0), 64.0),
+    "lattice": ((0.1, 0.2, 0.0), 64.0),
+    "fractal1": ((0, 0, 0), 64.0),
+    "mandelbulb": ((0, 0, -2.5), 64.0),
+    "menger": ((0.5, 0.5, -2.0), 48.0),
+}
+
+
+def build_scene(name: str):
+    return SCENES[name][0]()
+
+
+def image_schema(case: str):
+    scene_name, samples, kw = IMAGES[case]
+    sc = build_scene(scene_name)
+    schema = J.make_schema(sc, IMG_W, IMG_H, **kw)
+    return sc, samples, schema
+
+
+def halton_pairs(n: int):
+    h2, h3 = J.halton(2), J.halton(3)
+    return [(next(h2), next(h3)) for _ in range(n)]
+
+
+def sdf_points(n: int = 4096, seed: int = 7) -> np.ndarray:
+    rng = np.random.default_rng(seed)
+    p = rng.uniform(-2.5, 2.5, (n, 3)).astype(np.float32)
+    p[: n // 8] *= 0.3  # denser near the origin, inside the fractals
+    return p
+
+
+def camera_rays(position, w: int = 64, h: int = 32, fov: float = 1.5) -> np.ndarray:
+    """Unit directions through pixel centres (computed in float64, rounded
+    once): inputs for the cast-ray goldens, n x 6 (origin, dir)."""
+    ys, xs = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    px = ((xs + 0.5) / w * 2 - 1) * (w / h) * np.tan(fov / 2)
+    py = ((ys + 0.5) / h * 2 - 1) * np.tan(fov / 2)
+    d = np.stack([px, py, np.ones_like(px)], -1)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    o = np.broadcast_to(np.asarray(position, np.float64), d.shape)
+    return np.concatenate([o, d], -1).reshape(-1, 6).astype(np.float32)
