@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpixels/s of the sphere-tracing path on the Mandelbulb
+scene at 3840x2160 (BASELINE.json), one process per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one sample of every pixel of the frame (one run of the reference's
+main() per pixel: RenderJobExecutor.tsx:299) + the frame assembly on rank 0.
+With N GPUs the frame's rows are sharded (no exchange between samples; each
+pixel depends only on itself) and the colour plane is gathered
+to rank 0 over RCCL once per step, as the reference presents once per sample
+in its live loop (index.tsx:158-169).  Total work is fixed => strong scaling.
+
+Rank 0 prints ONE JSON line.  `roofline` is the fp32-VALU roofline of the
+pixel kernel (the path has no contraction, so no MFMA; HBM traffic is ~100 B
+per ~2e4 flops): achieved = algorithmic flops per launch / HIP-event kernel
+time.  `cpu_baseline` is the oracle (the CPU restatement, kind "port") on the
+host cores over a bounded sample of the same frame.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 128 lanes x 2 flop x 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+
+WORKLOADS = {
+    # C3b is the headline; the others are selectable for profiling
+    "c3b": dict(name="C3b mandelbulb(power 8, 8 iter, bailout 2) 3840x2160 full [256] 1 point light", scene="mandelbulb",
+                width=3840, height=2160, counts=(256,), mode="full", position=(0.0, 0.0, -2.5), light=True),
+    "c3a": dict(name="C3a mandelbulb 3840x2160 preview [256]", scene="mandelbulb", width=3840, height=2160, counts=(256,),
+                mode="preview", position=(0.0, 0.0, -2.5), light=False),
+    "c2": dict(name="C2 single sphere 1920x1080 preview [128]", scene="sphere", width=1920, height=1080, counts=(128,),
+               mode="preview", position=(0.0, 0.0, -3.0), light=False),
+    "c4": dict(name="C4 csg64 smooth-union 4096x4096 full [128] 1 light", scene="csg64", width=4096, height=4096, counts=(128,),
+               mode="full", position=(0.0, 0.0, -5.0), light=True),
+    "c5": dict(name="C5 csg64 8192x8192 full [128,64,64] soft light", scene="csg64", width=8192, height=8192, counts=(128, 64, 64),
+               mode="full", position=(0.0, 0.0, -5.0), light="soft"),
+}
+
+
+def make_workload(key):
+    from raymarching_engine_amd import job as J, scene as S
+
+    w = WORKLOADS[key]
+    sc = {"mandelbulb": S.Mandelbulb, "sphere": S.single_sphere, "csg64": S.csg64}[w["scene"]]()
+    lights = []
+    if w["light"]:
+        lights = [J.point_light((2.0, 3.0, -4.0), size=0.3 if w["light"] == "soft" else 0.0)]
+    schema = J.make_schema(sc, w["width"], w["height"], counts=w["counts"], render_mode=w["mode"], position=w["position"], lights=lights)
+    return w, sc, schema
+
+
+def shard_rows(height, world, rank):
+    """Contiguous row blocks: rank g holds rows [g*H/N, (g+1)*H/N)."""
+    b = [(height * i) // world for i in range(world + 1)]
+    return b[rank], b[rank + 1] - b[rank]
+
+
+def cpu_baseline(sc, schema, target_seconds=12.0):
+    """The oracle on the host cores over evenly spaced rows of the same frame."""
+    from oracle import oracle as O
+    from raymarching_engine_amd import job as J
+
+    O.build()
+    O.set_tan_mode(O.TAN_PORTABLE)
+    W, H = schema["render"]["width"], schema["render"]["height"]
+    u = J.uniforms_from_schema(schema, (0.5, 1.0 / 3.0))
+    cores = O.host_cores()
+
+    # one row per thread-chunk is too fine for OpenMP-over-rows: render bands of `cores` rows
+    def run_bands(starts, band, count=False):
+        t0 = time.perf_counter()
+        flops = 0
+        for y in starts:
+            fr = O.Frame(W, H, y, band)
+            flops += O.render(sc, u, fr, threads=cores, count_flops=count)
+        return time.perf_counter() - t0, flops
+
+    band = max(1, cores)
+    probe_starts = [int((H - band) * f) for f in (0.1, 0.5, 0.9)]
+    t_probe, _ = run_bands(probe_starts, band)
+    per_band = max(t_probe / len(probe_starts), 1e-4)
+    n = int(max(4, min((H // band), target_seconds / per_band)))
+    starts = [int((H - band) * (i + 0.5) / n) for i in range(n)]
+    t, _ = run_bands(starts, band)
+    px = n * band * W
+    # instrumented algorithmic flops per pixel-sample on a thinner sample of the same rows
+    _, flops = run_bands(starts[:: max(1, n // 12)], band, count=True)
+    flops_px = flops / (len(starts[:: max(1, n // 12)]) * band * W)
+    return {"value": px / t / 1e6, "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": f"{n} bands of {band} rows evenly spaced over the {W}x{H} frame ({px} pixel-samples, {t:.1f} s), oracle/rm_oracle.c with OpenMP"}, flops_px
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3b", choices=list(WORKLOADS))
+    ap.add_argument("--strict", action="store_true", help="parity build instead of the fast build")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    from raymarching_engine_amd import abi, job as J, native
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    wl, sc, schema = make_workload(args.workload)
+    W, H = wl["width"], wl["height"]
+    row_begin, row_count = shard_rows(H, world, rank)
+    flags = abi.RM_RENDER_STRICT if args.strict else abi.RM_RENDER_FAST
+
+    ctx = native.Context(local_rank)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # launches ordered with torch / RCCL work
+    planes = [torch.zeros((row_count, W, 4), dtype=torch.float32, device=dev) for _ in range(3)]
+    fb = ctx.wrap_framebuffer(W, H, row_begin, row_count, *(p.data_ptr() for p in planes))
+    scene = ctx.create_scene(sc)
+    frame = None
+    if world > 1 and rank == 0:
+        counts = [shard_rows(H, world, r)[1] for r in range(world)]
+        frame = [torch.empty((c, W, 4), dtype=torch.float32, device=dev) for c in counts]
+
+    h2, h3 = J.halton(2), J.halton(3)
+
+    def step():
+        u = J.uniforms_from_schema(schema, (next(h2), next(h3)))
+        ctx.render_sample(scene, fb, u, None, flags)
+        if world > 1:
+            dist.gather(planes[0], frame if rank == 0 else None, dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = W * H * args.steps / elapsed / 1e6
+
+    out = None
+    if rank == 0:
+        # kernel time of this rank's launch, HIP events on the launch stream
+        u = J.uniforms_from_schema(schema, (0.5, 1.0 / 3.0))
+        kernel_ms = ctx.render_timed(scene, fb, u, max(3, min(args.steps, 10)), None, flags)
+        cpu, flops_px = (None, None)
+        if world == 1 and not args.no_cpu_baseline:
+            cpu, flops_px = cpu_baseline(sc, schema)
+        nominal_px = {"c3b": 145.5e3, "c3a": 71.7e3, "c2": 2.2e3, "c4": 403e3, "c5": 817e3}[args.workload]
+        px_launch = row_count * W
+        roof = None
+        if flops_px is not None:
+            achieved = flops_px * px_launch / (kernel_ms * 1e-3) / 1e12
+            roof = {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+                    "flops_per_pixel_sample_instrumented": flops_px, "flops_per_pixel_sample_nominal": nominal_px,
+                    "frac_nominal": nominal_px * px_launch / (kernel_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
+                    "kernel_ms": kernel_ms, "pixels_per_launch": px_launch,
+                    "hbm_algorithmic_GBs": 96.0 * px_launch / (kernel_ms * 1e-3) / 1e9, "hbm_peak_GBs": PEAK_HBM_GBS}
+        out = {
+            "metric": "Mpixels/sec at 3840x2160 Mandelbulb" if args.workload in ("c3b", "c3a") else "Mpixels/sec",
+            "value": value, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl["name"], "build": "strict" if args.strict else "fast",
+                       "rows_per_gpu": row_count, "sharding": "contiguous row blocks, colour plane gathered to rank 0 per step" if world > 1 else "none",
+                       "planes": "color+normal_dof+albedo_depth fp32, accumulated in place"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+    fb.destroy()
+    scene.destroy()
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

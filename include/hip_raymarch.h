@@ -276,12 +276,6 @@ int rm_probe_camera(rm_ctx* ctx, const RmUniforms* uniforms, int width, int heig
  * out = height*width*count floats, HOST pointer. */
 int rm_probe_rng(rm_ctx* ctx, const RmUniforms* uniforms, int width, int height, int count, float* out);
 
-/* ---- present ----------------------------------------------------------- */
-
-/* Tone map of display.frag:20-64 (next-row N1): out = row_count*width RGBA8,
- * HOST pointer: colour * (1/samples), DoF-radius driven Gaussian blur, gamma 1/2.2. */
-int rm_present(rm_ctx* ctx, rm_fb* fb, int samples, uint8_t* out_rgba8);
-
 #ifdef __cplusplus
 }
 #endif

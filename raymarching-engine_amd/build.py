@@ -1,0 +1,62 @@
+"""Builds libhip_raymarch.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+CSRC = HERE / "csrc"
+OBJ = CSRC / "_obj"
+LIB = HERE / "libhip_raymarch.so"
+ARCH = "gfx950"
+
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# rm_strict: no FMA contraction (the parity build); rm_fast: contraction on.
+# Neither gets -fno-hip-fp32-correctly-rounded-divide-sqrt: plain '/' and
+# sqrtf stay IEEE in both (the random stream relies on it); the fast build
+# asks for v_rcp_f32 / v_sqrt_f32 explicitly where it wants them.
+UNITS = {
+    "rm_strict": ["-ffp-contract=off"],
+    "rm_fast": ["-ffp-contract=fast"],
+    "rm_api": [],
+}
+
+
+def hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _sources_mtime() -> float:
+    files = list(CSRC.glob("*.hip")) + list(CSRC.glob("*.hpp")) + list(CSRC.glob("*.inc")) + [HERE.parent / "include" / "hip_raymarch.h"]
+    return max(f.stat().st_mtime for f in files)
+
+
+def build_native(force: bool = False, verbose: bool = False, extra=()) -> Path:
+    if not force and LIB.exists() and LIB.stat().st_mtime >= _sources_mtime():
+        return LIB
+    OBJ.mkdir(exist_ok=True)
+    cc = hipcc()
+
+    def compile_unit(name):
+        cmd = [cc, *COMMON, *UNITS[name], *extra, "-c", str(CSRC / f"{name}.hip"), "-o", str(OBJ / f"{name}.o")]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        list(ex.map(compile_unit, UNITS))
+    cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", str(LIB)] + [str(OBJ / f"{n}.o") for n in UNITS]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_native(force="--force" in sys.argv, verbose=True))

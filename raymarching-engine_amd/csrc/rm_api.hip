@@ -1,0 +1,416 @@
+// rm_api.hip -- the C ABI of libhip_raymarch.so (include/hip_raymarch.h).
+//
+// Host side only: contexts, scene upload/validation, framebuffers and the
+// launches.  There is NO CPU path: without a GPU rm_ctx_create fails with
+// RM_ERR_NO_DEVICE and nothing else can be called.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/hip_raymarch.h"
+#include "rm_params.hpp"
+
+struct rm_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string error;
+};
+
+struct rm_scene {
+  rm_ctx* ctx = nullptr;
+  DevScene dev{};
+  RmPrim* d_prims = nullptr;
+};
+
+struct rm_fb {
+  rm_ctx* ctx = nullptr;
+  int width = 0, height = 0, row_begin = 0, row_count = 0;
+  float4* plane[3] = {nullptr, nullptr, nullptr};
+  bool owned = false;
+};
+
+static thread_local std::string g_create_error;
+
+static int fail(rm_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->error = msg;
+  else g_create_error = msg;
+  return code;
+}
+
+#define RM_HIP(ctx, expr)                                                                              \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess) return fail(ctx, RM_ERR_DEVICE, std::string(#expr ": ") + hipGetErrorString(e_)); \
+  } while (0)
+
+extern "C" {
+
+int rm_abi_version(void) { return RM_ABI_VERSION; }
+
+void rm_material_default(RmMaterial* m) {  // Validate.tsx:18-51
+  std::memset(m, 0, sizeof *m);
+  m->diffuse[0] = m->diffuse[1] = m->diffuse[2] = 0.6f;
+  m->diffuse_cutoff = 35.0f;
+  m->specular[0] = m->specular[1] = m->specular[2] = 0.6f;
+  m->specular_cutoff = 35.0f;
+  m->roughness = 0.2f;
+  m->subsurface = 11111115.0f;
+  m->subsurface_color[0] = m->subsurface_color[1] = m->subsurface_color[2] = 1.0f;
+  m->ior = 100.0f;
+  m->sky_color[0] = 0.7f;
+  m->sky_color[1] = 0.8f;
+  m->sky_color[2] = 1.0f;
+  m->sky_floor = 0.2f;
+  m->sky_scale = 2.0f;
+  m->sky_radius = 36.0f;
+  m->sky_axis = 1;
+}
+
+int rm_ctx_create(int device, rm_ctx** out) {
+  if (!out) return fail(nullptr, RM_ERR_INVALID, "rm_ctx_create: out is NULL");
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(nullptr, RM_ERR_NO_DEVICE, "no HIP device: libhip_raymarch has no CPU fallback (" +
+                                               std::string(e == hipSuccess ? "device count 0" : hipGetErrorString(e)) + ")");
+  if (device < 0 || device >= count) return fail(nullptr, RM_ERR_INVALID, "rm_ctx_create: device index out of range");
+  rm_ctx* ctx = new (std::nothrow) rm_ctx();
+  if (!ctx) return fail(nullptr, RM_ERR_DEVICE, "out of host memory");
+  ctx->device = device;
+  if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess) {
+    std::string msg = std::string("rm_ctx_create: ") + hipGetErrorString(e);
+    delete ctx;
+    return fail(nullptr, RM_ERR_DEVICE, msg);
+  }
+  ctx->stream = ctx->own_stream;
+  *out = ctx;
+  return RM_OK;
+}
+
+void rm_ctx_destroy(rm_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+const char* rm_last_error(const rm_ctx* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int rm_ctx_set_stream(rm_ctx* ctx, void* hip_stream) {
+  if (!ctx) return RM_ERR_INVALID;
+  ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  return RM_OK;
+}
+
+int rm_sync(rm_ctx* ctx) {
+  if (!ctx) return RM_ERR_INVALID;
+  RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RM_OK;
+}
+
+// ---- scene -------------------------------------------------------------------
+
+static bool finite_all(const float* p, int n) {
+  for (int i = 0; i < n; i++)
+    if (!std::isfinite(p[i])) return false;
+  return true;
+}
+
+int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out) {
+  if (!ctx || !desc || !out) return fail(ctx, RM_ERR_INVALID, "rm_scene_create: NULL argument");
+  *out = nullptr;
+  char buf[256];
+  // the analogue of the GLSL compile: reject what the kernels cannot run, with an "info log"
+  if (desc->kind < 0 || desc->kind >= RM_SCENE_KIND_COUNT) {
+    std::snprintf(buf, sizeof buf, "scene: unknown kind %d", desc->kind);
+    return fail(ctx, RM_ERR_INVALID, buf);
+  }
+  if (!finite_all(desc->params, 16)) return fail(ctx, RM_ERR_INVALID, "scene: non-finite parameter");
+  if (desc->material.sky_axis < 0 || desc->material.sky_axis > 2) return fail(ctx, RM_ERR_INVALID, "scene: material.sky_axis must be 0, 1 or 2");
+  if (desc->kind == RM_SCENE_TABLE) {
+    if (desc->nprims < 1 || desc->nprims > RM_MAX_PRIMS || !desc->prims) {
+      std::snprintf(buf, sizeof buf, "scene: primitive table needs 1..%d rows (got %d)", RM_MAX_PRIMS, desc->nprims);
+      return fail(ctx, RM_ERR_INVALID, buf);
+    }
+    for (int i = 0; i < desc->nprims; i++) {
+      const RmPrim& p = desc->prims[i];
+      const int type = p.type & 0xff, op = (p.type >> 8) & 0xff;
+      if ((type != RM_PRIM_SPHERE && type != RM_PRIM_BOX) || op > RM_OP_INTERSECT || (p.type >> 16) != 0) {
+        std::snprintf(buf, sizeof buf, "scene: row %d: unknown primitive/operator 0x%x", i, p.type);
+        return fail(ctx, RM_ERR_INVALID, buf);
+      }
+      if (!finite_all(p.center, 3) || !finite_all(p.size, 3) || !std::isfinite(p.k)) {
+        std::snprintf(buf, sizeof buf, "scene: row %d: non-finite value", i);
+        return fail(ctx, RM_ERR_INVALID, buf);
+      }
+      if (op == RM_OP_SMOOTH_UNION && !(p.k > 0.0f) && i > 0) {
+        std::snprintf(buf, sizeof buf, "scene: row %d: smooth union needs k > 0", i);
+        return fail(ctx, RM_ERR_INVALID, buf);
+      }
+    }
+  } else if (desc->kind == RM_SCENE_MANDELBULB) {
+    if (!(desc->params[RM_P_BULB_ITERATIONS] >= 0.0f && desc->params[RM_P_BULB_ITERATIONS] <= 64.0f))
+      return fail(ctx, RM_ERR_INVALID, "scene: mandelbulb iterations must be in 0..64");
+  }
+  rm_scene* s = new (std::nothrow) rm_scene();
+  if (!s) return fail(ctx, RM_ERR_DEVICE, "out of host memory");
+  s->ctx = ctx;
+  s->dev.kind = desc->kind;
+  s->dev.nprims = desc->kind == RM_SCENE_TABLE ? desc->nprims : 0;
+  std::memcpy(s->dev.p, desc->params, sizeof s->dev.p);
+  s->dev.mat = desc->material;
+  (void)hipSetDevice(ctx->device);
+  if (s->dev.nprims > 0) {
+    const size_t bytes = sizeof(RmPrim) * (size_t)s->dev.nprims;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_prims), bytes);
+    if (e == hipSuccess) e = hipMemcpy(s->d_prims, desc->prims, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      if (s->d_prims) (void)hipFree(s->d_prims);
+      delete s;
+      return fail(ctx, RM_ERR_DEVICE, std::string("rm_scene_create: ") + hipGetErrorString(e));
+    }
+    s->dev.prims = s->d_prims;
+  }
+  *out = s;
+  return RM_OK;
+}
+
+void rm_scene_destroy(rm_scene* scene) {
+  if (!scene) return;
+  (void)hipSetDevice(scene->ctx->device);
+  (void)hipStreamSynchronize(scene->ctx->stream);
+  if (scene->d_prims) (void)hipFree(scene->d_prims);
+  delete scene;
+}
+
+// ---- framebuffers --------------------------------------------------------------
+
+static int fb_check(rm_ctx* ctx, int width, int height, int row_begin, int row_count) {
+  if (width < 1 || height < 1 || width > 65536 || height > 65536) return fail(ctx, RM_ERR_INVALID, "framebuffer: size must be 1..65536");
+  if (row_begin < 0 || row_count < 1 || row_begin + row_count > height) return fail(ctx, RM_ERR_INVALID, "framebuffer: row window outside the image");
+  return RM_OK;
+}
+
+int rm_fb_create(rm_ctx* ctx, int width, int height, int row_begin, int row_count, rm_fb** out) {
+  if (!ctx || !out) return fail(ctx, RM_ERR_INVALID, "rm_fb_create: NULL argument");
+  *out = nullptr;
+  if (int rc = fb_check(ctx, width, height, row_begin, row_count)) return rc;
+  rm_fb* fb = new (std::nothrow) rm_fb();
+  if (!fb) return fail(ctx, RM_ERR_DEVICE, "out of host memory");
+  fb->ctx = ctx;
+  fb->width = width; fb->height = height; fb->row_begin = row_begin; fb->row_count = row_count;
+  fb->owned = true;
+  (void)hipSetDevice(ctx->device);
+  const size_t bytes = sizeof(float4) * (size_t)width * (size_t)row_count;
+  for (int i = 0; i < 3; i++) {
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&fb->plane[i]), bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(fb->plane[i], 0, bytes, ctx->stream);
+    if (e != hipSuccess) {
+      for (int j = 0; j <= i; j++)
+        if (fb->plane[j]) (void)hipFree(fb->plane[j]);
+      delete fb;
+      return fail(ctx, RM_ERR_DEVICE, std::string("rm_fb_create: ") + hipGetErrorString(e));
+    }
+  }
+  *out = fb;
+  return RM_OK;
+}
+
+int rm_fb_wrap(rm_ctx* ctx, int width, int height, int row_begin, int row_count, void* color, void* normal_dof,
+               void* albedo_depth, rm_fb** out) {
+  if (!ctx || !out || !color) return fail(ctx, RM_ERR_INVALID, "rm_fb_wrap: NULL argument");
+  *out = nullptr;
+  if (int rc = fb_check(ctx, width, height, row_begin, row_count)) return rc;
+  if ((normal_dof == nullptr) != (albedo_depth == nullptr)) return fail(ctx, RM_ERR_INVALID, "rm_fb_wrap: give both G-buffer planes or neither");
+  if ((reinterpret_cast<uintptr_t>(color) | reinterpret_cast<uintptr_t>(normal_dof) | reinterpret_cast<uintptr_t>(albedo_depth)) & 15u)
+    return fail(ctx, RM_ERR_INVALID, "rm_fb_wrap: planes must be 16-byte aligned");
+  rm_fb* fb = new (std::nothrow) rm_fb();
+  if (!fb) return fail(ctx, RM_ERR_DEVICE, "out of host memory");
+  fb->ctx = ctx;
+  fb->width = width; fb->height = height; fb->row_begin = row_begin; fb->row_count = row_count;
+  fb->plane[0] = static_cast<float4*>(color);
+  fb->plane[1] = static_cast<float4*>(normal_dof);
+  fb->plane[2] = static_cast<float4*>(albedo_depth);
+  fb->owned = false;
+  *out = fb;
+  return RM_OK;
+}
+
+int rm_fb_clear(rm_fb* fb) {
+  if (!fb) return RM_ERR_INVALID;
+  rm_ctx* ctx = fb->ctx;
+  const size_t bytes = sizeof(float4) * (size_t)fb->width * (size_t)fb->row_count;
+  for (int i = 0; i < 3; i++)
+    if (fb->plane[i]) RM_HIP(ctx, hipMemsetAsync(fb->plane[i], 0, bytes, ctx->stream));
+  return RM_OK;
+}
+
+void rm_fb_destroy(rm_fb* fb) {
+  if (!fb) return;
+  (void)hipSetDevice(fb->ctx->device);
+  (void)hipStreamSynchronize(fb->ctx->stream);
+  if (fb->owned)
+    for (int i = 0; i < 3; i++)
+      if (fb->plane[i]) (void)hipFree(fb->plane[i]);
+  delete fb;
+}
+
+int rm_fb_download(rm_fb* fb, int plane, float* host) {
+  if (!fb || !host || plane < 0 || plane > 2) return fb ? fail(fb->ctx, RM_ERR_INVALID, "rm_fb_download: bad argument") : RM_ERR_INVALID;
+  rm_ctx* ctx = fb->ctx;
+  if (!fb->plane[plane]) return fail(ctx, RM_ERR_INVALID, "rm_fb_download: this framebuffer has no such plane");
+  const size_t bytes = sizeof(float4) * (size_t)fb->width * (size_t)fb->row_count;
+  RM_HIP(ctx, hipMemcpyAsync(host, fb->plane[plane], bytes, hipMemcpyDeviceToHost, ctx->stream));
+  RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RM_OK;
+}
+
+int rm_fb_upload(rm_fb* fb, int plane, const float* host) {
+  if (!fb || !host || plane < 0 || plane > 2) return fb ? fail(fb->ctx, RM_ERR_INVALID, "rm_fb_upload: bad argument") : RM_ERR_INVALID;
+  rm_ctx* ctx = fb->ctx;
+  if (!fb->plane[plane]) return fail(ctx, RM_ERR_INVALID, "rm_fb_upload: this framebuffer has no such plane");
+  const size_t bytes = sizeof(float4) * (size_t)fb->width * (size_t)fb->row_count;
+  RM_HIP(ctx, hipMemcpyAsync(fb->plane[plane], host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RM_OK;
+}
+
+void* rm_fb_device_ptr(rm_fb* fb, int plane) { return (fb && plane >= 0 && plane <= 2) ? fb->plane[plane] : nullptr; }
+
+// ---- the hot path ---------------------------------------------------------------
+
+static int build_params(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* u, const RmRect* tile, int flags,
+                        KParams* P, bool* empty) {
+  if (!ctx || !scene || !fb || !u) return fail(ctx, RM_ERR_INVALID, "render: NULL argument");
+  if (scene->ctx != ctx || fb->ctx != ctx) return fail(ctx, RM_ERR_INVALID, "render: scene/framebuffer belong to another context");
+  if (u->renderMode != 0 && u->renderMode != 1) return fail(ctx, RM_ERR_INVALID, "render: renderMode must be 0 (full) or 1 (preview)");
+  if (!(u->reflections >= 0.0f && u->reflections <= (float)RM_MAX_BOUNCES)) return fail(ctx, RM_ERR_INVALID, "render: reflections must be in 0..10 (raymarchingStepCountsArray[10])");
+  if (u->lightCount < 0 || u->lightCount > RM_MAX_LIGHTS) return fail(ctx, RM_ERR_INVALID, "render: lightCount must be in 0..10");
+  const bool color_only = (flags & RM_RENDER_COLOR_ONLY) != 0;
+  if (!color_only && u->renderMode == 0 && (!fb->plane[1] || !fb->plane[2]))
+    return fail(ctx, RM_ERR_INVALID, "render: framebuffer has no G-buffer planes; pass RM_RENDER_COLOR_ONLY");
+  RmRect t = tile ? *tile : RmRect{0, 0, fb->width, fb->height};
+  // clip to the image and to this framebuffer's row window
+  int x0 = t.x < 0 ? 0 : t.x, y0 = t.y < fb->row_begin ? fb->row_begin : t.y;
+  int x1 = t.x + t.w > fb->width ? fb->width : t.x + t.w;
+  int y1 = t.y + t.h > fb->row_begin + fb->row_count ? fb->row_begin + fb->row_count : t.y + t.h;
+  *empty = x1 <= x0 || y1 <= y0;
+  P->u = *u;
+  P->scene = scene->dev;
+  P->color = fb->plane[0];
+  P->normal_dof = color_only ? nullptr : fb->plane[1];
+  P->albedo_depth = color_only ? nullptr : fb->plane[2];
+  P->W = fb->width; P->H = fb->height; P->row_begin = fb->row_begin;
+  P->tx = x0; P->ty = y0; P->tw = x1 - x0; P->th = y1 - y0;
+  P->retire_eps = 0.0f;
+  return RM_OK;
+}
+
+static hipError_t launch(const KParams& P, int flags, hipStream_t stream) {
+  return (flags & RM_RENDER_FAST) ? rm_fast::launch_pixels(P, stream) : rm_strict::launch_pixels(P, stream);
+}
+
+int rm_render_sample(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* uniforms, const RmRect* tile, int flags) {
+  KParams P;
+  bool empty = false;
+  if (int rc = build_params(ctx, scene, fb, uniforms, tile, flags, &P, &empty)) return rc;
+  if (empty) return RM_OK;
+  RM_HIP(ctx, hipSetDevice(ctx->device));
+  RM_HIP(ctx, launch(P, flags, ctx->stream));
+  return RM_OK;
+}
+
+int rm_render_samples(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* uniforms, const float* rand_noise_pairs,
+                      int count, const RmRect* tile, int flags) {
+  KParams P;
+  bool empty = false;
+  if (int rc = build_params(ctx, scene, fb, uniforms, tile, flags, &P, &empty)) return rc;
+  if (count < 0 || (count > 0 && !rand_noise_pairs)) return fail(ctx, RM_ERR_INVALID, "rm_render_samples: bad count / NULL randNoise");
+  if (empty) return RM_OK;
+  RM_HIP(ctx, hipSetDevice(ctx->device));
+  for (int i = 0; i < count; i++) {
+    P.u.randNoise[0] = rand_noise_pairs[2 * i];
+    P.u.randNoise[1] = rand_noise_pairs[2 * i + 1];
+    RM_HIP(ctx, launch(P, flags, ctx->stream));
+  }
+  return RM_OK;
+}
+
+int rm_render_timed(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* uniforms, int count, const RmRect* tile,
+                    int flags, float* ms_per_launch) {
+  KParams P;
+  bool empty = false;
+  if (int rc = build_params(ctx, scene, fb, uniforms, tile, flags, &P, &empty)) return rc;
+  if (count < 1 || !ms_per_launch) return fail(ctx, RM_ERR_INVALID, "rm_render_timed: bad count / NULL result");
+  if (empty) return fail(ctx, RM_ERR_INVALID, "rm_render_timed: empty tile");
+  RM_HIP(ctx, hipSetDevice(ctx->device));
+  RM_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  for (int i = 0; i < count; i++) RM_HIP(ctx, launch(P, flags, ctx->stream));
+  RM_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  RM_HIP(ctx, hipEventSynchronize(ctx->ev1));
+  float ms = 0.0f;
+  RM_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  *ms_per_launch = ms / (float)count;
+  return RM_OK;
+}
+
+// ---- probes ----------------------------------------------------------------------
+
+int rm_probe(rm_ctx* ctx, rm_scene* scene, int what, const float* in, int n, float param, int flags, float* out) {
+  if (!ctx || !scene || !in || !out) return fail(ctx, RM_ERR_INVALID, "rm_probe: NULL argument");
+  if (what < RM_PROBE_SDF || what > RM_PROBE_MATERIAL) return fail(ctx, RM_ERR_INVALID, "rm_probe: unknown probe");
+  if (n <= 0) return RM_OK;
+  static const int in_w[4] = {3, 6, 3, 3}, out_w[4] = {1, 3, 3, 12};
+  RM_HIP(ctx, hipSetDevice(ctx->device));
+  float *d_in = nullptr, *d_out = nullptr;
+  const size_t in_bytes = sizeof(float) * (size_t)in_w[what] * (size_t)n, out_bytes = sizeof(float) * (size_t)out_w[what] * (size_t)n;
+  RM_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&d_in), in_bytes));
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_out), out_bytes);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    ProbeParams P{scene->dev, d_in, d_out, n, what, param};
+    e = (flags & RM_RENDER_FAST) ? rm_fast::launch_probe(P, ctx->stream) : rm_strict::launch_probe(P, ctx->stream);
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_in);
+  if (d_out) (void)hipFree(d_out);
+  if (e != hipSuccess) return fail(ctx, RM_ERR_DEVICE, std::string("rm_probe: ") + hipGetErrorString(e));
+  return RM_OK;
+}
+
+static int camera_rng(rm_ctx* ctx, const RmUniforms* u, int width, int height, int what, int count, float* out) {
+  if (!ctx || !u || !out || width < 1 || height < 1 || count < 1) return fail(ctx, RM_ERR_INVALID, "probe: bad argument");
+  RM_HIP(ctx, hipSetDevice(ctx->device));
+  float* d_out = nullptr;
+  const size_t bytes = sizeof(float) * (size_t)width * (size_t)height * (size_t)(what == 1 ? count : 8);
+  RM_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&d_out), bytes));
+  hipError_t e = rm_strict::launch_camera_rng(*u, width, height, what, count, d_out, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_out);
+  if (e != hipSuccess) return fail(ctx, RM_ERR_DEVICE, std::string("probe: ") + hipGetErrorString(e));
+  return RM_OK;
+}
+
+int rm_probe_camera(rm_ctx* ctx, const RmUniforms* uniforms, int width, int height, float* out) {
+  return camera_rng(ctx, uniforms, width, height, 0, 1, out);
+}
+
+int rm_probe_rng(rm_ctx* ctx, const RmUniforms* uniforms, int width, int height, int count, float* out) {
+  return camera_rng(ctx, uniforms, width, height, 1, count, out);
+}
+
+}  // extern "C"

@@ -1,0 +1,204 @@
+"""ctypes binding of libhip_raymarch.so (include/hip_raymarch.h).
+
+The library is the product's compute path.  If it is missing this module
+raises: there is no Python or CPU fallback for rendering.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+
+from . import abi
+from .scene import Scene
+
+LIB_PATH = Path(__file__).resolve().parent / "libhip_raymarch.so"
+
+# every symbol include/hip_raymarch.h declares
+EXPORTS = [
+    "rm_abi_version", "rm_material_default", "rm_ctx_create", "rm_ctx_destroy", "rm_last_error", "rm_ctx_set_stream",
+    "rm_sync", "rm_scene_create", "rm_scene_destroy", "rm_fb_create", "rm_fb_wrap", "rm_fb_clear", "rm_fb_destroy",
+    "rm_fb_download", "rm_fb_upload", "rm_fb_device_ptr", "rm_render_sample", "rm_render_samples", "rm_render_timed",
+    "rm_probe", "rm_probe_camera", "rm_probe_rng",
+]
+
+
+class RmError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(message)
+        self.code = code
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the HIP library (loading needs no GPU; creating a context does)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RmError(abi.RM_ERR_DEVICE, f"{LIB_PATH} is missing: build it with `python raymarching-engine_amd/build.py` "
+                                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(str(LIB_PATH))
+    vp, fp, ip = C.c_void_p, C.POINTER(C.c_float), C.c_int
+    sig = {
+        "rm_abi_version": (ip, []),
+        "rm_material_default": (None, [C.POINTER(abi.RmMaterial)]),
+        "rm_ctx_create": (ip, [ip, C.POINTER(vp)]),
+        "rm_ctx_destroy": (None, [vp]),
+        "rm_last_error": (C.c_char_p, [vp]),
+        "rm_ctx_set_stream": (ip, [vp, vp]),
+        "rm_sync": (ip, [vp]),
+        "rm_scene_create": (ip, [vp, C.POINTER(abi.RmSceneDesc), C.POINTER(vp)]),
+        "rm_scene_destroy": (None, [vp]),
+        "rm_fb_create": (ip, [vp, ip, ip, ip, ip, C.POINTER(vp)]),
+        "rm_fb_wrap": (ip, [vp, ip, ip, ip, ip, vp, vp, vp, C.POINTER(vp)]),
+        "rm_fb_clear": (ip, [vp]),
+        "rm_fb_destroy": (None, [vp]),
+        "rm_fb_download": (ip, [vp, ip, fp]),
+        "rm_fb_upload": (ip, [vp, ip, fp]),
+        "rm_fb_device_ptr": (vp, [vp, ip]),
+        "rm_render_sample": (ip, [vp, vp, vp, C.POINTER(abi.RmUniforms), C.POINTER(abi.RmRect), ip]),
+        "rm_render_samples": (ip, [vp, vp, vp, C.POINTER(abi.RmUniforms), fp, ip, C.POINTER(abi.RmRect), ip]),
+        "rm_render_timed": (ip, [vp, vp, vp, C.POINTER(abi.RmUniforms), ip, C.POINTER(abi.RmRect), ip, fp]),
+        "rm_probe": (ip, [vp, vp, ip, fp, ip, C.c_float, ip, fp]),
+        "rm_probe_camera": (ip, [vp, C.POINTER(abi.RmUniforms), ip, ip, fp]),
+        "rm_probe_rng": (ip, [vp, C.POINTER(abi.RmUniforms), ip, ip, ip, fp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def scene_key(scene: Scene) -> bytes:
+    """Cache key of a scene description (the reference keys its program cache
+    by the source string, ShaderCache.tsx:91-119)."""
+    d = scene.desc()
+    prims = bytes(C.string_at(d.prims, C.sizeof(abi.RmPrim) * d.nprims)) if d.nprims else b""
+    return bytes([d.kind & 0xFF]) + bytes(d.params) + bytes(d.material) + prims
+
+
+def _fp(a: np.ndarray):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class Context:
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.rm_ctx_create(device, C.byref(h))
+        if rc != abi.RM_OK:
+            raise RmError(rc, self.lib.rm_last_error(None).decode())
+        self.h = h
+        self.device = device
+
+    def _check(self, rc: int):
+        if rc != abi.RM_OK:
+            raise RmError(rc, self.lib.rm_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.lib.rm_ctx_destroy(self.h)
+            self.h = None
+
+    def set_stream(self, hip_stream: Optional[int]):
+        self._check(self.lib.rm_ctx_set_stream(self.h, C.c_void_p(hip_stream or 0)))
+
+    def sync(self):
+        self._check(self.lib.rm_sync(self.h))
+
+    def create_scene(self, scene: Scene) -> "SceneHandle":
+        return SceneHandle(self, scene)
+
+    def create_framebuffer(self, width: int, height: int, row_begin: int = 0, row_count: Optional[int] = None) -> "Framebuffer":
+        return Framebuffer(self, width, height, row_begin, height if row_count is None else row_count)
+
+    def wrap_framebuffer(self, width, height, row_begin, row_count, color_ptr, normal_ptr=None, albedo_ptr=None) -> "Framebuffer":
+        return Framebuffer(self, width, height, row_begin, row_count, wrap=(color_ptr, normal_ptr, albedo_ptr))
+
+    def render_sample(self, scene: "SceneHandle", fb: "Framebuffer", uniforms: abi.RmUniforms, tile: Optional[abi.RmRect] = None,
+                      flags: int = abi.RM_RENDER_STRICT):
+        self._check(self.lib.rm_render_sample(self.h, scene.h, fb.h, C.byref(uniforms), C.byref(tile) if tile is not None else None, flags))
+
+    def render_samples(self, scene, fb, uniforms, rand_noise_pairs, tile=None, flags=abi.RM_RENDER_STRICT):
+        rn = np.ascontiguousarray(rand_noise_pairs, np.float32).reshape(-1, 2)
+        self._check(self.lib.rm_render_samples(self.h, scene.h, fb.h, C.byref(uniforms), _fp(rn), len(rn),
+                                               C.byref(tile) if tile is not None else None, flags))
+
+    def render_timed(self, scene, fb, uniforms, count: int, tile=None, flags=abi.RM_RENDER_STRICT) -> float:
+        ms = C.c_float(0.0)
+        self._check(self.lib.rm_render_timed(self.h, scene.h, fb.h, C.byref(uniforms), count,
+                                             C.byref(tile) if tile is not None else None, flags, C.byref(ms)))
+        return float(ms.value)
+
+    def probe(self, scene: "SceneHandle", what: int, inputs: np.ndarray, param: float = 0.0, flags: int = abi.RM_RENDER_STRICT) -> np.ndarray:
+        in_w = {abi.RM_PROBE_SDF: 3, abi.RM_PROBE_CAST_RAY: 6, abi.RM_PROBE_NORMAL: 3, abi.RM_PROBE_MATERIAL: 3}[what]
+        out_w = {abi.RM_PROBE_SDF: 1, abi.RM_PROBE_CAST_RAY: 3, abi.RM_PROBE_NORMAL: 3, abi.RM_PROBE_MATERIAL: 12}[what]
+        a = np.ascontiguousarray(inputs, np.float32).reshape(-1, in_w)
+        out = np.empty((len(a), out_w), np.float32)
+        self._check(self.lib.rm_probe(self.h, scene.h, what, _fp(a), len(a), float(param), flags, _fp(out)))
+        return out[:, 0] if out_w == 1 else out
+
+    def probe_camera(self, uniforms: abi.RmUniforms, width: int, height: int) -> np.ndarray:
+        out = np.empty((height, width, 8), np.float32)
+        self._check(self.lib.rm_probe_camera(self.h, C.byref(uniforms), width, height, _fp(out)))
+        return out
+
+    def probe_rng(self, uniforms: abi.RmUniforms, width: int, height: int, count: int) -> np.ndarray:
+        out = np.empty((height, width, count), np.float32)
+        self._check(self.lib.rm_probe_rng(self.h, C.byref(uniforms), width, height, count, _fp(out)))
+        return out
+
+
+class SceneHandle:
+    def __init__(self, ctx: Context, scene: Scene):
+        self.ctx = ctx
+        desc = scene.desc()
+        h = C.c_void_p()
+        ctx._check(ctx.lib.rm_scene_create(ctx.h, C.byref(desc), C.byref(h)))
+        self.h = h
+
+    def destroy(self):
+        if self.h:
+            self.ctx.lib.rm_scene_destroy(self.h)
+            self.h = None
+
+
+class Framebuffer:
+    def __init__(self, ctx: Context, width, height, row_begin, row_count, wrap=None):
+        self.ctx = ctx
+        self.width, self.height, self.row_begin, self.row_count = width, height, row_begin, row_count
+        h = C.c_void_p()
+        if wrap is None:
+            ctx._check(ctx.lib.rm_fb_create(ctx.h, width, height, row_begin, row_count, C.byref(h)))
+        else:
+            ctx._check(ctx.lib.rm_fb_wrap(ctx.h, width, height, row_begin, row_count, C.c_void_p(wrap[0]),
+                                          C.c_void_p(wrap[1] or 0), C.c_void_p(wrap[2] or 0), C.byref(h)))
+        self.h = h
+
+    def clear(self):
+        self.ctx._check(self.ctx.lib.rm_fb_clear(self.h))
+
+    def destroy(self):
+        if self.h:
+            self.ctx.lib.rm_fb_destroy(self.h)
+            self.h = None
+
+    def download(self, plane: int = abi.RM_PLANE_COLOR) -> np.ndarray:
+        out = np.empty((self.row_count, self.width, 4), np.float32)
+        self.ctx._check(self.ctx.lib.rm_fb_download(self.h, plane, _fp(out)))
+        return out
+
+    def upload(self, plane: int, data: np.ndarray):
+        a = np.ascontiguousarray(data, np.float32)
+        assert a.shape == (self.row_count, self.width, 4)
+        self.ctx._check(self.ctx.lib.rm_fb_upload(self.h, plane, _fp(a)))
+
+    def device_ptr(self, plane: int = abi.RM_PLANE_COLOR) -> int:
+        return int(self.ctx.lib.rm_fb_device_ptr(self.h, plane) or 0)

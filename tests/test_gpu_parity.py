@@ -1,0 +1,330 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the
+committed goldens.  All of these need a real MI355X: run with -m gpu.
+
+Bars:
+  * bit-exact: the random stream, texcoord, the camera block, and every scene
+    whose SDF is + - * / sqrt floor abs min max only (strict build);
+  * scenes through pow/sin/cos/acos/atan/log: ocml and libm are both ~1 ulp
+    libraries but not the same bits, so a stated tolerance;
+  * whole images: fraction of pixels whose relative difference exceeds 1e-5
+    (a last-bit difference at a silhouette or a branch pick is a different
+    pixel), plus bit-exact invariances at full size.
+"""
+import numpy as np
+import pytest
+
+import golden_cases as GC
+from oracle import oracle as O
+from raymarching_engine_amd import abi
+from raymarching_engine_amd import job as J
+from raymarching_engine_amd import scene as S
+
+pytestmark = pytest.mark.gpu
+
+GOLD = GC.__file__.rsplit("/", 1)[0] + "/golden/"
+STRICT, FAST = abi.RM_RENDER_STRICT, abi.RM_RENDER_FAST
+
+
+def load(name):
+    return np.load(GOLD + name + ".npz")
+
+
+def same_bits(a, b):
+    a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    return (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+
+
+def rel_diff(ref, got):
+    with np.errstate(invalid="ignore"):
+        d = np.abs(ref - got) / np.maximum(1.0, np.abs(ref))
+    d[same_bits(ref, got)] = 0.0
+    d[np.isnan(d)] = np.inf
+    return d
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from raymarching_engine_amd import native
+
+    c = native.Context(0)
+    O.set_tan_mode(O.TAN_PORTABLE)
+    yield c
+    c.close()
+
+
+def render_gpu(ctx, sc, schema, noises, flags=STRICT, rows=None, tile=None):
+    r = schema["render"]
+    h = ctx.create_scene(sc)
+    rb, rc = rows if rows else (0, r["height"])
+    fb = ctx.create_framebuffer(r["width"], r["height"], rb, rc)
+    for n in noises:
+        ctx.render_sample(h, fb, J.uniforms_from_schema(schema, tuple(n)), tile, flags)
+    out = [fb.download(p) for p in (0, 1, 2)]
+    fb.destroy()
+    h.destroy()
+    return out
+
+
+def render_oracle(sc, schema, noises, nan_mode=O.NAN_IEEE, rows=None, tile=None):
+    r = schema["render"]
+    rb, rc = rows if rows else (0, r["height"])
+    fr = O.Frame(r["width"], r["height"], rb, rc)
+    for n in noises:
+        O.render(sc, J.uniforms_from_schema(schema, tuple(n)), fr, tile=tile, nan_mode=nan_mode, threads=O.host_cores())
+    return [fr.color, fr.normal_dof, fr.albedo_depth]
+
+
+# ---- building blocks ----------------------------------------------------------
+
+
+@pytest.mark.parametrize("name", ["rng_32x32", "rng_24x16"])
+def test_rng_stream_bits(ctx, name):
+    z = load(name)
+    h, w = z["uniform4"].shape[:2]
+    u = J.uniforms_from_schema(J.make_schema(GC.build_scene("sphere"), w, h), tuple(z["rand_noise"]))
+    got = ctx.probe_rng(u, w, h, 4)
+    assert same_bits(got, O.rng(u, w, h, 4)).all()  # any size: same definition of texcoord
+    if name == "rng_32x32":
+        assert same_bits(got, z["uniform4"]).all()  # the reference's GLSL itself
+
+
+def test_rng_stream_bits_4k(ctx):
+    u = J.uniforms_from_schema(J.make_schema(GC.build_scene("sphere"), 3840, 2160), (0.625, 4.0 / 9.0))
+    got = ctx.probe_rng(u, 3840, 16, 3)  # rows 0..15 of a 3840-wide image (texcoord.y differs: H=16 here)
+    assert same_bits(got, O.rng(u, 3840, 16, 3)).all()
+
+
+@pytest.mark.parametrize("mode", ["perspective", "orthographic", "panoramic"])
+def test_camera_block(ctx, mode):
+    schema = J.make_schema(GC.build_scene("sphere"), 240, 135, camera=mode, rotation=GC.ROT, position=(0.3, -0.2, -3.0), dof_distance=2.5)
+    u = J.uniforms_from_schema(schema, (0.5, 1 / 3))
+    got, want = ctx.probe_camera(u, 240, 135), O.camera(u, 240, 135)
+    if mode == "panoramic":  # sin/cos: ocml vs libm
+        assert np.abs(got - want).max() <= 5e-7
+    else:
+        assert same_bits(got, want).all()
+
+
+@pytest.mark.parametrize("name", list(GC.SCENES))
+def test_sdf_probe(ctx, name):
+    z = load("sdf_" + name)
+    sc = GC.build_scene(name)
+    h = ctx.create_scene(sc)
+    got = ctx.probe(h, abi.RM_PROBE_SDF, z["points"])
+    want = O.eval_sdf(sc, z["points"])
+    if name in ("sphere", "csg64", "csg_mixed", "lattice"):
+        assert same_bits(got, want).all()
+        assert same_bits(got, z["sdf"]).all()  # = the reference GLSL's bits
+    else:
+        d = np.abs(got - want)
+        p99, mx = {"mandelbulb": (2e-6, 2e-4)}.get(name, (1e-6, 4e-6))
+        assert np.percentile(d, 99) <= p99 and d.max() <= mx
+    # fast build: hardware-rate divide/sqrt/transcendentals
+    fast = ctx.probe(h, abi.RM_PROBE_SDF, z["points"], flags=FAST)
+    d = np.abs(fast - want) / np.maximum(1.0, np.abs(want))
+    assert np.percentile(d, 99) <= {"mandelbulb": 2e-4}.get(name, 2e-5)
+    h.destroy()
+
+
+@pytest.mark.parametrize("name", list(GC.CAST))
+def test_cast_ray_and_normal_probe(ctx, name):
+    z = load("cast_" + name)
+    sc = GC.build_scene(name)
+    h = ctx.create_scene(sc)
+    steps = float(z["steps"])
+    got = ctx.probe(h, abi.RM_PROBE_CAST_RAY, z["rays"], steps)
+    want = O.cast_ray(sc, z["rays"], steps)
+    n_got = ctx.probe(h, abi.RM_PROBE_NORMAL, z["normal_points"], 1e-5)
+    n_want = O.normal(sc, z["normal_points"], 1e-5)
+    if name in ("sphere", "csg64", "lattice"):
+        assert same_bits(got, want).all() and same_bits(got, z["end"]).all()
+        assert same_bits(n_got, n_want).all()
+    else:
+        fin = np.isfinite(want).all(1)
+        assert np.mean(fin == np.isfinite(got).all(1)) >= 0.999
+        d = rel_diff(want[fin], got[fin]).max(1)
+        assert np.percentile(d, 95) <= {"mandelbulb": 2e-2}.get(name, 1e-5)
+    h.destroy()
+
+
+def test_material_probe(ctx):
+    for name in ("sphere", "lattice"):
+        z = load("misc_material_" + name)
+        sc = GC.build_scene(name)
+        h = ctx.create_scene(sc)
+        got = ctx.probe(h, abi.RM_PROBE_MATERIAL, z["points"])
+        assert same_bits(got, O.material(sc, z["points"])).all()
+        assert same_bits(got[:, 0:3], z["diffuse"]).all() and np.allclose(got[:, 6:9], z["emission"], rtol=1e-6, atol=0)
+        h.destroy()
+
+
+# ---- whole main() -------------------------------------------------------------
+
+# fraction of pixels allowed to differ by more than 1e-5 from the oracle (strict build)
+IMAGE_BARS = {"mandelbulb_preview": 0.03, "mandelbulb_full_light": 0.08, "fractal1_full_2b": 0.05, "tree_preview": 0.02,
+              "sphere_full_dof_fog": 0.02, "csg_mixed_full_2b": 0.02}
+
+
+@pytest.mark.parametrize("case", list(GC.IMAGES))
+def test_whole_main_image_vs_oracle(ctx, case):
+    sc, samples, schema = GC.image_schema(case)
+    z = load("image_" + case)
+    noises = z["rand_noise"]
+    got = render_gpu(ctx, sc, schema, noises)
+    want = render_oracle(sc, schema, noises, nan_mode=O.NAN_IEEE)
+    full = schema["render"]["renderMode"] == "full"
+    bar = IMAGE_BARS.get(case, 0.005)
+    for k in range(3 if full else 1):
+        d = rel_diff(want[k], got[k]).max(-1)
+        assert np.mean(d > 1e-5) <= bar, f"plane {k}: {np.mean(d > 1e-5):.4f} of pixels differ from the oracle"
+    # against the reference GLSL itself (x86 NaN convention there): where its pixels are finite
+    ref = z["color"]
+    fin = np.isfinite(ref).all(-1) & np.isfinite(got[0]).all(-1)
+    d = rel_diff(ref, got[0]).max(-1)[fin]
+    bar_ref = {"mandelbulb_preview": 0.03, "mandelbulb_full_light": 0.08, "fractal1_full_2b": 0.06, "tree_preview": 0.02,
+               "sphere_full_dof_fog": 0.03, "csg_mixed_full_2b": 0.03}.get(case, 0.01)
+    assert np.mean(d > 1e-5) <= bar_ref, f"{np.mean(d > 1e-5):.4f} of pixels differ from the reference GLSL"
+
+
+@pytest.mark.parametrize("case", ["sphere_full_light", "csg64_full_light", "mandelbulb_full_light", "fractal1_preview", "lattice_full_2b"])
+def test_fast_build_close_to_strict(ctx, case):
+    """RM_RENDER_FAST: same random stream (bit-exact RNG), hardware-rate math.
+    Bar: >= 90 % of pixels within 1e-3 relative of the strict build (the rest
+    are last-bit-induced branch/silhouette flips), and the image mean within 1 %."""
+    sc, samples, schema = GC.image_schema(case)
+    noises = load("image_" + case)["rand_noise"]
+    a = render_gpu(ctx, sc, schema, noises, STRICT)[0]
+    b = render_gpu(ctx, sc, schema, noises, FAST)[0]
+    d = rel_diff(a, b).max(-1)
+    assert np.mean(d <= 1e-3) >= 0.90
+    fin = np.isfinite(a).all(-1) & np.isfinite(b).all(-1)
+    assert abs(a[fin][:, :3].mean() - b[fin][:, :3].mean()) <= 0.01 * max(1e-6, abs(a[fin][:, :3].mean()))
+
+
+# ---- full-size properties (BASELINE.json sizes) -----------------------------------
+
+
+def _c3b(width=3840, height=2160, counts=(256,)):
+    sc = S.Mandelbulb()
+    schema = J.make_schema(sc, width, height, counts=counts, render_mode="full", position=(0, 0, -2.5), lights=GC.LIGHT)
+    return sc, schema
+
+
+@pytest.mark.parametrize("flags", [STRICT, FAST])
+def test_c3b_crop_matches_oracle(ctx, flags):
+    """Headline config (Mandelbulb 3840x2160, full, [256], 1 light): a 64x32
+    crop through the fractal's silhouette rendered with global coordinates,
+    against the oracle on the same pixels."""
+    sc, schema = _c3b()
+    tile = abi.RmRect(1888, 1064, 64, 32)
+    noises = GC.halton_pairs(1)
+    got = render_gpu(ctx, sc, schema, noises, flags, rows=(1064, 32), tile=tile)[0][:, 1888:1952]
+    want = render_oracle(sc, schema, noises, rows=(1064, 32), tile=(1888, 1064, 64, 32))[0][:, 1888:1952]
+    d = rel_diff(want, got).max(-1)
+    assert np.mean(d > 1e-3) <= (0.10 if flags == STRICT else 0.20)
+    assert np.array_equal(got[..., 3], want[..., 3])
+
+
+def test_full_size_invariances(ctx):
+    """At 3840x2160 (fast build, the benchmarked configuration): (1) the same
+    inputs give the same bits; (2) two row windows (what two GPUs would hold)
+    equal the single-frame render bit for bit; (3) a tiled render
+    (`subdivisions`) equals the untiled one; (4) alpha counts samples."""
+    sc, schema = _c3b(counts=(48,))
+    noises = GC.halton_pairs(2)
+    flags = FAST | abi.RM_RENDER_COLOR_ONLY
+    a = render_gpu(ctx, sc, schema, noises, flags)[0]
+    b = render_gpu(ctx, sc, schema, noises, flags)[0]
+    assert same_bits(a, b).all()
+    top = render_gpu(ctx, sc, schema, noises, flags, rows=(1080, 1080))[0]
+    bot = render_gpu(ctx, sc, schema, noises, flags, rows=(0, 1080))[0]
+    assert same_bits(np.concatenate([bot, top], 0), a).all()
+    h = ctx.create_scene(sc)
+    fb = ctx.create_framebuffer(3840, 2160)
+    sub = dict(schema)
+    sub["render"] = dict(schema["render"], subdivisions=3)
+    for n in noises:
+        for yp in range(3):
+            for xp in range(3):
+                ctx.render_sample(h, fb, J.uniforms_from_schema(schema, n), J.tile_rect(sub, xp, yp), flags)
+    assert same_bits(fb.download(0), a).all()
+    assert np.array_equal(a[..., 3], np.full(a.shape[:2], 2.0, np.float32))
+    fb.destroy()
+    h.destroy()
+
+
+def test_c4_c5_configs_run_and_match_on_a_crop(ctx):
+    """BASELINE.json configs[3]/[4] (64-primitive smooth-union CSG, soft shadow
+    + 3 bounces): one row window as a GPU of an 8-way split would hold it."""
+    sc = S.csg64()
+    for (w, h, counts, light) in ((4096, 4096, (128,), GC.LIGHT), (8192, 8192, (128, 64, 64), GC.SOFT_LIGHT)):
+        schema = J.make_schema(sc, w, h, counts=counts, render_mode="full", position=(0, 0, -5.0), lights=light)
+        rows = (h // 2, 16)
+        tile = abi.RmRect(w // 2 - 32, h // 2, 64, 16)
+        noises = GC.halton_pairs(1)
+        got = render_gpu(ctx, sc, schema, noises, STRICT, rows=rows, tile=tile)[0][:, w // 2 - 32 : w // 2 + 32]
+        want = render_oracle(sc, schema, noises, rows=rows, tile=(w // 2 - 32, h // 2, 64, 16))[0][:, w // 2 - 32 : w // 2 + 32]
+        d = rel_diff(want, got).max(-1)
+        assert np.mean(d > 1e-5) <= 0.03
+
+
+# ---- boundary behaviour -----------------------------------------------------------
+
+
+def test_errors_are_values(ctx):
+    from raymarching_engine_amd import native
+
+    bad = S.CsgScene().smooth_union(-1.0).sphere((0, 0, 0), 1).sphere((1, 0, 0), 1)
+    with pytest.raises(native.RmError) as e:
+        ctx.create_scene(bad)
+    assert e.value.code == abi.RM_ERR_INVALID and "smooth union" in str(e.value)
+    with pytest.raises(native.RmError):
+        ctx.create_framebuffer(64, 64, 60, 8)
+    sc = GC.build_scene("sphere")
+    h = ctx.create_scene(sc)
+    fb = ctx.create_framebuffer(32, 32)
+    u = J.uniforms_from_schema(J.make_schema(sc, 32, 32), (0.5, 1 / 3))
+    u.lightCount = 11
+    with pytest.raises(native.RmError):
+        ctx.render_sample(h, fb, u)
+    # empty / out-of-window tiles are no-ops
+    u.lightCount = 0
+    ctx.render_sample(h, fb, u, abi.RmRect(40, 40, 8, 8))
+    ctx.render_sample(h, fb, u, abi.RmRect(0, 0, 0, 0))
+    assert not fb.download(0).any()
+    fb.destroy()
+    h.destroy()
+
+
+def test_do_render_job_generator_semantics(ctx):
+    """doRenderJob (RenderJobExecutor.tsx:77-341): yields every
+    sampleYieldInterval samples, presents, keeps accumulating under one
+    frameid, clears on a new one, returns errors as values."""
+    J.reset_halton()
+    jc = J.RenderJobContext(0)
+    sc = GC.build_scene("sphere")
+    schema = J.make_schema(sc, 64, 32, render_mode="full", samples_per_pixel=4, sample_yield_interval=2, frameid=7)
+    seen = []
+    res = J.drain(J.do_render_job(schema, jc)(lambda s, c, fb, n: seen.append(n)))
+    assert res == {"success": True} and seen == [0, 2, 4]
+    fb = jc.fbo_create(64, 32, 7)
+    assert np.array_equal(fb.download(0)[..., 3], np.full((32, 64), 4.0, np.float32))
+    jc.fbo_delete(64, 32, 7)
+    res = J.drain(J.do_render_job(schema, jc)(lambda *a: None))  # same frameid: keeps accumulating
+    fb = jc.fbo_create(64, 32, 7)
+    assert np.array_equal(fb.download(0)[..., 3], np.full((32, 64), 8.0, np.float32))
+    jc.fbo_delete(64, 32, 7)
+    schema2 = dict(schema, render=dict(schema["render"], frameid=8))
+    J.drain(J.do_render_job(schema2, jc)(lambda *a: None))  # new frameid: cleared first
+    fb = jc.fbo_create(64, 32, 8)
+    assert np.array_equal(fb.download(0)[..., 3], np.full((32, 64), 4.0, np.float32))
+    # matches the oracle fed with the same Halton sequence
+    J.reset_halton()
+    jc2 = J.RenderJobContext(0)
+    J.drain(J.do_render_job(schema, jc2)(lambda *a: None))
+    got = jc2.fbo_create(64, 32, 7).download(0)
+    want = render_oracle(sc, schema, GC.halton_pairs(4))[0]
+    assert np.mean(rel_diff(want, got).max(-1) > 1e-5) <= 0.01
+    bad = dict(schema, sdfScene=S.CsgScene().smooth_union(0.0).sphere((0, 0, 0), 1).sphere((1, 0, 0), 1))
+    res = J.drain(J.do_render_job(bad, jc)(lambda *a: None))
+    assert res["success"] is False and res["why"]["type"] == "fragment"
