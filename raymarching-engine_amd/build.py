@@ -14,13 +14,13 @@ LIB = HERE / "libhip_raymarch.so"
 ARCH = "gfx950"
 
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
-# rm_strict: no FMA contraction (the parity build); rm_fast: contraction on.
+# Both kernel units are contract-off: an FMA exists only where the code asks for one (rm_device.hpp FM::fma).
 # Neither gets -fno-hip-fp32-correctly-rounded-divide-sqrt: plain '/' and
 # sqrtf stay IEEE in both (the random stream relies on it); the fast build
 # asks for v_rcp_f32 / v_sqrt_f32 explicitly where it wants them.
 UNITS = {
     "rm_strict": ["-ffp-contract=off"],
-    "rm_fast": ["-ffp-contract=fast"],
+    "rm_fast": ["-ffp-contract=off"],
     "rm_api": [],
 }
 
@@ -37,25 +37,29 @@ def _sources_mtime() -> float:
     return max(f.stat().st_mtime for f in files)
 
 
-def build_native(force: bool = False, verbose: bool = False, extra=()) -> Path:
-    if not force and LIB.exists() and LIB.stat().st_mtime >= _sources_mtime():
-        return LIB
-    OBJ.mkdir(exist_ok=True)
+def build_native(force: bool = False, verbose: bool = False, extra=(), out: Path = None, tag: str = "") -> Path:
+    """`extra`/`out`/`tag` build an experiment variant next to the product library."""
+    global OBJ
+    lib = Path(out) if out else LIB
+    if not force and lib.exists() and lib.stat().st_mtime >= _sources_mtime():
+        return lib
+    obj = CSRC / ("_obj" + tag)
+    obj.mkdir(exist_ok=True)
     cc = hipcc()
 
     def compile_unit(name):
-        cmd = [cc, *COMMON, *UNITS[name], *extra, "-c", str(CSRC / f"{name}.hip"), "-o", str(OBJ / f"{name}.o")]
+        cmd = [cc, *COMMON, *UNITS[name], *extra, "-c", str(CSRC / f"{name}.hip"), "-o", str(obj / f"{name}.o")]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
 
     with ThreadPoolExecutor(max_workers=3) as ex:
         list(ex.map(compile_unit, UNITS))
-    cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", str(LIB)] + [str(OBJ / f"{n}.o") for n in UNITS]
+    cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", str(lib)] + [str(obj / f"{n}.o") for n in UNITS]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

@@ -319,7 +319,7 @@ static int build_params(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniform
 }
 
 static hipError_t launch(const KParams& P, int flags, hipStream_t stream) {
-  return (flags & RM_RENDER_FAST) ? rm_fast::launch_pixels(P, stream) : rm_strict::launch_pixels(P, stream);
+  return (flags & RM_RENDER_FAST) ? rm::launch_pixels_fast(P, stream) : rm::launch_pixels_strict(P, stream);
 }
 
 int rm_render_sample(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* uniforms, const RmRect* tile, int flags) {
@@ -381,7 +381,7 @@ int rm_probe(rm_ctx* ctx, rm_scene* scene, int what, const float* in, int n, flo
   if (e == hipSuccess) e = hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
     ProbeParams P{scene->dev, d_in, d_out, n, what, param};
-    e = (flags & RM_RENDER_FAST) ? rm_fast::launch_probe(P, ctx->stream) : rm_strict::launch_probe(P, ctx->stream);
+    e = (flags & RM_RENDER_FAST) ? rm::launch_probe_fast(P, ctx->stream) : rm::launch_probe_strict(P, ctx->stream);
   }
   if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -397,7 +397,7 @@ static int camera_rng(rm_ctx* ctx, const RmUniforms* u, int width, int height, i
   float* d_out = nullptr;
   const size_t bytes = sizeof(float) * (size_t)width * (size_t)height * (size_t)(what == 1 ? count : 8);
   RM_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&d_out), bytes));
-  hipError_t e = rm_strict::launch_camera_rng(*u, width, height, what, count, d_out, ctx->stream);
+  hipError_t e = rm::launch_camera_rng(*u, width, height, what, count, d_out, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   (void)hipFree(d_out);

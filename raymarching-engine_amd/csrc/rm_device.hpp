@@ -1,15 +1,24 @@
 // rm_device.hpp -- device-side building blocks of the gfx950 sphere tracer.
 //
-// Included by rm_strict.hip (compiled -ffp-contract=off, IEEE divide/sqrt: the
-// parity build) and rm_fast.hip (contraction on, hardware-rate divide/sqrt,
-// RM_FAST defined).  Everything lives in namespace RM_NS so both builds link
-// into one library.
+// Both kernel translation units are compiled with -ffp-contract=off, so an
+// FMA exists only where the code asks for one.  Arithmetic is written against
+// a math policy:
 //
-// What it implements (file:line = client/public/shader/raymarcher.frag of the
-// reference unless stated): GLSL built-ins with the semantics pinned in
-// oracle/rm_oracle.c, the per-pixel random stream (:46-49,:78-101), the helper
-// SDFs (:74-76,:108-112), the scene kinds of include/hip_raymarch.h and the
-// material functions (settings/shader-editor/Validate.tsx:18-51).
+//   PM  "precise": exactly the operations the oracle performs -- IEEE
+//       add/mul/div/sqrt, no FMA, ocml's ~1 ulp pow/log/sin/cos/acos/atan.
+//       The parity build uses it everywhere.
+//   FM  "fast": v_fma_f32, v_rcp_f32 / v_sqrt_f32 / v_sin_f32 / v_cos_f32 /
+//       v_exp_f32 / v_log_f32 at hardware rate, trig-free power-8 Mandelbulb.
+//       The fast build uses it for the MARCH only (castRay's sdf evaluations,
+//       >= 98 % of the work); normals, the subsurface test, materials, the
+//       RNG and all shading stay on PM.  Why: sceneNormal is a forward
+//       difference with delta = 1e-5 (raymarcher.frag:153-160,:264), which
+//       sits on the fp32 noise floor -- the rounding noise of sdf() IS part of
+//       the reference's image (it blurs the GGX highlight, :365-371).  Coarser
+//       rounding in those four evaluations biases the lighting by several
+//       per cent (measured); in the march it only moves the hit point by ulps.
+//
+// file:line = client/public/shader/raymarcher.frag of the reference unless stated.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -17,7 +26,7 @@
 #include "../../include/hip_raymarch.h"
 #include "rm_params.hpp"
 
-namespace RM_NS {
+namespace rm {
 
 #define RM_DEV __device__ __forceinline__
 
@@ -31,53 +40,66 @@ RM_DEV v3 operator-(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
 RM_DEV v3 operator*(v3 a, v3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
 RM_DEV v3 operator*(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
 RM_DEV v3 adds(v3 a, float s) { return V(a.x + s, a.y + s, a.z + s); }
-RM_DEV float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-
-// ---- divide / sqrt / reciprocal: IEEE in the parity build, hardware rate in the fast build
-#ifdef RM_FAST
-RM_DEV float rm_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-RM_DEV float rm_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
-RM_DEV float rm_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-#else
-RM_DEV float rm_rcp(float x) { return 1.0f / x; }
-RM_DEV float rm_div(float a, float b) { return a / b; }
-RM_DEV float rm_sqrt(float x) { return sqrtf(x); }
-#endif
-
-RM_DEV float length(v3 a) { return rm_sqrt(dot(a, a)); }
-RM_DEV float distance(v3 a, v3 b) { return length(a - b); }
-// v * (1/length(v)): the form pinned against the reference GLSL (oracle/rm_oracle.c vnormalize)
-RM_DEV v3 normalize(v3 a) { return a * rm_rcp(length(a)); }
-RM_DEV v3 cross(v3 a, v3 b) { return V(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
-RM_DEV v3 reflect(v3 i, v3 n) { return i - n * (2.0f * dot(n, i)); }
 RM_DEV v3 vabs(v3 a) { return V(fabsf(a.x), fabsf(a.y), fabsf(a.z)); }
 
-// ---- GLSL built-ins.  min/max are IEEE minNum/maxNum = v_min_f32/v_max_f32
-// (the NaN convention OR_NAN_IEEE of the oracle).
+// ---- math policies --------------------------------------------------------------
+
+struct PM {
+  static constexpr bool fast = false;
+  static RM_DEV float fma(float a, float b, float c) { return a * b + c; }  // two roundings, like GLSL/C
+  static RM_DEV float rcp(float x) { return 1.0f / x; }
+  static RM_DEV float div(float a, float b) { return a / b; }
+  static RM_DEV float sqrt(float x) { return sqrtf(x); }
+  static RM_DEV float pow(float x, float y) { return powf(fabsf(x), y); }  // |x|: oracle/rm_oracle.c gl_pow
+  static RM_DEV float log(float x) { return logf(x); }
+  static RM_DEV float sin(float x) { return sinf(x); }
+  static RM_DEV float cos(float x) { return cosf(x); }
+  static RM_DEV float acos(float x) { return acosf(x); }
+  static RM_DEV float atan2(float y, float x) { return atan2f(y, x); }
+};
+
+struct FM {
+  static constexpr bool fast = true;
+  static RM_DEV float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+  static RM_DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+  static RM_DEV float div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+  static RM_DEV float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+  static RM_DEV float pow(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(fabsf(x))); }
+  static RM_DEV float log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718056f; }
+  static RM_DEV float sin(float x) { return __builtin_amdgcn_sinf(x * 0.15915494309189535f); }
+  static RM_DEV float cos(float x) { return __builtin_amdgcn_cosf(x * 0.15915494309189535f); }
+  static RM_DEV float acos(float x) { return acosf(x); }
+  static RM_DEV float atan2(float y, float x) { return atan2f(y, x); }
+};
+
+// ---- vector helpers / GLSL built-ins (semantics pinned in oracle/rm_oracle.c)
+
+template <class M> RM_DEV float dot(v3 a, v3 b) { return M::fma(a.z, b.z, M::fma(a.y, b.y, a.x * b.x)); }
+template <class M> RM_DEV float length(v3 a) { return M::sqrt(dot<M>(a, a)); }
+template <class M> RM_DEV float distance(v3 a, v3 b) { return length<M>(a - b); }
+// v * (1/length(v)): the form pinned against the reference GLSL
+template <class M> RM_DEV v3 normalize(v3 a) { return a * M::rcp(length<M>(a)); }
+template <class M> RM_DEV v3 madd(v3 a, float s, v3 b) { return V(M::fma(a.x, s, b.x), M::fma(a.y, s, b.y), M::fma(a.z, s, b.z)); }  // a*s + b
+RM_DEV v3 cross(v3 a, v3 b) { return V(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
+template <class M> RM_DEV v3 reflect(v3 i, v3 n) { return i - n * (2.0f * dot<M>(n, i)); }
+
+// min/max are IEEE minNum/maxNum = v_min_f32/v_max_f32 (NaN convention OR_NAN_IEEE)
 RM_DEV float gmax(float x, float y) { return fmaxf(x, y); }
 RM_DEV float gmin(float x, float y) { return fminf(x, y); }
 RM_DEV float gclamp(float x, float lo, float hi) { return gmin(gmax(x, lo), hi); }
-RM_DEV float gfract(float x) { return x - floorf(x); }
-RM_DEV float gmod(float x, float y) { return x - y * floorf(rm_div(x, y)); }
+template <class M> RM_DEV float gmod(float x, float y) { return x - y * floorf(M::div(x, y)); }
 RM_DEV float gsign(float x) { return (float)((x > 0.0f) - (x < 0.0f)); }
-RM_DEV float gmix(float x, float y, float a) { return x + a * (y - x); }
+template <class M> RM_DEV float gmix(float x, float y, float a) { return M::fma(a, y - x, x); }  // x + a*(y-x)
 RM_DEV v3 vmaxs(v3 a, float s) { return V(gmax(a.x, s), gmax(a.y, s), gmax(a.z, s)); }
-RM_DEV v3 vmods(v3 a, float s) { return V(gmod(a.x, s), gmod(a.y, s), gmod(a.z, s)); }
+template <class M> RM_DEV v3 vmods(v3 a, float s) { return V(gmod<M>(a.x, s), gmod<M>(a.y, s), gmod<M>(a.z, s)); }
 RM_DEV bool is_inf(float x) { return fabsf(x) == __builtin_inff(); }
 RM_DEV bool is_nan(float x) { return x != x; }
-RM_DEV bool any_nonfinite(v3 a) { return !(fabsf(a.x) < __builtin_inff()) || !(fabsf(a.y) < __builtin_inff()) || !(fabsf(a.z) < __builtin_inff()); }
-
-#ifdef RM_FAST
-RM_DEV float gpow(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(fabsf(x))); }
-RM_DEV float rm_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718056f; }
-RM_DEV float rm_sin(float x) { return __builtin_amdgcn_sinf(x * 0.15915494309189535f); }
-RM_DEV float rm_cos(float x) { return __builtin_amdgcn_cosf(x * 0.15915494309189535f); }
-#else
-RM_DEV float gpow(float x, float y) { return powf(fabsf(x), y); }
-RM_DEV float rm_log(float x) { return logf(x); }
-RM_DEV float rm_sin(float x) { return sinf(x); }
-RM_DEV float rm_cos(float x) { return cosf(x); }
-#endif
+RM_DEV bool finite(float x) { return fabsf(x) < __builtin_inff(); }
+RM_DEV bool any_nonfinite(v3 a) { return !finite(a.x) || !finite(a.y) || !finite(a.z); }
+RM_DEV bool same_bits(v3 a, v3 b) {
+  return __float_as_uint(a.x) == __float_as_uint(b.x) && __float_as_uint(a.y) == __float_as_uint(b.y) &&
+         __float_as_uint(a.z) == __float_as_uint(b.z);
+}
 
 // mat4 * vec4(v, 0).xyz, column-major (:190,:195,:196,:199)
 RM_DEV v3 mat_rotate(const float* m, v3 v) {
@@ -86,10 +108,9 @@ RM_DEV v3 mat_rotate(const float* m, v3 v) {
 }
 
 // ---- the portable tangent (oracle/rm_oracle.c or_tan, oracle/gl/glref.py):
-// one fixed sequence of IEEE operations, never contracted, in BOTH builds, so
-// the random stream is the same bits everywhere.
+// one fixed sequence of IEEE operations (no FMA: the TU is contract-off; plain
+// '/' and sqrtf are correctly rounded), the same bits in every build.
 RM_DEV float rm_tan(float x) {
-#pragma clang fp contract(off)
   float k = floorf(x * 0.636619772f + 0.5f);
   float r = x - k * 1.5703125f;
   r = r - k * 4.83751296997e-4f;
@@ -102,31 +123,26 @@ RM_DEV float rm_tan(float x) {
   c = c * r2 + 4.166664568298827e-2f;
   c = c * r2 * r2 + (1.0f - 0.5f * r2);
   float odd = k - 2.0f * floorf(k * 0.5f);
-  // plain '/' is the correctly rounded IEEE division in BOTH builds (neither is
-  // compiled with -fno-hip-fp32-correctly-rounded-divide-sqrt; the fast build
-  // asks for v_rcp_f32 explicitly through rm_div), so the stream does not
-  // depend on the build
   return (odd > 0.5f) ? (-c / s) : (s / c);
 }
 
 // ---- RNG: :44-49, :78-105.  distance(xy*PHI, xy) depends on the pixel only,
 // so it is computed once; every sample is then the same operations as the GLSL.
 struct Rng {
-  float seed;   // :78
-  float x1000;  // texcoord.x * 1000
-  float dist;   // distance(xy * PHI, xy)
-  float n0, n1; // randNoise
+  float seed;    // :78
+  float x1000;   // texcoord.x * 1000
+  float dist;    // distance(xy * PHI, xy)
+  float n0, n1;  // randNoise
 };
 
 RM_DEV Rng rng_init(float tcx, float tcy, float n0, float n1) {
-#pragma clang fp contract(off)
   const float PHI = 1.61803398874989484820459f;
   Rng r;
   r.seed = 0.0f;
   float x = tcx * 1000.0f, y = tcy * 1000.0f;
   float dx = x * PHI - x, dy = y * PHI - y;
   r.x1000 = x;
-  r.dist = sqrtf(dx * dx + dy * dy);  // correctly rounded in both builds
+  r.dist = sqrtf(dx * dx + dy * dy);
   r.n0 = n0;
   r.n1 = n1;
   return r;
@@ -134,14 +150,12 @@ RM_DEV Rng rng_init(float tcx, float tcy, float n0, float n1) {
 
 // :46-49
 RM_DEV float gold_noise(const Rng& r, float seed) {
-#pragma clang fp contract(off)
   float t = rm_tan(r.dist * seed) * r.x1000;
   return t - floorf(t);
 }
 
 // :91-94
 RM_DEV float uniform_sample(Rng& r) {
-#pragma clang fp contract(off)
   r.seed += 0.131223f;
   float a = r.n0 + r.seed;
   return gold_noise(r, a - floorf(a));
@@ -149,20 +163,16 @@ RM_DEV float uniform_sample(Rng& r) {
 
 // :80-89 (PI is 3.141592 there)
 RM_DEV void box_muller(Rng& r, float& ox, float& oy) {
-  float u1, u2;
-  {
-#pragma clang fp contract(off)
-    r.seed += 0.123123213f;
-    float a = r.n0 + r.seed;
-    u1 = gold_noise(r, a - floorf(a));
-    r.seed += 0.123123213f;
-    float b = r.n1 + r.seed;
-    u2 = gold_noise(r, b - floorf(b));
-  }
-  float two_pi_u2 = 2.0f * 3.141592f * u2;
-  float rad = rm_sqrt(-2.0f * rm_log(u1));
-  ox = rad * rm_cos(two_pi_u2);
-  oy = rad * rm_sin(two_pi_u2);
+  r.seed += 0.123123213f;
+  float a = r.n0 + r.seed;
+  const float u1 = gold_noise(r, a - floorf(a));
+  r.seed += 0.123123213f;
+  float b = r.n1 + r.seed;
+  const float u2 = gold_noise(r, b - floorf(b));
+  const float two_pi_u2 = 2.0f * 3.141592f * u2;
+  const float rad = sqrtf(-2.0f * logf(u1));
+  ox = rad * cosf(two_pi_u2);
+  oy = rad * sinf(two_pi_u2);
 }
 
 // :96-101
@@ -170,10 +180,10 @@ RM_DEV v3 sphere_sample(Rng& r) {
   float ax, ay, bx, by;
   box_muller(r, ax, ay);
   box_muller(r, bx, by);
-  return normalize(V(ax, ay, bx));
+  return normalize<PM>(V(ax, ay, bx));
 }
 
-// ---- scene block as the kernels see it ---------------------------------------
+// ---- scene in LDS ---------------------------------------------------------------
 
 #define RM_TAB_POW 24  // per-level constants staged in LDS for the iterated kinds
 
@@ -184,18 +194,18 @@ struct SceneLds {
 };
 
 // :74-76
-RM_DEV float sdf_sphere(v3 p, v3 c, float r) { return distance(p, c) - r; }
+template <class M> RM_DEV float sdf_sphere(v3 p, v3 c, float r) { return distance<M>(p, c) - r; }
 
 // :108-112
-RM_DEV float sd_box(v3 p, v3 b) {
+template <class M> RM_DEV float sd_box(v3 p, v3 b) {
   v3 q = vabs(p) - b;
-  return length(vmaxs(q, 0.0f)) + gmin(gmax(q.x, gmax(q.y, q.z)), 0.0f);
+  return length<M>(vmaxs(q, 0.0f)) + gmin(gmax(q.x, gmax(q.y, q.z)), 0.0f);
 }
 
 // examples/smooth-tree.glsl:20-22
-RM_DEV float op_smooth_union(float d1, float d2, float k) {
-  float h = gclamp(0.5f + rm_div(0.5f * (d2 - d1), k), 0.0f, 1.0f);
-  return gmix(d2, d1, h) - k * h * (1.0f - h);
+template <class M> RM_DEV float op_smooth_union(float d1, float d2, float k) {
+  float h = gclamp(0.5f + M::div(0.5f * (d2 - d1), k), 0.0f, 1.0f);
+  return gmix<M>(d2, d1, h) - k * h * (1.0f - h);
 }
 
 template <int KIND>
@@ -210,6 +220,7 @@ struct Sdf<RM_SCENE_TABLE> {
     const float4* src = reinterpret_cast<const float4*>(sc.prims);
     for (int i = threadIdx.x; i < sc.nprims * 2; i += blockDim.x) lds.rows[i] = src[i];
   }
+  template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds& lds, v3 p) {
     float d = 0.0f;
     const int n = sc.nprims;
@@ -219,12 +230,12 @@ struct Sdf<RM_SCENE_TABLE> {
       const int type = __builtin_amdgcn_readfirstlane(__float_as_int(a.x));
       const v3 c = V(a.z, a.w, b.x);
       float di;
-      if ((type & 0xff) == RM_PRIM_SPHERE) di = sdf_sphere(p, c, b.y);
-      else di = sd_box(p - c, V(b.y, b.z, b.w));
+      if ((type & 0xff) == RM_PRIM_SPHERE) di = sdf_sphere<M>(p, c, b.y);
+      else di = sd_box<M>(p - c, V(b.y, b.z, b.w));
       if (i == 0) { d = di; continue; }
       const int op = (type >> 8) & 0xff;
       if (op == RM_OP_UNION) d = gmin(d, di);
-      else if (op == RM_OP_SMOOTH_UNION) d = op_smooth_union(d, di, a.y);
+      else if (op == RM_OP_SMOOTH_UNION) d = op_smooth_union<M>(d, di, a.y);
       else if (op == RM_OP_SUBTRACT) d = gmax(d, -di);
       else d = gmax(d, di);
     }
@@ -237,6 +248,7 @@ struct Sdf<RM_SCENE_TABLE> {
 template <>
 struct Sdf<RM_SCENE_MANDELBULB> {
   static RM_DEV void stage(const DevScene&, SceneLds&) {}
+  template <class M>
   static RM_DEV float eval_generic(const DevScene& sc, v3 pos) {
     const float power = sc.p[RM_P_BULB_POWER];
     const int iterations = (int)sc.p[RM_P_BULB_ITERATIONS];
@@ -244,23 +256,22 @@ struct Sdf<RM_SCENE_MANDELBULB> {
     v3 z = pos;
     float dr = 1.0f, r = 0.0f;
     for (int i = 0; i < iterations; i++) {
-      r = length(z);
+      r = length<M>(z);
       if (r > bailout) break;
-      float theta = acosf(rm_div(z.z, r));
-      float phi = atan2f(z.y, z.x);
-      dr = gpow(r, power - 1.0f) * power * dr + 1.0f;
-      float zr = gpow(r, power);
+      float theta = M::acos(M::div(z.z, r));
+      float phi = M::atan2(z.y, z.x);
+      dr = M::pow(r, power - 1.0f) * power * dr + 1.0f;
+      float zr = M::pow(r, power);
       theta = theta * power;
       phi = phi * power;
-      z = V(rm_sin(theta) * rm_cos(phi), rm_sin(phi) * rm_sin(theta), rm_cos(theta)) * zr;
+      z = V(M::sin(theta) * M::cos(phi), M::sin(phi) * M::sin(theta), M::cos(theta)) * zr;
       z = z + pos;
     }
-    return rm_div(0.5f * rm_log(r) * r, dr);
+    return M::div(0.5f * M::log(r) * r, dr);
   }
-#ifdef RM_FAST
   // Power 8 without trigonometry: with rho = |z.xy|, (z.z + i rho)^8 =
   // r^8 (cos 8theta + i sin 8theta) and (z.x + i z.y)^8 = rho^8 (cos 8phi + i sin 8phi),
-  // each by three complex squarings.  Same function as eval_generic up to
+  // each by three complex squarings.  The same function as eval_generic up to
   // rounding; 2 sqrt + 1 rcp per iteration instead of 12 transcendentals.
   static RM_DEV float eval_pow8(const DevScene& sc, v3 pos) {
     const int iterations = (int)sc.p[RM_P_BULB_ITERATIONS];
@@ -268,38 +279,33 @@ struct Sdf<RM_SCENE_MANDELBULB> {
     v3 z = pos;
     float dr = 1.0f, r2 = 0.0f;
     for (int i = 0; i < iterations; i++) {
-      const float rho2 = z.x * z.x + z.y * z.y;
-      r2 = rho2 + z.z * z.z;
+      const float rho2 = FM::fma(z.y, z.y, z.x * z.x);
+      r2 = FM::fma(z.z, z.z, rho2);
       if (r2 > bail2) break;
-      const float r = __builtin_amdgcn_sqrtf(r2);
-      const float rho = __builtin_amdgcn_sqrtf(rho2);
+      const float r = FM::sqrt(r2);
+      const float rho = FM::sqrt(rho2);
       const float r4 = r2 * r2;
-      dr = (r4 * r2 * r) * 8.0f * dr + 1.0f;
-      // (A + iB) = (z.z + i rho)^8
-      float A = z.z, B = rho, t;
-      t = (A + B) * (A - B); B = 2.0f * A * B; A = t;
-      t = (A + B) * (A - B); B = 2.0f * A * B; A = t;
-      t = (A + B) * (A - B); B = 2.0f * A * B; A = t;
-      // (C + iD) = (z.x + i z.y)^8
-      float C = z.x, D = z.y;
-      t = (C + D) * (C - D); D = 2.0f * C * D; C = t;
-      t = (C + D) * (C - D); D = 2.0f * C * D; C = t;
-      t = (C + D) * (C - D); D = 2.0f * C * D; C = t;
+      dr = FM::fma((r4 * r2 * r) * 8.0f, dr, 1.0f);
+      // (A + iB) = (z.z + i rho)^8, (C + iD) = (z.x + i z.y)^8
+      float A = z.z, B = rho, C = z.x, D = z.y, t;
+#pragma unroll
+      for (int s = 0; s < 3; s++) {
+        t = (A + B) * (A - B); B = 2.0f * A * B; A = t;
+        t = (C + D) * (C - D); D = 2.0f * C * D; C = t;
+      }
       const float rho4 = rho2 * rho2;
       const float rho8 = rho4 * rho4;
-      const float s = rho8 > 0.0f ? B * __builtin_amdgcn_rcpf(rho8) : 0.0f;  // r^8 sin(8 theta) / rho^8
-      // phi = atan(0, 0) = 0 on the axis: cos 8phi = 1
-      z = V(rho8 > 0.0f ? s * C : B, s * D, A) + pos;
+      const bool on_axis = !(rho8 > 0.0f);  // phi = atan(0, 0) = 0 there: cos 8phi = 1, sin 8theta = 0
+      const float s8 = on_axis ? 0.0f : B * FM::rcp(rho8);  // r^8 sin(8 theta) / rho^8
+      z = V(FM::fma(s8, C, pos.x), FM::fma(s8, D, pos.y), A + pos.z);
     }
-    const float r = __builtin_amdgcn_sqrtf(r2);
-    return 0.5f * rm_log(r) * r * __builtin_amdgcn_rcpf(dr);
+    const float r = FM::sqrt(r2);
+    return 0.5f * FM::log(r) * r * FM::rcp(dr);
   }
-#endif
+  template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds&, v3 p) {
-#ifdef RM_FAST
-    if (sc.p[RM_P_BULB_POWER] == 8.0f) return eval_pow8(sc, p);
-#endif
-    return eval_generic(sc, p);
+    if (M::fast && sc.p[RM_P_BULB_POWER] == 8.0f) return eval_pow8(sc, p);
+    return eval_generic<M>(sc, p);
   }
 };
 
@@ -307,27 +313,28 @@ struct Sdf<RM_SCENE_MANDELBULB> {
 // computed once per workgroup with the same pow the per-evaluation GLSL uses
 RM_DEV void stage_pow_table(SceneLds& lds, float base, float first) {
   float* t = reinterpret_cast<float*>(lds.rows);
-  if (threadIdx.x < RM_TAB_POW) t[threadIdx.x] = gpow(base, first + (float)threadIdx.x);
+  if (threadIdx.x < RM_TAB_POW) t[threadIdx.x] = PM::pow(base, first + (float)threadIdx.x);
 }
 
 // RM_SCENE_SPHERE_GRID: examples/guide.glsl:91-102 == examples/fractal1.glsl:23-34
 template <>
 struct Sdf<RM_SCENE_SPHERE_GRID> {
   static RM_DEV void stage(const DevScene& sc, SceneLds& lds) { stage_pow_table(lds, sc.p[RM_P_GRID_SCALE], -1.0f); }
+  template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds& lds, v3 p) {
     const float* tab = reinterpret_cast<const float*>(lds.rows);
     const float iters = sc.p[RM_P_GRID_ITERATIONS];
     float min_dist = 9999.9f;
     int k = 0;
     for (float i = -1.0f; i < iters; i += 1.0f, k++) {
-      const float sf = k < RM_TAB_POW ? tab[k] : gpow(sc.p[RM_P_GRID_SCALE], i);
-      const float half = rm_div(sf, 2.0f), third = rm_div(sf, 3.0f);
-      v3 d = vabs(adds(vmods(adds(p, 0.5f * sf), sf), -half));
+      const float sf = k < RM_TAB_POW ? tab[k] : PM::pow(sc.p[RM_P_GRID_SCALE], i);
+      const float half = sf / 2.0f, third = sf / 3.0f;
+      v3 d = vabs(adds(vmods<M>(adds(p, 0.5f * sf), sf), -half));
       d = adds(d, -third);
-      min_dist = gmin(length(d) - 0.21f * sf, min_dist);
+      min_dist = gmin(length<M>(d) - 0.21f * sf, min_dist);
     }
     const v3 c = V(sc.p[RM_P_GRID_CENTER], sc.p[RM_P_GRID_CENTER + 1], sc.p[RM_P_GRID_CENTER + 2]);
-    return gmax(length(p - c) - sc.p[RM_P_GRID_BIG_SIZE], -min_dist);
+    return gmax(length<M>(p - c) - sc.p[RM_P_GRID_BIG_SIZE], -min_dist);
   }
 };
 
@@ -335,10 +342,11 @@ struct Sdf<RM_SCENE_SPHERE_GRID> {
 template <>
 struct Sdf<RM_SCENE_SPHERE_LATTICE> {
   static RM_DEV void stage(const DevScene&, SceneLds&) {}
+  template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds&, v3 p) {
     const float period = sc.p[RM_P_LATTICE_PERIOD], half = period * 0.5f;
-    v3 rep = adds(vmods(adds(p, half), period), -half);
-    return length(rep - V(0.0f, 0.0f, 0.0f)) - sc.p[RM_P_LATTICE_RADIUS];
+    v3 rep = adds(vmods<M>(adds(p, half), period), -half);
+    return length<M>(rep - V(0.0f, 0.0f, 0.0f)) - sc.p[RM_P_LATTICE_RADIUS];
   }
 };
 
@@ -346,17 +354,18 @@ struct Sdf<RM_SCENE_SPHERE_LATTICE> {
 template <>
 struct Sdf<RM_SCENE_MENGER> {
   static RM_DEV void stage(const DevScene&, SceneLds& lds) { stage_pow_table(lds, 0.33333333333333f, 1.0f); }
+  template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds& lds, v3 p) {
     const float* tab = reinterpret_cast<const float*>(lds.rows);
     const float iters = sc.p[RM_P_MENGER_ITERATIONS];
-    float min_dist = sd_box(adds(p, 0.5f), V(0.5f, 0.5f, 0.5f));
+    float min_dist = sd_box<M>(adds(p, 0.5f), V(0.5f, 0.5f, 0.5f));
     int k = 0;
     for (float i = 1.0f; i < iters; i += 1.0f, k++) {
-      const float sf = k < RM_TAB_POW ? tab[k] : gpow(0.33333333333333f, i);
-      v3 g = adds(vmods(p, sf * 3.0f), -(sf * 1.5f));
-      float a = sd_box(g, V(sf * 1.51f, sf * 0.5f, sf * 0.5f));
-      float b = sd_box(g, V(sf * 0.5f, sf * 1.51f, sf * 0.5f));
-      float c = sd_box(g, V(sf * 0.5f, sf * 0.5f, sf * 1.51f));
+      const float sf = k < RM_TAB_POW ? tab[k] : PM::pow(0.33333333333333f, i);
+      v3 g = adds(vmods<M>(p, sf * 3.0f), -(sf * 1.5f));
+      float a = sd_box<M>(g, V(sf * 1.51f, sf * 0.5f, sf * 0.5f));
+      float b = sd_box<M>(g, V(sf * 0.5f, sf * 1.51f, sf * 0.5f));
+      float c = sd_box<M>(g, V(sf * 0.5f, sf * 0.5f, sf * 1.51f));
       min_dist = gmax(min_dist, -gmin(gmin(a, b), c));
     }
     return min_dist;
@@ -370,13 +379,14 @@ struct KifsTrig {
 };
 RM_DEV KifsTrig kifs_trig(const DevScene& sc) {
   const float* a = &sc.p[RM_P_KIFS_ANGLES];
-  return KifsTrig{rm_cos(a[0]), rm_sin(a[0]), rm_cos(a[1]), rm_sin(a[1]), rm_cos(a[2]), rm_sin(a[2])};
+  return KifsTrig{cosf(a[0]), sinf(a[0]), cosf(a[1]), sinf(a[1]), cosf(a[2]), sinf(a[2])};
 }
+template <class M>
 RM_DEV v3 kifs_rotate(v3 t, const KifsTrig& g) {
   float nx, ny;
-  nx = t.x * g.c0 + t.y * -g.s0; ny = t.x * g.s0 + t.y * g.c0; t.x = nx; t.y = ny;
-  nx = t.y * g.c1 + t.z * -g.s1; ny = t.y * g.s1 + t.z * g.c1; t.y = nx; t.z = ny;
-  nx = t.x * g.c2 + t.z * -g.s2; ny = t.x * g.s2 + t.z * g.c2; t.x = nx; t.z = ny;
+  nx = M::fma(t.y, -g.s0, t.x * g.c0); ny = M::fma(t.y, g.c0, t.x * g.s0); t.x = nx; t.y = ny;
+  nx = M::fma(t.z, -g.s1, t.y * g.c1); ny = M::fma(t.z, g.c1, t.y * g.s1); t.y = nx; t.z = ny;
+  nx = M::fma(t.z, -g.s2, t.x * g.c2); ny = M::fma(t.z, g.c2, t.x * g.s2); t.x = nx; t.z = ny;
   return t;
 }
 
@@ -384,6 +394,7 @@ RM_DEV v3 kifs_rotate(v3 t, const KifsTrig& g) {
 template <>
 struct Sdf<RM_SCENE_KIFS_TREE> {
   static RM_DEV void stage(const DevScene& sc, SceneLds& lds) { stage_pow_table(lds, sc.p[RM_P_KIFS_SCALE], 0.0f); }
+  template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds& lds, v3 p) {
     const float* tab = reinterpret_cast<const float*>(lds.rows);
     const float iters = sc.p[RM_P_KIFS_ITERATIONS], scale = sc.p[RM_P_KIFS_SCALE], offset = sc.p[RM_P_KIFS_OFFSET];
@@ -393,12 +404,12 @@ struct Sdf<RM_SCENE_KIFS_TREE> {
     float min_dist = 9999.0f;
     int k = 0;
     for (float i = 0.0f; i < iters; i += 1.0f, k++) {
-      const float csf = k < RM_TAB_POW ? tab[k] : gpow(scale, i);
-      const float box = sd_box(t * csf, V(1.0f * csf, 0.1f * csf, 0.1f * csf));
-      min_dist = smoothen ? op_smooth_union(min_dist, box, csf * 0.25f) : gmin(min_dist, box);
-      t = V(rm_div(t.x, scale), rm_div(t.y, scale), rm_div(t.z, scale));
+      const float csf = k < RM_TAB_POW ? tab[k] : PM::pow(scale, i);
+      const float box = sd_box<M>(t * csf, V(1.0f * csf, 0.1f * csf, 0.1f * csf));
+      min_dist = smoothen ? op_smooth_union<M>(min_dist, box, csf * 0.25f) : gmin(min_dist, box);
+      t = V(M::div(t.x, scale), M::div(t.y, scale), M::div(t.z, scale));
       t = vabs(t) - V(1.0f * offset, 0.1f * offset, 0.1f * offset);
-      t = kifs_rotate(t, g);
+      t = kifs_rotate<M>(t, g);
     }
     return min_dist;
   }
@@ -408,51 +419,52 @@ struct Sdf<RM_SCENE_KIFS_TREE> {
 template <>
 struct Sdf<RM_SCENE_KIFS_BOX> {
   static RM_DEV void stage(const DevScene&, SceneLds&) {}
+  template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds&, v3 p) {
     const float iters = sc.p[RM_P_KIFS_ITERATIONS], scale = sc.p[RM_P_KIFS_SCALE], offset = sc.p[RM_P_KIFS_OFFSET];
     const KifsTrig g = kifs_trig(sc);
     v3 t = p;
     for (float i = 0.0f; i < iters; i += 1.0f) {
-      t = V(rm_div(t.x, scale), rm_div(t.y, scale), rm_div(t.z, scale));
+      t = V(M::div(t.x, scale), M::div(t.y, scale), M::div(t.z, scale));
       t = vabs(t) - V(offset, offset, offset);
-      t = kifs_rotate(t, g);
+      t = kifs_rotate<M>(t, g);
     }
-    const float csf = gpow(scale, roundf(iters));
-    return sd_box(t * csf, V(csf, csf, csf));
+    const float csf = PM::pow(scale, roundf(iters));
+    return sd_box<M>(t * csf, V(csf, csf, csf));
   }
 };
 
 // ---- material functions (Validate.tsx:18-51 with the constants of RmMaterial)
 
 RM_DEV v3 cut_color(const float* col, float cutoff, v3 p) {
-  return length(p) > cutoff ? V(0.0f, 0.0f, 0.0f) : V(col[0], col[1], col[2]);
+  return length<PM>(p) > cutoff ? V(0.0f, 0.0f, 0.0f) : V(col[0], col[1], col[2]);
 }
 RM_DEV v3 scene_diffuse(const DevScene& sc, v3 p) { return cut_color(sc.mat.diffuse, sc.mat.diffuse_cutoff, p); }
 RM_DEV v3 scene_specular(const DevScene& sc, v3 p) { return cut_color(sc.mat.specular, sc.mat.specular_cutoff, p); }
 // Validate.tsx:47-51
 RM_DEV v3 scene_emission(const DevScene& sc, v3 p) {
   const RmMaterial& m = sc.mat;
-  const v3 n = normalize(p);
+  const v3 n = normalize<PM>(p);
   const float comp = m.sky_axis == 0 ? n.x : m.sky_axis == 1 ? n.y : n.z;
   const float d = gmax(comp, m.sky_floor);
   const v3 bright = V(m.sky_color[0] * d * 1.0f, m.sky_color[1] * d * 1.0f, m.sky_color[2] * d * 1.0f);
-  return length(p) > m.sky_radius ? bright * m.sky_scale : V(0.0f, 0.0f, 0.0f);
+  return length<PM>(p) > m.sky_radius ? bright * m.sky_scale : V(0.0f, 0.0f, 0.0f);
 }
 
 // :148-150
-RM_DEV float inv_exp_dist(float x, float lambda) { return rm_div(-rm_log(1.0f - x), lambda); }
+RM_DEV float inv_exp_dist(float x, float lambda) { return -logf(1.0f - x) / lambda; }
 
 // :172-175
 RM_DEV float schlick(float cos_theta, float n1, float n2) {
-  const float r0 = gpow(rm_div(n1 - n2, n1 + n2), 2.0f);
-  return r0 + (1.0f - r0) * gpow(1.0f - cos_theta, 5.0f);
+  const float r0 = PM::pow((n1 - n2) / (n1 + n2), 2.0f);
+  return r0 + (1.0f - r0) * PM::pow(1.0f - cos_theta, 5.0f);
 }
 
 // :61-65
 RM_DEV v3 rodrigues(v3 v, v3 k, float theta) {
-  const float c = rm_cos(theta);
-  const float s = rm_sqrt(1.0f - c * c);
-  return v * c + cross(k, v) * s + k * (dot(k, v) * (1.0f - c));
+  const float c = cosf(theta);
+  const float s = sqrtf(1.0f - c * c);
+  return v * c + cross(k, v) * s + k * (dot<PM>(k, v) * (1.0f - c));
 }
 
-}  // namespace RM_NS
+}  // namespace rm

@@ -1,7 +1,7 @@
-// Fast build of the kernels: FMA contraction, v_rcp/v_sqrt/v_sin/v_cos/v_exp/v_log
-// at hardware rate, trig-free power-8 Mandelbulb.  The random stream is the
-// same bits as in the parity build (rm_device.hpp rm_tan / Rng).
-#define RM_NS rm_fast
-#define RM_FAST 1
+// Fast build of the kernels: the march on the fast policy (rm_device.hpp FM:
+// v_fma / v_rcp / v_sqrt / v_log at hardware rate, trig-free power-8
+// Mandelbulb); normals, shading and the random stream as in the parity build.
+#define RM_BUILD_FAST 1
+#include <type_traits>
 #include "rm_device.hpp"
 #include "rm_kernels.inc"

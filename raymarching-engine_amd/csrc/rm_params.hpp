@@ -34,11 +34,10 @@ struct ProbeParams {
   float param;
 };
 
-#define RM_DECLARE_LAUNCHERS(NS)                                                                              \
-  namespace NS {                                                                                              \
-  hipError_t launch_pixels(const KParams& P, hipStream_t stream);                                             \
-  hipError_t launch_probe(const ProbeParams& P, hipStream_t stream);                                          \
-  hipError_t launch_camera_rng(const RmUniforms& u, int W, int H, int what, int count, float* out, hipStream_t stream); \
-  }
-RM_DECLARE_LAUNCHERS(rm_strict)
-RM_DECLARE_LAUNCHERS(rm_fast)
+namespace rm {
+hipError_t launch_pixels_strict(const KParams& P, hipStream_t stream);
+hipError_t launch_pixels_fast(const KParams& P, hipStream_t stream);
+hipError_t launch_probe_strict(const ProbeParams& P, hipStream_t stream);
+hipError_t launch_probe_fast(const ProbeParams& P, hipStream_t stream);
+hipError_t launch_camera_rng(const RmUniforms& u, int W, int H, int what, int count, float* out, hipStream_t stream);
+}  // namespace rm

@@ -1,4 +1,5 @@
-// Parity build of the kernels: compiled with -ffp-contract=off, IEEE divide and sqrt.
-#define RM_NS rm_strict
+// Parity build of the kernels: every operation on the precise policy (rm_device.hpp PM).
+#define RM_BUILD_FAST 0
+#include <type_traits>
 #include "rm_device.hpp"
 #include "rm_kernels.inc"

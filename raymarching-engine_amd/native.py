@@ -14,7 +14,10 @@ import numpy as np
 from . import abi
 from .scene import Scene
 
-LIB_PATH = Path(__file__).resolve().parent / "libhip_raymarch.so"
+import os
+
+# RM_LIB selects an experiment build of the SAME library (tools/); default = the in-tree product
+LIB_PATH = Path(os.environ.get("RM_LIB") or Path(__file__).resolve().parent / "libhip_raymarch.so")
 
 # every symbol include/hip_raymarch.h declares
 EXPORTS = [
