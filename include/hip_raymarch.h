@@ -171,8 +171,12 @@ typedef struct RmRect {
 /* render flags */
 enum {
   RM_RENDER_STRICT = 0,      /* fixed step counts, IEEE division/sqrt, no contraction: the parity build */
-  RM_RENDER_FAST = 1,        /* wave-ballot early retire + hardware-rate math; results within the documented tolerance */
-  RM_RENDER_COLOR_ONLY = 2   /* do not read/write the two G-buffer planes (benchmark "single colour frame" mode) */
+  RM_RENDER_FAST = 1,        /* hardware-rate math in the march + tolerance retire (rm_ctx_set_retire_eps); results within the documented tolerance */
+  RM_RENDER_COLOR_ONLY = 2,  /* do not read/write the two G-buffer planes (benchmark "single colour frame" mode) */
+  RM_RENDER_MEGAKERNEL = 4,  /* one thread = one pixel for the whole of main() (the first, simplest kernel) instead of
+                                the default wavefront pipeline with the ray-compacting march; same results */
+  RM_RENDER_NO_COST_CLASSES = 8 /* wavefront march in one pass even for scene kinds whose sdf cost depends on the
+                                   point (Mandelbulb); a measurement switch, same results */
 };
 
 enum { RM_PLANE_COLOR = 0, RM_PLANE_NORMAL_DOF = 1, RM_PLANE_ALBEDO_DEPTH = 2 };
@@ -190,6 +194,19 @@ const char* rm_last_error(const rm_ctx* ctx);
 /* Use an externally owned hipStream_t (e.g. torch's current stream) for all
  * later launches; NULL restores the context's own stream. */
 int rm_ctx_set_stream(rm_ctx* ctx, void* hip_stream);
+/* RM_RENDER_FAST only: a marching lane counts as settled once its step
+ * |d| <= eps * max(1, |p|_inf) (default 2^-21, i.e. a step of at most four
+ * ulps of the hit point); a wave leaves the march when all its lanes are
+ * settled.  eps = 0 keeps only the exact test (position bitwise unchanged),
+ * which is what RM_RENDER_STRICT always uses.  Rays on a fractal surface never
+ * settle bitwise -- sdf() there is rounding noise of a few 1e-8 and p wanders
+ * by ulps for ever -- so the exact test alone retires no wave on the fractal
+ * (measured: DESIGN.md). */
+int rm_ctx_set_retire_eps(rm_ctx* ctx, float eps);
+/* Diagnostics of the wavefront march, filled only by builds compiled with
+ * -DRM_WF_STATS (zeros otherwise): out16[8*shadow + 4*pass2 + {0,1,2}] =
+ * rays marched, lane-steps, wave-steps since the last reset. */
+int rm_debug_counters(rm_ctx* ctx, unsigned long long* out16, int reset);
 /* Completion point: the reference's generator yield / present cadence
  * (RenderJobExecutor.tsx:163-166) maps to "enqueue samples, rm_sync, present". */
 int rm_sync(rm_ctx* ctx);
@@ -261,8 +278,11 @@ int rm_render_timed(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* u
  *   RM_PROBE_CAST_RAY in: n x (float3 p, float3 dir)    out: n x float3  castRay(p,dir,steps)   raymarcher.frag:163-170
  *   RM_PROBE_NORMAL   in: n x float3 p                  out: n x float3  sceneNormal(p, delta)  raymarcher.frag:153-160
  *   RM_PROBE_MATERIAL in: n x float3 p                  out: n x 12 floats diffuse,specular,emission,(roughness,subsurface,ior)
+ *   RM_PROBE_CAST_STEPS in: n x (float3 p, float3 dir)  out: n x float   number of castRay steps after which the ray's
+ *                                                       position no longer changes bitwise (= steps if it never settles);
+ *                                                       a measurement aid for the wave-retire, not a reference function
  */
-enum { RM_PROBE_SDF = 0, RM_PROBE_CAST_RAY = 1, RM_PROBE_NORMAL = 2, RM_PROBE_MATERIAL = 3 };
+enum { RM_PROBE_SDF = 0, RM_PROBE_CAST_RAY = 1, RM_PROBE_NORMAL = 2, RM_PROBE_MATERIAL = 3, RM_PROBE_CAST_STEPS = 4 };
 int rm_probe(rm_ctx* ctx, rm_scene* scene, int what, const float* in, int n, float param,
              int flags, float* out);
 

@@ -13,7 +13,9 @@ OBJ = CSRC / "_obj"
 LIB = HERE / "libhip_raymarch.so"
 ARCH = "gfx950"
 
-COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# -fno-slp-vectorize: hipcc otherwise packs the scalar f32 chains of the distance estimators into
+# v_pk_*_f32 plus register shuffles, which is 7 % slower on the headline kernel (measured on MI355X)
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize"]
 # Both kernel units are contract-off: an FMA exists only where the code asks for one (rm_device.hpp FM::fma).
 # Neither gets -fno-hip-fp32-correctly-rounded-divide-sqrt: plain '/' and
 # sqrtf stay IEEE in both (the random stream relies on it); the fast build

@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -20,6 +21,15 @@ struct rm_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float retire_eps = 4.76837158203125e-07f;  // 2^-21
+  int cu_count = 256;
+  int pass2_blocks_per_cu = 3;
+  // wavefront pipeline workspace (per-ray state + queue heads), grown on demand
+  float4* ws = nullptr;
+  size_t ws_rays = 0;
+  unsigned int* heads = nullptr;  // 3 counters per march launch: head(pass 0/1), head(pass 2), parked count
+  unsigned int* ws_list = nullptr;  // parked ray ids
+  unsigned long long* stats = nullptr;  // 16 counters, filled by RM_WF_STATS builds only
   std::string error;
 };
 
@@ -92,6 +102,9 @@ int rm_ctx_create(int device, rm_ctx** out) {
     return fail(nullptr, RM_ERR_DEVICE, msg);
   }
   ctx->stream = ctx->own_stream;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->cu_count = cus;
+  if (const char* v = std::getenv("RM_PASS2_BLOCKS_PER_CU")) { int n = std::atoi(v); if (n >= 1 && n <= 8) ctx->pass2_blocks_per_cu = n; }
   *out = ctx;
   return RM_OK;
 }
@@ -100,6 +113,10 @@ void rm_ctx_destroy(rm_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->heads) (void)hipFree(ctx->heads);
+  if (ctx->ws_list) (void)hipFree(ctx->ws_list);
+  if (ctx->stats) (void)hipFree(ctx->stats);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -111,6 +128,23 @@ const char* rm_last_error(const rm_ctx* ctx) { return ctx ? ctx->error.c_str() :
 int rm_ctx_set_stream(rm_ctx* ctx, void* hip_stream) {
   if (!ctx) return RM_ERR_INVALID;
   ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  return RM_OK;
+}
+
+int rm_ctx_set_retire_eps(rm_ctx* ctx, float eps) {
+  if (!ctx) return RM_ERR_INVALID;
+  if (!(eps >= 0.0f && eps <= 1e-3f)) return fail(ctx, RM_ERR_INVALID, "rm_ctx_set_retire_eps: eps must be in [0, 1e-3]");
+  ctx->retire_eps = eps;
+  return RM_OK;
+}
+
+int rm_debug_counters(rm_ctx* ctx, unsigned long long* out16, int reset) {
+  if (!ctx || !out16) return RM_ERR_INVALID;
+  for (int i = 0; i < 16; i++) out16[i] = 0;
+  if (!ctx->stats) return RM_OK;
+  RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  RM_HIP(ctx, hipMemcpy(out16, ctx->stats, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost));
+  if (reset) RM_HIP(ctx, hipMemset(ctx->stats, 0, sizeof(unsigned long long) * 16));
   return RM_OK;
 }
 
@@ -314,12 +348,99 @@ static int build_params(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniform
   P->albedo_depth = color_only ? nullptr : fb->plane[2];
   P->W = fb->width; P->H = fb->height; P->row_begin = fb->row_begin;
   P->tx = x0; P->ty = y0; P->tw = x1 - x0; P->th = y1 - y0;
-  P->retire_eps = 0.0f;
+  P->retire_eps = (flags & RM_RENDER_FAST) ? ctx->retire_eps : 0.0f;
   return RM_OK;
 }
 
-static hipError_t launch(const KParams& P, int flags, hipStream_t stream) {
-  return (flags & RM_RENDER_FAST) ? rm::launch_pixels_fast(P, stream) : rm::launch_pixels_strict(P, stream);
+#define RM_MAX_MARCHES (RM_MAX_BOUNCES * (1 + RM_MAX_LIGHTS))
+
+// One sample through the wavefront pipeline (rm_wavefront.inc).
+static hipError_t launch_wavefront(rm_ctx* ctx, const KParams& P, int flags) {
+  hipStream_t stream = ctx->stream;
+  const bool fast = (flags & RM_RENDER_FAST) != 0;
+  rm::WfParams W{};
+  W.k = P;
+  W.tiles_x = (P.tw + 7) / 8;
+  const int tiles_y = (P.th + 7) / 8;
+  W.n_rays = W.tiles_x * tiles_y * 64;
+  hipError_t e;
+  if (!ctx->heads) {
+    if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->heads), sizeof(unsigned int) * 3 * RM_MAX_MARCHES)) != hipSuccess) return e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->stats), sizeof(unsigned long long) * 16)) != hipSuccess) return e;
+    if ((e = hipMemset(ctx->stats, 0, sizeof(unsigned long long) * 16)) != hipSuccess) return e;
+  }
+  if (ctx->ws_rays < (size_t)W.n_rays) {
+    if (ctx->ws) {
+      if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+      (void)hipFree(ctx->ws);
+      (void)hipFree(ctx->ws_list);
+      ctx->ws = nullptr;
+      ctx->ws_list = nullptr;
+      ctx->ws_rays = 0;
+    }
+    if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->ws), sizeof(float4) * (size_t)rm::WF_ARRAYS * (size_t)W.n_rays)) != hipSuccess) return e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->ws_list), sizeof(unsigned int) * (size_t)W.n_rays)) != hipSuccess) return e;
+    ctx->ws_rays = (size_t)W.n_rays;
+  }
+  for (int i = 0; i < rm::WF_ARRAYS; i++) W.a[i] = ctx->ws + (size_t)i * ctx->ws_rays;
+  if ((e = hipMemsetAsync(ctx->heads, 0, sizeof(unsigned int) * 3 * RM_MAX_MARCHES, stream)) != hipSuccess) return e;
+  W.list = ctx->ws_list;
+  W.stats = ctx->stats;
+  const bool classes = rm::wf_kind_has_cost_classes(P.scene.kind) && !(flags & RM_RENDER_NO_COST_CLASSES);
+  // persistent march grid: every SIMD slot of the chip, or fewer when there are few rays
+  int blocks = ctx->cu_count * 8;
+  const int needed = (W.n_rays + 255) / 256;
+  if (blocks > needed) blocks = needed;
+  int march = 0;
+  auto do_march = [&](int pos_array, int dir_array, bool preview) -> hipError_t {
+    W.pos_array = pos_array;
+    W.dir_array = dir_array;
+    unsigned int* c = ctx->heads + 3 * march++;
+    auto go = [&](int pass) { return fast ? rm::wf_launch_march_fast(W, preview, pass, blocks, stream) : rm::wf_launch_march_strict(W, preview, pass, blocks, stream); };
+    W.head = c;
+    W.list_count = c + 2;
+    if (!classes) return go(0);
+    hipError_t e1 = go(1);  // cheap evaluations; parks the rays that need the deep one
+    if (e1 != hipSuccess) return e1;
+    W.head = c + 1;
+    // the parked rays, compacted.  Fewer waves than SIMD slots on purpose: the
+    // list is short (the rays near the surface) and every wave ends with a tail
+    // in which a few never-settling rays run alone, so the idle-lane cost grows
+    // with the number of waves; 2-3 waves per SIMD already saturate the VALU of
+    // this dependent-chain code (measured: DESIGN.md)
+    const int saved = blocks;
+    const int pass2 = ctx->cu_count * ctx->pass2_blocks_per_cu;
+    if (blocks > pass2) blocks = pass2;
+    hipError_t e2 = go(2);
+    blocks = saved;
+    return e2;
+  };
+  if ((e = rm::wf_launch_stage(W, 0, stream)) != hipSuccess) return e;  // setup
+  if (P.u.renderMode == 1) {
+    if ((e = do_march(rm::WF_POS, rm::WF_DIR, true)) != hipSuccess) return e;
+    return rm::wf_launch_stage(W, 1, stream);
+  }
+  int bounces = 0;
+  for (float i = 0.0f; i < P.u.reflections; i += 1.0f) bounces++;
+  if (bounces == 0) return rm::wf_launch_stage(W, 2, stream);
+  for (int b = 0; b < bounces; b++) {
+    W.bounce = b;
+    W.last_bounce = b == bounces - 1;
+    if ((e = do_march(rm::WF_POS, rm::WF_DIR, false)) != hipSuccess) return e;
+    if ((e = rm::wf_launch_stage(W, 4, stream)) != hipSuccess) return e;  // shade
+    for (int j = 0; j < P.u.lightCount; j++) {
+      W.light = j;
+      if ((e = do_march(rm::WF_SPOS, rm::WF_SDIR, false)) != hipSuccess) return e;
+      if ((e = rm::wf_launch_stage(W, 3, stream)) != hipSuccess) return e;  // light
+    }
+  }
+  return hipSuccess;
+}
+
+static hipError_t launch(rm_ctx* ctx, const KParams& P, int flags) {
+  if (flags & RM_RENDER_MEGAKERNEL)
+    return (flags & RM_RENDER_FAST) ? rm::launch_pixels_fast(P, ctx->stream) : rm::launch_pixels_strict(P, ctx->stream);
+  return launch_wavefront(ctx, P, flags);
 }
 
 int rm_render_sample(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* uniforms, const RmRect* tile, int flags) {
@@ -328,7 +449,7 @@ int rm_render_sample(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* 
   if (int rc = build_params(ctx, scene, fb, uniforms, tile, flags, &P, &empty)) return rc;
   if (empty) return RM_OK;
   RM_HIP(ctx, hipSetDevice(ctx->device));
-  RM_HIP(ctx, launch(P, flags, ctx->stream));
+  RM_HIP(ctx, launch(ctx, P, flags));
   return RM_OK;
 }
 
@@ -343,7 +464,7 @@ int rm_render_samples(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms*
   for (int i = 0; i < count; i++) {
     P.u.randNoise[0] = rand_noise_pairs[2 * i];
     P.u.randNoise[1] = rand_noise_pairs[2 * i + 1];
-    RM_HIP(ctx, launch(P, flags, ctx->stream));
+    RM_HIP(ctx, launch(ctx, P, flags));
   }
   return RM_OK;
 }
@@ -357,7 +478,7 @@ int rm_render_timed(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* u
   if (empty) return fail(ctx, RM_ERR_INVALID, "rm_render_timed: empty tile");
   RM_HIP(ctx, hipSetDevice(ctx->device));
   RM_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  for (int i = 0; i < count; i++) RM_HIP(ctx, launch(P, flags, ctx->stream));
+  for (int i = 0; i < count; i++) RM_HIP(ctx, launch(ctx, P, flags));
   RM_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   RM_HIP(ctx, hipEventSynchronize(ctx->ev1));
   float ms = 0.0f;
@@ -370,9 +491,9 @@ int rm_render_timed(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* u
 
 int rm_probe(rm_ctx* ctx, rm_scene* scene, int what, const float* in, int n, float param, int flags, float* out) {
   if (!ctx || !scene || !in || !out) return fail(ctx, RM_ERR_INVALID, "rm_probe: NULL argument");
-  if (what < RM_PROBE_SDF || what > RM_PROBE_MATERIAL) return fail(ctx, RM_ERR_INVALID, "rm_probe: unknown probe");
+  if (what < RM_PROBE_SDF || what > RM_PROBE_CAST_STEPS) return fail(ctx, RM_ERR_INVALID, "rm_probe: unknown probe");
   if (n <= 0) return RM_OK;
-  static const int in_w[4] = {3, 6, 3, 3}, out_w[4] = {1, 3, 3, 12};
+  static const int in_w[5] = {3, 6, 3, 3, 6}, out_w[5] = {1, 3, 3, 12, 1};
   RM_HIP(ctx, hipSetDevice(ctx->device));
   float *d_in = nullptr, *d_out = nullptr;
   const size_t in_bytes = sizeof(float) * (size_t)in_w[what] * (size_t)n, out_bytes = sizeof(float) * (size_t)out_w[what] * (size_t)n;
@@ -380,7 +501,7 @@ int rm_probe(rm_ctx* ctx, rm_scene* scene, int what, const float* in, int n, flo
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_out), out_bytes);
   if (e == hipSuccess) e = hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
-    ProbeParams P{scene->dev, d_in, d_out, n, what, param};
+    ProbeParams P{scene->dev, d_in, d_out, n, what, param, (flags & RM_RENDER_FAST) ? ctx->retire_eps : 0.0f};
     e = (flags & RM_RENDER_FAST) ? rm::launch_probe_fast(P, ctx->stream) : rm::launch_probe_strict(P, ctx->stream);
   }
   if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream);

@@ -216,6 +216,7 @@ struct Sdf;
 // through readfirstlane so the per-row switch is a scalar branch.
 template <>
 struct Sdf<RM_SCENE_TABLE> {
+  static constexpr bool has_cost_classes = false;  // every evaluation costs the same
   static RM_DEV void stage(const DevScene& sc, SceneLds& lds) {
     const float4* src = reinterpret_cast<const float4*>(sc.prims);
     for (int i = threadIdx.x; i < sc.nprims * 2; i += blockDim.x) lds.rows[i] = src[i];
@@ -249,6 +250,17 @@ template <>
 struct Sdf<RM_SCENE_MANDELBULB> {
   static RM_DEV void stage(const DevScene&, SceneLds&) {}
   template <class M>
+  static RM_DEV void generic_round(v3& z, float& dr, v3 pos, float r, float power) {
+    float theta = M::acos(M::div(z.z, r));
+    float phi = M::atan2(z.y, z.x);
+    dr = M::pow(r, power - 1.0f) * power * dr + 1.0f;
+    float zr = M::pow(r, power);
+    theta = theta * power;
+    phi = phi * power;
+    z = V(M::sin(theta) * M::cos(phi), M::sin(phi) * M::sin(theta), M::cos(theta)) * zr;
+    z = z + pos;
+  }
+  template <class M>
   static RM_DEV float eval_generic(const DevScene& sc, v3 pos) {
     const float power = sc.p[RM_P_BULB_POWER];
     const int iterations = (int)sc.p[RM_P_BULB_ITERATIONS];
@@ -258,14 +270,7 @@ struct Sdf<RM_SCENE_MANDELBULB> {
     for (int i = 0; i < iterations; i++) {
       r = length<M>(z);
       if (r > bailout) break;
-      float theta = M::acos(M::div(z.z, r));
-      float phi = M::atan2(z.y, z.x);
-      dr = M::pow(r, power - 1.0f) * power * dr + 1.0f;
-      float zr = M::pow(r, power);
-      theta = theta * power;
-      phi = phi * power;
-      z = V(M::sin(theta) * M::cos(phi), M::sin(phi) * M::sin(theta), M::cos(theta)) * zr;
-      z = z + pos;
+      generic_round<M>(z, dr, pos, r, power);
     }
     return M::div(0.5f * M::log(r) * r, dr);
   }
@@ -273,6 +278,24 @@ struct Sdf<RM_SCENE_MANDELBULB> {
   // r^8 (cos 8theta + i sin 8theta) and (z.x + i z.y)^8 = rho^8 (cos 8phi + i sin 8phi),
   // each by three complex squarings.  The same function as eval_generic up to
   // rounding; 2 sqrt + 1 rcp per iteration instead of 12 transcendentals.
+  static RM_DEV void pow8_round(v3& z, float& dr, v3 pos, float rho2, float r2) {
+    const float r = FM::sqrt(r2);
+    const float rho = FM::sqrt(rho2);
+    const float r4 = r2 * r2;
+    dr = FM::fma((r4 * r2 * r) * 8.0f, dr, 1.0f);
+    // (A + iB) = (z.z + i rho)^8, (C + iD) = (z.x + i z.y)^8
+    float A = z.z, B = rho, C = z.x, D = z.y, t;
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+      t = (A + B) * (A - B); B = 2.0f * A * B; A = t;
+      t = (C + D) * (C - D); D = 2.0f * C * D; C = t;
+    }
+    const float rho4 = rho2 * rho2;
+    const float rho8 = rho4 * rho4;
+    const bool on_axis = !(rho8 > 0.0f);  // phi = atan(0, 0) = 0 there: cos 8phi = 1, sin 8theta = 0
+    const float s8 = on_axis ? 0.0f : B * FM::rcp(rho8);  // r^8 sin(8 theta) / rho^8
+    z = V(FM::fma(s8, C, pos.x), FM::fma(s8, D, pos.y), A + pos.z);
+  }
   static RM_DEV float eval_pow8(const DevScene& sc, v3 pos) {
     const int iterations = (int)sc.p[RM_P_BULB_ITERATIONS];
     const float bail2 = sc.p[RM_P_BULB_BAILOUT] * sc.p[RM_P_BULB_BAILOUT];
@@ -282,22 +305,7 @@ struct Sdf<RM_SCENE_MANDELBULB> {
       const float rho2 = FM::fma(z.y, z.y, z.x * z.x);
       r2 = FM::fma(z.z, z.z, rho2);
       if (r2 > bail2) break;
-      const float r = FM::sqrt(r2);
-      const float rho = FM::sqrt(rho2);
-      const float r4 = r2 * r2;
-      dr = FM::fma((r4 * r2 * r) * 8.0f, dr, 1.0f);
-      // (A + iB) = (z.z + i rho)^8, (C + iD) = (z.x + i z.y)^8
-      float A = z.z, B = rho, C = z.x, D = z.y, t;
-#pragma unroll
-      for (int s = 0; s < 3; s++) {
-        t = (A + B) * (A - B); B = 2.0f * A * B; A = t;
-        t = (C + D) * (C - D); D = 2.0f * C * D; C = t;
-      }
-      const float rho4 = rho2 * rho2;
-      const float rho8 = rho4 * rho4;
-      const bool on_axis = !(rho8 > 0.0f);  // phi = atan(0, 0) = 0 there: cos 8phi = 1, sin 8theta = 0
-      const float s8 = on_axis ? 0.0f : B * FM::rcp(rho8);  // r^8 sin(8 theta) / rho^8
-      z = V(FM::fma(s8, C, pos.x), FM::fma(s8, D, pos.y), A + pos.z);
+      pow8_round(z, dr, pos, rho2, r2);
     }
     const float r = FM::sqrt(r2);
     return 0.5f * FM::log(r) * r * FM::rcp(dr);
@@ -306,6 +314,49 @@ struct Sdf<RM_SCENE_MANDELBULB> {
   static RM_DEV float eval(const DevScene& sc, const SceneLds&, v3 p) {
     if (M::fast && sc.p[RM_P_BULB_POWER] == 8.0f) return eval_pow8(sc, p);
     return eval_generic<M>(sc, p);
+  }
+  // Cost classes.  The evaluation runs 0..`iterations` rounds of z -> z^n + c
+  // depending on how close p is to the set: far points bail out at once, points
+  // on the surface run them all (about 10x the cost).  eval_cheap is eval() with
+  // the round count capped: it returns false -- and no distance -- when p needs
+  // more than `cap` rounds; otherwise the same bits as eval().  The wavefront
+  // march uses it to keep cheap and expensive rays in separate waves.
+  static constexpr bool has_cost_classes = true;
+  static constexpr int cheap_cap = 2;
+  template <class M>
+  static RM_DEV bool eval_cheap(const DevScene& sc, const SceneLds& lds, v3 p, float& d) {
+    const int iterations = (int)sc.p[RM_P_BULB_ITERATIONS];
+    if (iterations <= cheap_cap) { d = eval<M>(sc, lds, p); return true; }
+    // a capped run that used all its rounds without bailing out is not a finished evaluation
+    bool bailed = false;
+    if (M::fast && sc.p[RM_P_BULB_POWER] == 8.0f) {
+      const float bail2 = sc.p[RM_P_BULB_BAILOUT] * sc.p[RM_P_BULB_BAILOUT];
+      v3 z = p;
+      float dr = 1.0f, r2 = 0.0f;
+      for (int i = 0; i <= cheap_cap; i++) {
+        const float rho2 = FM::fma(z.y, z.y, z.x * z.x);
+        r2 = FM::fma(z.z, z.z, rho2);
+        if (r2 > bail2) { bailed = true; break; }
+        if (i == cheap_cap) break;
+        pow8_round(z, dr, p, rho2, r2);
+      }
+      if (!bailed) return false;
+      const float r = FM::sqrt(r2);
+      d = 0.5f * FM::log(r) * r * FM::rcp(dr);
+      return true;
+    }
+    const float power = sc.p[RM_P_BULB_POWER], bailout = sc.p[RM_P_BULB_BAILOUT];
+    v3 z = p;
+    float dr = 1.0f, r = 0.0f;
+    for (int i = 0; i <= cheap_cap; i++) {
+      r = length<M>(z);
+      if (r > bailout) { bailed = true; break; }
+      if (i == cheap_cap) break;
+      generic_round<M>(z, dr, p, r, power);
+    }
+    if (!bailed) return false;
+    d = M::div(0.5f * M::log(r) * r, dr);
+    return true;
   }
 };
 
@@ -319,6 +370,7 @@ RM_DEV void stage_pow_table(SceneLds& lds, float base, float first) {
 // RM_SCENE_SPHERE_GRID: examples/guide.glsl:91-102 == examples/fractal1.glsl:23-34
 template <>
 struct Sdf<RM_SCENE_SPHERE_GRID> {
+  static constexpr bool has_cost_classes = false;  // every evaluation costs the same
   static RM_DEV void stage(const DevScene& sc, SceneLds& lds) { stage_pow_table(lds, sc.p[RM_P_GRID_SCALE], -1.0f); }
   template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds& lds, v3 p) {
@@ -341,6 +393,7 @@ struct Sdf<RM_SCENE_SPHERE_GRID> {
 // RM_SCENE_SPHERE_LATTICE: dist/examples/sphere-grid.glsl:42-49
 template <>
 struct Sdf<RM_SCENE_SPHERE_LATTICE> {
+  static constexpr bool has_cost_classes = false;  // every evaluation costs the same
   static RM_DEV void stage(const DevScene&, SceneLds&) {}
   template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds&, v3 p) {
@@ -353,6 +406,7 @@ struct Sdf<RM_SCENE_SPHERE_LATTICE> {
 // RM_SCENE_MENGER: examples/menger-sponge.glsl:6-23
 template <>
 struct Sdf<RM_SCENE_MENGER> {
+  static constexpr bool has_cost_classes = false;  // every evaluation costs the same
   static RM_DEV void stage(const DevScene&, SceneLds& lds) { stage_pow_table(lds, 0.33333333333333f, 1.0f); }
   template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds& lds, v3 p) {
@@ -393,6 +447,7 @@ RM_DEV v3 kifs_rotate(v3 t, const KifsTrig& g) {
 // RM_SCENE_KIFS_TREE: examples/tree.glsl:16-36, examples/smooth-tree.glsl:30-56
 template <>
 struct Sdf<RM_SCENE_KIFS_TREE> {
+  static constexpr bool has_cost_classes = false;  // every evaluation costs the same
   static RM_DEV void stage(const DevScene& sc, SceneLds& lds) { stage_pow_table(lds, sc.p[RM_P_KIFS_SCALE], 0.0f); }
   template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds& lds, v3 p) {
@@ -418,6 +473,7 @@ struct Sdf<RM_SCENE_KIFS_TREE> {
 // RM_SCENE_KIFS_BOX: examples/rotation-fractal.glsl:16-35
 template <>
 struct Sdf<RM_SCENE_KIFS_BOX> {
+  static constexpr bool has_cost_classes = false;  // every evaluation costs the same
   static RM_DEV void stage(const DevScene&, SceneLds&) {}
   template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds&, v3 p) {

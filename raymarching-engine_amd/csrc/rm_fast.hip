@@ -5,3 +5,4 @@
 #include <type_traits>
 #include "rm_device.hpp"
 #include "rm_kernels.inc"
+#include "rm_wavefront.inc"

@@ -32,9 +32,48 @@ struct ProbeParams {
   int n;
   int what;
   float param;
+  float retire_eps;
 };
 
 namespace rm {
+enum {
+  WF_POS = 0,   // xyz ray position (march in/out), w = step budget
+  WF_DIR,       // xyz ray direction, w = deltaZ (preview)
+  WF_OLD,       // xyz position at the start of the bounce, w = rng.seed
+  WF_ALB,       // xyz albedo accumulated over bounces
+  WF_LIG,       // xyz light accumulated over bounces
+  WF_NRM,       // xyz normal of the current bounce
+  WF_PDIR,      // xyz prevRayDirection
+  WF_DIF,       // xyz diffuseCol
+  WF_SPC,       // xyz specularCol
+  WF_PALB,      // xyz prevAlbedo
+  WF_ADJ,       // xyz adjustedLightPosition
+  WF_SPOS,      // shadow ray position (march in/out), w = step budget
+  WF_SDIR,      // shadow ray direction
+  WF_AUX,       // preview: x = stepsTaken, y = depth
+  WF_ARRAYS
+};
+
+struct WfParams {
+  KParams k;
+  float4* a[WF_ARRAYS];
+  unsigned int* head;  // queue head of THIS march launch (zeroed by the host)
+  unsigned int* list;        // ray ids parked by the cheap pass for the full pass
+  unsigned int* list_count;  // number of parked rays (zeroed by the host)
+  unsigned long long* stats;  // RM_WF_STATS builds: [shadow?][pass2?][rays, lane-steps, wave-steps, -]
+  int n_rays;          // tiles_x * tiles_y * 64
+  int tiles_x;
+  int bounce;          // current bounce index
+  int light;           // current light index
+  int last_bounce;     // 1: this is the last bounce of the sample
+  int pos_array, dir_array;  // which arrays the march kernel works on
+};
+
+// pass 0: single pass; 1: cheap pass (parks rays that need the deep evaluation); 2: full pass over the parked list
+hipError_t wf_launch_march_strict(const WfParams& W, bool preview, int pass, int blocks, hipStream_t stream);
+hipError_t wf_launch_march_fast(const WfParams& W, bool preview, int pass, int blocks, hipStream_t stream);
+bool wf_kind_has_cost_classes(int kind);
+hipError_t wf_launch_stage(const WfParams& W, int stage, hipStream_t stream);
 hipError_t launch_pixels_strict(const KParams& P, hipStream_t stream);
 hipError_t launch_pixels_fast(const KParams& P, hipStream_t stream);
 hipError_t launch_probe_strict(const ProbeParams& P, hipStream_t stream);

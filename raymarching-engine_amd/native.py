@@ -22,7 +22,7 @@ LIB_PATH = Path(os.environ.get("RM_LIB") or Path(__file__).resolve().parent / "l
 # every symbol include/hip_raymarch.h declares
 EXPORTS = [
     "rm_abi_version", "rm_material_default", "rm_ctx_create", "rm_ctx_destroy", "rm_last_error", "rm_ctx_set_stream",
-    "rm_sync", "rm_scene_create", "rm_scene_destroy", "rm_fb_create", "rm_fb_wrap", "rm_fb_clear", "rm_fb_destroy",
+    "rm_ctx_set_retire_eps", "rm_debug_counters", "rm_sync", "rm_scene_create", "rm_scene_destroy", "rm_fb_create", "rm_fb_wrap", "rm_fb_clear", "rm_fb_destroy",
     "rm_fb_download", "rm_fb_upload", "rm_fb_device_ptr", "rm_render_sample", "rm_render_samples", "rm_render_timed",
     "rm_probe", "rm_probe_camera", "rm_probe_rng",
 ]
@@ -54,6 +54,8 @@ def load_library():
         "rm_ctx_destroy": (None, [vp]),
         "rm_last_error": (C.c_char_p, [vp]),
         "rm_ctx_set_stream": (ip, [vp, vp]),
+        "rm_ctx_set_retire_eps": (ip, [vp, C.c_float]),
+        "rm_debug_counters": (ip, [vp, C.POINTER(C.c_ulonglong), ip]),
         "rm_sync": (ip, [vp]),
         "rm_scene_create": (ip, [vp, C.POINTER(abi.RmSceneDesc), C.POINTER(vp)]),
         "rm_scene_destroy": (None, [vp]),
@@ -113,6 +115,14 @@ class Context:
     def set_stream(self, hip_stream: Optional[int]):
         self._check(self.lib.rm_ctx_set_stream(self.h, C.c_void_p(hip_stream or 0)))
 
+    def set_retire_eps(self, eps: float):
+        self._check(self.lib.rm_ctx_set_retire_eps(self.h, float(eps)))
+
+    def debug_counters(self, reset: bool = True):
+        out = (C.c_ulonglong * 16)()
+        self._check(self.lib.rm_debug_counters(self.h, out, 1 if reset else 0))
+        return list(out)
+
     def sync(self):
         self._check(self.lib.rm_sync(self.h))
 
@@ -141,8 +151,8 @@ class Context:
         return float(ms.value)
 
     def probe(self, scene: "SceneHandle", what: int, inputs: np.ndarray, param: float = 0.0, flags: int = abi.RM_RENDER_STRICT) -> np.ndarray:
-        in_w = {abi.RM_PROBE_SDF: 3, abi.RM_PROBE_CAST_RAY: 6, abi.RM_PROBE_NORMAL: 3, abi.RM_PROBE_MATERIAL: 3}[what]
-        out_w = {abi.RM_PROBE_SDF: 1, abi.RM_PROBE_CAST_RAY: 3, abi.RM_PROBE_NORMAL: 3, abi.RM_PROBE_MATERIAL: 12}[what]
+        in_w = {abi.RM_PROBE_SDF: 3, abi.RM_PROBE_CAST_RAY: 6, abi.RM_PROBE_NORMAL: 3, abi.RM_PROBE_MATERIAL: 3, abi.RM_PROBE_CAST_STEPS: 6}[what]
+        out_w = {abi.RM_PROBE_SDF: 1, abi.RM_PROBE_CAST_RAY: 3, abi.RM_PROBE_NORMAL: 3, abi.RM_PROBE_MATERIAL: 12, abi.RM_PROBE_CAST_STEPS: 1}[what]
         a = np.ascontiguousarray(inputs, np.float32).reshape(-1, in_w)
         out = np.empty((len(a), out_w), np.float32)
         self._check(self.lib.rm_probe(self.h, scene.h, what, _fp(a), len(a), float(param), flags, _fp(out)))

@@ -216,6 +216,45 @@ def test_fast_build_close_to_strict(ctx, case):
     assert abs(ma - mb) <= (0.02 if case == "mandelbulb_full_light" else 0.005) * max(1e-6, abs(ma))  # 2048 px, 1 spp of a fractal with GGX highlights
 
 
+@pytest.mark.parametrize("case", list(GC.IMAGES))
+def test_wavefront_pipeline_equals_megakernel(ctx, case):
+    """The default wavefront pipeline (ray-compacting persistent march,
+    rm_wavefront.inc) and the one-thread-one-pixel kernel run the same
+    per-pixel program: bit-identical in the strict build, and in the fast
+    build when only the exact retire is enabled (eps = 0)."""
+    sc, samples, schema = GC.image_schema(case)
+    noises = load("image_" + case)["rand_noise"]
+    a = render_gpu(ctx, sc, schema, noises, STRICT)
+    b = render_gpu(ctx, sc, schema, noises, STRICT | abi.RM_RENDER_MEGAKERNEL)
+    full = schema["render"]["renderMode"] == "full"
+    for k in range(3 if full else 1):
+        assert same_bits(a[k], b[k]).all(), f"plane {k}"
+    ctx.set_retire_eps(0.0)
+    try:
+        a = render_gpu(ctx, sc, schema, noises, FAST)
+        b = render_gpu(ctx, sc, schema, noises, FAST | abi.RM_RENDER_MEGAKERNEL)
+    finally:
+        ctx.set_retire_eps(2.0 ** -21)
+    for k in range(3 if full else 1):
+        assert same_bits(a[k], b[k]).all(), f"fast plane {k}"
+
+
+def test_wavefront_odd_sizes_and_tiles(ctx):
+    """Tile rectangles that are not multiples of 8 (padding rays), a row window,
+    and a one-pixel image."""
+    sc = GC.build_scene("csg_mixed")
+    schema = J.make_schema(sc, 37, 21, render_mode="full", counts=(24, 12), position=(0.3, 0.2, -4.0), lights=GC.LIGHT)
+    noises = GC.halton_pairs(2)
+    for rows, tile in ((None, None), ((5, 11), None), (None, abi.RmRect(3, 2, 17, 13)), ((5, 11), abi.RmRect(30, 0, 20, 40))):
+        a = render_gpu(ctx, sc, schema, noises, STRICT, rows=rows, tile=tile)
+        b = render_gpu(ctx, sc, schema, noises, STRICT | abi.RM_RENDER_MEGAKERNEL, rows=rows, tile=tile)
+        for k in range(3):
+            assert same_bits(a[k], b[k]).all()
+    one = J.make_schema(sc, 1, 1, render_mode="preview", counts=(16,), position=(0.3, 0.2, -4.0))
+    a = render_gpu(ctx, sc, one, noises, STRICT)[0]
+    assert same_bits(a, render_oracle(sc, one, noises)[0]).all()
+
+
 # ---- full-size properties (BASELINE.json sizes) -----------------------------------
 
 
