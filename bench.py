@@ -7,10 +7,11 @@ scene at 3840x2160 (BASELINE.json), one process per GPU.
 
 A step = one sample of every pixel of the frame (one run of the reference's
 main() per pixel: RenderJobExecutor.tsx:299) + the frame assembly on rank 0.
-With N GPUs the frame's rows are sharded (no exchange between samples; each
-pixel depends only on itself) and the colour plane is gathered
-to rank 0 over RCCL once per step, as the reference presents once per sample
-in its live loop (index.tsx:158-169).  Total work is fixed => strong scaling.
+With N GPUs the frame's rows are sharded in 8-row stripes dealt round-robin
+(no exchange between samples; each pixel depends only on itself, SURVEY.md
+8(e)) and the colour plane is gathered to rank 0 over RCCL once per step and
+put back in image order, as the reference presents once per sample in its live
+loop (index.tsx:158-169).  Total work is fixed => strong scaling.
 
 Rank 0 prints ONE JSON line.  `roofline` is the fp32-VALU roofline of the
 pixel kernel (the path has no contraction, so no MFMA; HBM traffic is ~100 B
@@ -60,12 +61,6 @@ def make_workload(key):
     return w, sc, schema
 
 
-def shard_rows(height, world, rank):
-    """Contiguous row blocks: rank g holds rows [g*H/N, (g+1)*H/N)."""
-    b = [(height * i) // world for i in range(world + 1)]
-    return b[rank], b[rank + 1] - b[rank]
-
-
 def cpu_baseline(sc, schema, target_seconds=12.0):
     """The oracle on the host cores over evenly spaced rows of the same frame."""
     from oracle import oracle as O
@@ -108,13 +103,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3b", choices=list(WORKLOADS))
     ap.add_argument("--strict", action="store_true", help="parity build instead of the fast build")
+    ap.add_argument("--megakernel", action="store_true", help="one-thread-one-pixel kernel instead of the wavefront pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     import numpy as np
     import torch
 
-    from raymarching_engine_amd import abi, job as J, native
+    from raymarching_engine_amd import abi, dist as rmdist, job as J, native, shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -132,18 +128,19 @@ def main():
 
     wl, sc, schema = make_workload(args.workload)
     W, H = wl["width"], wl["height"]
-    row_begin, row_count = shard_rows(H, world, rank)
     flags = abi.RM_RENDER_STRICT if args.strict else abi.RM_RENDER_FAST
+    if args.megakernel:
+        flags |= abi.RM_RENDER_MEGAKERNEL
 
     ctx = native.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # launches ordered with torch / RCCL work
-    planes = [torch.zeros((row_count, W, 4), dtype=torch.float32, device=dev) for _ in range(3)]
-    fb = ctx.wrap_framebuffer(W, H, row_begin, row_count, *(p.data_ptr() for p in planes))
+    gatherer = rmdist.FrameGatherer(H, W, world, rank, dev)
+    row_count = gatherer.rows
+    # planes live in torch memory (padded to the largest shard so that the gather is regular)
+    planes = [torch.zeros((gatherer.max_rows, W, 4), dtype=torch.float32, device=dev) for _ in range(3)]
+    fb = ctx.create_striped_framebuffer(W, H, shard.STRIPE_ROWS, world, rank, *(p.data_ptr() for p in planes))
+    assert fb.row_count == row_count
     scene = ctx.create_scene(sc)
-    frame = None
-    if world > 1 and rank == 0:
-        counts = [shard_rows(H, world, r)[1] for r in range(world)]
-        frame = [torch.empty((c, W, 4), dtype=torch.float32, device=dev) for c in counts]
 
     h2, h3 = J.halton(2), J.halton(3)
 
@@ -151,7 +148,7 @@ def main():
         u = J.uniforms_from_schema(schema, (next(h2), next(h3)))
         ctx.render_sample(scene, fb, u, None, flags)
         if world > 1:
-            dist.gather(planes[0], frame if rank == 0 else None, dst=0)
+            gatherer.gather(planes[0], dist)
 
     for _ in range(args.warmup):
         step()
@@ -198,7 +195,8 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["name"], "build": "strict" if args.strict else "fast",
-                       "rows_per_gpu": row_count, "sharding": "contiguous row blocks, colour plane gathered to rank 0 per step" if world > 1 else "none",
+                       "rows_per_gpu": row_count, "pipeline": "megakernel" if args.megakernel else "wavefront",
+                       "sharding": f"{shard.STRIPE_ROWS}-row stripes round-robin over ranks, colour plane gathered to rank 0 and re-ordered every step" if world > 1 else "none",
                        "planes": "color+normal_dof+albedo_depth fp32, accumulated in place"},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -234,6 +234,17 @@ void rm_scene_destroy(rm_scene* scene);
  * across GPUs): pixel coordinates, texcoord and aspect stay global.
  * Planes are zero-initialised.  Row 0 is the BOTTOM row (GL convention). */
 int rm_fb_create(rm_ctx* ctx, int width, int height, int row_begin, int row_count, rm_fb** out);
+/* Row-striped window for sharding one image over several GPUs with balanced
+ * cost: the frame is cut into stripes of `stripe_rows` rows and this
+ * framebuffer holds, packed in ascending order, the stripes k with
+ * k % parts == part (rows r with (r / stripe_rows) % parts == part).
+ * rm_fb_rows() tells how many rows that is.  Planes may be caller-owned
+ * (non-NULL color; normal_dof/albedo_depth both or neither) or NULL to let the
+ * library allocate them.  Pixel coordinates stay global as in rm_fb_create. */
+int rm_fb_create_striped(rm_ctx* ctx, int width, int height, int stripe_rows, int parts, int part,
+                         void* color, void* normal_dof, void* albedo_depth, rm_fb** out);
+/* Number of image rows a framebuffer holds. */
+int rm_fb_rows(const rm_fb* fb);
 /* Same, but over caller-owned device memory (e.g. torch tensors): each plane
  * pointer addresses row_count*width float4; normal_dof/albedo_depth may be
  * NULL (then only RM_RENDER_COLOR_ONLY renders are accepted). */

@@ -41,7 +41,8 @@ struct rm_scene {
 
 struct rm_fb {
   rm_ctx* ctx = nullptr;
-  int width = 0, height = 0, row_begin = 0, row_count = 0;
+  int width = 0, height = 0, row_begin = 0, row_count = 0;  // row_count = rows held by the planes
+  int stripe_rows = 0, parts = 1, part = 0;                 // striped window when stripe_rows > 0
   float4* plane[3] = {nullptr, nullptr, nullptr};
   bool owned = false;
 };
@@ -262,6 +263,57 @@ int rm_fb_create(rm_ctx* ctx, int width, int height, int row_begin, int row_coun
   return RM_OK;
 }
 
+// rows r < y owned by a striped framebuffer
+static int striped_rows_below(int y, int stripe, int parts, int part) {
+  const int period = stripe * parts;
+  const int q = y / period, rem = y % period;
+  int in = rem - part * stripe;
+  in = in < 0 ? 0 : (in > stripe ? stripe : in);
+  return q * stripe + in;
+}
+
+int rm_fb_create_striped(rm_ctx* ctx, int width, int height, int stripe_rows, int parts, int part, void* color,
+                         void* normal_dof, void* albedo_depth, rm_fb** out) {
+  if (!ctx || !out) return fail(ctx, RM_ERR_INVALID, "rm_fb_create_striped: NULL argument");
+  *out = nullptr;
+  if (int rc = fb_check(ctx, width, height, 0, 1)) return rc;
+  if (stripe_rows < 1 || parts < 1 || part < 0 || part >= parts) return fail(ctx, RM_ERR_INVALID, "rm_fb_create_striped: need stripe_rows >= 1 and 0 <= part < parts");
+  if ((normal_dof == nullptr) != (albedo_depth == nullptr) || (!color && normal_dof)) return fail(ctx, RM_ERR_INVALID, "rm_fb_create_striped: give all planes, colour only, or none");
+  if ((reinterpret_cast<uintptr_t>(color) | reinterpret_cast<uintptr_t>(normal_dof) | reinterpret_cast<uintptr_t>(albedo_depth)) & 15u)
+    return fail(ctx, RM_ERR_INVALID, "rm_fb_create_striped: planes must be 16-byte aligned");
+  const int rows = striped_rows_below(height, stripe_rows, parts, part);
+  if (rows < 1) return fail(ctx, RM_ERR_INVALID, "rm_fb_create_striped: this part holds no rows");
+  rm_fb* fb = new (std::nothrow) rm_fb();
+  if (!fb) return fail(ctx, RM_ERR_DEVICE, "out of host memory");
+  fb->ctx = ctx;
+  fb->width = width; fb->height = height; fb->row_begin = 0; fb->row_count = rows;
+  fb->stripe_rows = stripe_rows; fb->parts = parts; fb->part = part;
+  if (color) {
+    fb->plane[0] = static_cast<float4*>(color);
+    fb->plane[1] = static_cast<float4*>(normal_dof);
+    fb->plane[2] = static_cast<float4*>(albedo_depth);
+    fb->owned = false;
+  } else {
+    fb->owned = true;
+    (void)hipSetDevice(ctx->device);
+    const size_t bytes = sizeof(float4) * (size_t)width * (size_t)rows;
+    for (int i = 0; i < 3; i++) {
+      hipError_t e = hipMalloc(reinterpret_cast<void**>(&fb->plane[i]), bytes);
+      if (e == hipSuccess) e = hipMemsetAsync(fb->plane[i], 0, bytes, ctx->stream);
+      if (e != hipSuccess) {
+        for (int j = 0; j <= i; j++)
+          if (fb->plane[j]) (void)hipFree(fb->plane[j]);
+        delete fb;
+        return fail(ctx, RM_ERR_DEVICE, std::string("rm_fb_create_striped: ") + hipGetErrorString(e));
+      }
+    }
+  }
+  *out = fb;
+  return RM_OK;
+}
+
+int rm_fb_rows(const rm_fb* fb) { return fb ? fb->row_count : 0; }
+
 int rm_fb_wrap(rm_ctx* ctx, int width, int height, int row_begin, int row_count, void* color, void* normal_dof,
                void* albedo_depth, rm_fb** out) {
   if (!ctx || !out || !color) return fail(ctx, RM_ERR_INVALID, "rm_fb_wrap: NULL argument");
@@ -336,18 +388,27 @@ static int build_params(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniform
   if (!color_only && u->renderMode == 0 && (!fb->plane[1] || !fb->plane[2]))
     return fail(ctx, RM_ERR_INVALID, "render: framebuffer has no G-buffer planes; pass RM_RENDER_COLOR_ONLY");
   RmRect t = tile ? *tile : RmRect{0, 0, fb->width, fb->height};
-  // clip to the image and to this framebuffer's row window
-  int x0 = t.x < 0 ? 0 : t.x, y0 = t.y < fb->row_begin ? fb->row_begin : t.y;
-  int x1 = t.x + t.w > fb->width ? fb->width : t.x + t.w;
-  int y1 = t.y + t.h > fb->row_begin + fb->row_count ? fb->row_begin + fb->row_count : t.y + t.h;
-  *empty = x1 <= x0 || y1 <= y0;
+  // clip to the image, then to the rows this framebuffer holds (as LOCAL row indices)
+  const int x0 = t.x < 0 ? 0 : t.x, x1 = t.x + t.w > fb->width ? fb->width : t.x + t.w;
+  int y0 = t.y < 0 ? 0 : t.y, y1 = t.y + t.h > fb->height ? fb->height : t.y + t.h;
+  if (y1 < y0) y1 = y0;
+  int l0, l1;
+  if (fb->stripe_rows > 0) {
+    l0 = striped_rows_below(y0, fb->stripe_rows, fb->parts, fb->part);
+    l1 = striped_rows_below(y1, fb->stripe_rows, fb->parts, fb->part);
+  } else {
+    l0 = (y0 < fb->row_begin ? fb->row_begin : y0) - fb->row_begin;
+    l1 = (y1 > fb->row_begin + fb->row_count ? fb->row_begin + fb->row_count : y1) - fb->row_begin;
+  }
+  *empty = x1 <= x0 || l1 <= l0;
   P->u = *u;
   P->scene = scene->dev;
   P->color = fb->plane[0];
   P->normal_dof = color_only ? nullptr : fb->plane[1];
   P->albedo_depth = color_only ? nullptr : fb->plane[2];
   P->W = fb->width; P->H = fb->height; P->row_begin = fb->row_begin;
-  P->tx = x0; P->ty = y0; P->tw = x1 - x0; P->th = y1 - y0;
+  P->stripe_rows = fb->stripe_rows; P->parts = fb->parts; P->part = fb->part;
+  P->tx = x0; P->ty = l0; P->tw = x1 - x0; P->th = l1 - l0;
   P->retire_eps = (flags & RM_RENDER_FAST) ? ctx->retire_eps : 0.0f;
   return RM_OK;
 }

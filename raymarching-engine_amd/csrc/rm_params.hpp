@@ -20,10 +20,17 @@ struct KParams {
   float4* normal_dof;    // nullptr = colour only
   float4* albedo_depth;
   int W, H;            // full image (textureSize(previousColor), raymarcher.frag:183)
-  int row_begin;       // first image row held by the planes
-  int tx, ty, tw, th;  // tile, already clipped to the window
+  int row_begin;       // contiguous window: first image row held by the planes
+  int stripe_rows, parts, part;  // striped window (stripe_rows > 0): rows r with (r / stripe_rows) % parts == part
+  int tx, ty, tw, th;  // tile clipped to the window; ty/th count LOCAL rows (rows of the planes)
   float retire_eps;    // 0 = exact (fixed-point) retire only
 };
+
+// image row of a local (plane) row
+__host__ __device__ inline int rm_global_row(const KParams& P, int local) {
+  if (P.stripe_rows <= 0) return P.row_begin + local;
+  return ((local / P.stripe_rows) * P.parts + P.part) * P.stripe_rows + local % P.stripe_rows;
+}
 
 struct ProbeParams {
   DevScene scene;

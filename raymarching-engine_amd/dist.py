@@ -1,0 +1,49 @@
+"""Frame assembly across ranks: one process per GPU, torch.distributed (backend
+"nccl" = RCCL over xGMI on a GPU node, "gloo" in the CPU tests).
+
+The only collective of the path is a gather of the colour plane to rank 0 once
+per presented frame; rendering itself needs no exchange.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+from . import shard
+
+
+class FrameGatherer:
+    """Gathers row-striped colour planes to `dst` and puts them in image order.
+
+    Every rank passes a plane padded to `max_rows` rows (ranks can differ by one
+    stripe); buffers and the row index tensors are allocated once.
+    """
+
+    def __init__(self, height: int, width: int, world: int, rank: int, device, dst: int = 0, channels: int = 4,
+                 stripe_rows: int = shard.STRIPE_ROWS):
+        import torch
+
+        self.torch = torch
+        self.height, self.width, self.world, self.rank, self.dst = height, width, world, rank, dst
+        self.stripe_rows = stripe_rows
+        self.counts = shard.row_counts(height, world, stripe_rows)
+        self.max_rows = max(self.counts)
+        self.rows = self.counts[rank]
+        self.recv: Optional[List] = None
+        self.frame = None
+        self.index = None
+        if rank == dst:
+            self.recv = [torch.empty((self.max_rows, width, channels), dtype=torch.float32, device=device) for _ in range(world)]
+            self.frame = torch.empty((height, width, channels), dtype=torch.float32, device=device)
+            self.index = [torch.as_tensor(shard.owned_rows(height, world, p, stripe_rows), device=device) for p in range(world)]
+
+    def gather(self, plane, dist):
+        """plane: [max_rows, W, C] tensor of this rank (first self.rows rows valid).
+        Returns the assembled [H, W, C] frame on dst, None elsewhere."""
+        if self.world == 1:
+            return plane[: self.rows]
+        dist.gather(plane, self.recv if self.rank == self.dst else None, dst=self.dst)
+        if self.rank != self.dst:
+            return None
+        for p in range(self.world):
+            self.frame.index_copy_(0, self.index[p], self.recv[p][: self.counts[p]])
+        return self.frame

@@ -22,7 +22,7 @@ LIB_PATH = Path(os.environ.get("RM_LIB") or Path(__file__).resolve().parent / "l
 # every symbol include/hip_raymarch.h declares
 EXPORTS = [
     "rm_abi_version", "rm_material_default", "rm_ctx_create", "rm_ctx_destroy", "rm_last_error", "rm_ctx_set_stream",
-    "rm_ctx_set_retire_eps", "rm_debug_counters", "rm_sync", "rm_scene_create", "rm_scene_destroy", "rm_fb_create", "rm_fb_wrap", "rm_fb_clear", "rm_fb_destroy",
+    "rm_ctx_set_retire_eps", "rm_debug_counters", "rm_sync", "rm_scene_create", "rm_scene_destroy", "rm_fb_create", "rm_fb_create_striped", "rm_fb_rows", "rm_fb_wrap", "rm_fb_clear", "rm_fb_destroy",
     "rm_fb_download", "rm_fb_upload", "rm_fb_device_ptr", "rm_render_sample", "rm_render_samples", "rm_render_timed",
     "rm_probe", "rm_probe_camera", "rm_probe_rng",
 ]
@@ -61,6 +61,8 @@ def load_library():
         "rm_scene_destroy": (None, [vp]),
         "rm_fb_create": (ip, [vp, ip, ip, ip, ip, C.POINTER(vp)]),
         "rm_fb_wrap": (ip, [vp, ip, ip, ip, ip, vp, vp, vp, C.POINTER(vp)]),
+        "rm_fb_create_striped": (ip, [vp, ip, ip, ip, ip, ip, vp, vp, vp, C.POINTER(vp)]),
+        "rm_fb_rows": (ip, [vp]),
         "rm_fb_clear": (ip, [vp]),
         "rm_fb_destroy": (None, [vp]),
         "rm_fb_download": (ip, [vp, ip, fp]),
@@ -132,6 +134,10 @@ class Context:
     def create_framebuffer(self, width: int, height: int, row_begin: int = 0, row_count: Optional[int] = None) -> "Framebuffer":
         return Framebuffer(self, width, height, row_begin, height if row_count is None else row_count)
 
+    def create_striped_framebuffer(self, width, height, stripe_rows, parts, part, color_ptr=None, normal_ptr=None, albedo_ptr=None) -> "Framebuffer":
+        """Rows r with (r // stripe_rows) % parts == part, packed (row sharding across GPUs)."""
+        return Framebuffer(self, width, height, 0, 0, striped=(stripe_rows, parts, part, color_ptr, normal_ptr, albedo_ptr))
+
     def wrap_framebuffer(self, width, height, row_begin, row_count, color_ptr, normal_ptr=None, albedo_ptr=None) -> "Framebuffer":
         return Framebuffer(self, width, height, row_begin, row_count, wrap=(color_ptr, normal_ptr, albedo_ptr))
 
@@ -184,11 +190,16 @@ class SceneHandle:
 
 
 class Framebuffer:
-    def __init__(self, ctx: Context, width, height, row_begin, row_count, wrap=None):
+    def __init__(self, ctx: Context, width, height, row_begin, row_count, wrap=None, striped=None):
         self.ctx = ctx
         self.width, self.height, self.row_begin, self.row_count = width, height, row_begin, row_count
         h = C.c_void_p()
-        if wrap is None:
+        if striped is not None:
+            s, n, r, c0, c1, c2 = striped
+            ctx._check(ctx.lib.rm_fb_create_striped(ctx.h, width, height, s, n, r, C.c_void_p(c0 or 0), C.c_void_p(c1 or 0),
+                                                    C.c_void_p(c2 or 0), C.byref(h)))
+            self.row_count = int(ctx.lib.rm_fb_rows(h))
+        elif wrap is None:
             ctx._check(ctx.lib.rm_fb_create(ctx.h, width, height, row_begin, row_count, C.byref(h)))
         else:
             ctx._check(ctx.lib.rm_fb_wrap(ctx.h, width, height, row_begin, row_count, C.c_void_p(wrap[0]),

@@ -317,6 +317,41 @@ def test_full_size_invariances(ctx):
     h.destroy()
 
 
+@pytest.mark.parametrize("parts", [2, 3, 8])
+def test_striped_row_sharding_equals_single_frame(ctx, parts):
+    """What N GPUs of a row-striped run would hold, assembled, is bit-identical
+    to the single-frame render (3840x2160, both pipelines)."""
+    from raymarching_engine_amd import shard
+
+    sc, schema = _c3b(counts=(32,))
+    noises = GC.halton_pairs(1)
+    flags = FAST
+    h = ctx.create_scene(sc)
+    for mk in (abi.RM_RENDER_MEGAKERNEL, 0):  # each pipeline against its own single-frame render
+        whole = render_gpu(ctx, sc, schema, noises, flags | mk)
+        pieces = [[], [], []]
+        for part in range(parts):
+            fb = ctx.create_striped_framebuffer(3840, 2160, shard.STRIPE_ROWS, parts, part)
+            assert fb.row_count == len(shard.owned_rows(2160, parts, part))
+            for n in noises:
+                ctx.render_sample(h, fb, J.uniforms_from_schema(schema, n), None, flags | mk)
+            for k in range(3):
+                pieces[k].append(fb.download(k))
+            fb.destroy()
+        for k in range(3):
+            assert same_bits(shard.assemble(pieces[k], 2160), whole[k]).all()
+    # a tile that cuts through stripes
+    fb = ctx.create_striped_framebuffer(3840, 2160, shard.STRIPE_ROWS, parts, parts - 1)
+    ctx.render_sample(h, fb, J.uniforms_from_schema(schema, noises[0]), abi.RmRect(100, 1001, 300, 77), flags)
+    rows = shard.owned_rows(2160, parts, parts - 1)
+    got = fb.download(0)
+    inside = (rows >= 1001) & (rows < 1078)
+    assert same_bits(got[inside][:, 100:400], whole[0][rows[inside]][:, 100:400]).all()
+    assert not got[~inside].any() and not got[:, :100].any() and not got[:, 400:].any()
+    fb.destroy()
+    h.destroy()
+
+
 def test_c4_c5_configs_run_and_match_on_a_crop(ctx):
     """BASELINE.json configs[3]/[4] (64-primitive smooth-union CSG, soft shadow
     + 3 bounces): one row window as a GPU of an 8-way split would hold it."""
