@@ -64,5 +64,19 @@ def build_native(force: bool = False, verbose: bool = False, extra=(), out: Path
     return lib
 
 
+def build_node_addon(force: bool = False) -> Path:
+    """The N-API addon of the JS host (js/rm_napi.cc), against the system Node headers."""
+    src, out = HERE / "js" / "rm_napi.cc", HERE / "js" / "rm_napi.node"
+    inc = Path("/usr/include/node")
+    if not (inc / "node_api.h").exists():
+        raise RuntimeError("Node N-API headers not found (/usr/include/node)")
+    if not force and out.exists() and out.stat().st_mtime >= max(src.stat().st_mtime, LIB.stat().st_mtime):
+        return out
+    subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-I", str(inc), str(src), "-o", str(out),
+                    "-L", str(HERE), "-lhip_raymarch", "-Wl,-rpath,$ORIGIN/.."], check=True)
+    return out
+
+
 if __name__ == "__main__":
     print(build_native(force="--force" in sys.argv, verbose=True))
+    print(build_node_addon(force="--force" in sys.argv))

@@ -1,0 +1,56 @@
+// Typings of the JS host (index.js).  The job description is the reference's
+// RenderJobSchema (client/src/renderer/RenderJobSchema.tsx:17-86) plus `sdfScene`.
+export type Vec3 = [number, number, number];
+export type UniformData = { type: "f" | "i" | "ui"; count: 1 | 2 | 3 | 4; data: number[] };
+export type RenderJobLight =
+  | { type: "point"; position: Vec3; color: Vec3; size: number }
+  | { type: "sun"; direction: Vec3; color: Vec3 };
+export interface Material {
+  diffuse: Vec3; diffuse_cutoff: number; specular: Vec3; specular_cutoff: number; roughness: number; subsurface: number;
+  subsurface_color: Vec3; ior: number; sky_color: Vec3; sky_floor: number; sky_scale: number; sky_radius: number; sky_axis: 0 | 1 | 2;
+}
+export class Scene { kind: number; params: number[]; material: Material; key(): string; }
+export class CsgScene extends Scene {
+  constructor(material?: Partial<Material>);
+  union(): this; smoothUnion(k: number): this; subtract(): this; intersect(): this;
+  sphere(center: Vec3, radius: number): this; box(center: Vec3, halfExtents: Vec3): this;
+  glsl(): string;
+}
+export class Mandelbulb extends Scene { constructor(power?: number, iterations?: number, bailout?: number, material?: Partial<Material>); }
+export function singleSphere(center?: Vec3, radius?: number, material?: Partial<Material>): CsgScene;
+export type RenderJobSchema = {
+  reflectionIterationCounts: number[];
+  normalDelta: number;
+  sdfShaderSource: string;
+  sdfScene: Scene;
+  customShaderParameters: { [key: string]: UniformData };
+  fogDensity: number;
+  time: number;
+  timeDelta: number;
+  dof: { amount: number; distance: number; showFocusedArea: boolean };
+  camera: {
+    position: Vec3; motion: Vec3; rotation: ArrayLike<number>;
+    mode: { type: "perspective"; fov: number } | { type: "orthographic"; size: number } | { type: "panoramic"; angleX: number; angleY: number };
+  };
+  render: {
+    samplesPerPixel: number; exposure: number; subdivisions: number; width: number; height: number; frameid: number;
+    blendWithPreviousFrameFactor: number; sampleYieldInterval: number; blendMode: "additive" | "mix"; renderMode: "full" | "preview";
+  };
+  lights: RenderJobLight[];
+};
+export type RenderJobFramebufferInfo = { width: number; height: number; frameid: number; download(plane?: 0 | 1 | 2): Float32Array };
+export type ShaderError = { type: "vertex" | "fragment" | "program"; infoLog: string };
+export class RenderJobContext {
+  constructor(device?: number, flags?: number);
+  fboCreate(width: number, height: number, frameid: number): RenderJobFramebufferInfo;
+  fboDelete(width: number, height: number, frameid: number): void;
+  close(): void;
+}
+export type Present = (schema: RenderJobSchema, context: RenderJobContext, framebuffers: RenderJobFramebufferInfo, samplesSoFar: number) => void;
+export function doRenderJob(schema: RenderJobSchema, context: RenderJobContext): Promise<
+  (present: Present) => Generator<undefined, { success: boolean; why?: ShaderError | { type: "general"; infoLog: string } }, unknown>
+>;
+export function uniformsFromSchema(schema: RenderJobSchema, randNoise: [number, number]): ArrayBuffer;
+export function halton(base: number): Generator<number, never, unknown>;
+export function resetHalton(): void;
+export const RM: { [name: string]: number };

@@ -1,0 +1,203 @@
+// index.js -- JavaScript host of the render-job API on top of the N-API addon.
+//
+// Mirrors client/src/renderer/RenderJobExecutor.tsx:77-341 of the reference:
+// `doRenderJob(schema, context)` resolves to a generator factory; the generator
+// yields every `sampleYieldInterval` samples after calling `present`, and
+// returns {success:true} or {success:false, why} -- errors are values.  The
+// gl.* block of the reference (:181-326) is one native call per sample.
+// The RenderJobSchema is the reference's (RenderJobSchema.tsx:17-86) plus
+// `sdfScene`, a scene built with the composition API below (a HIP kernel
+// cannot consume GLSL text; the composer emits both back ends).
+// Types: index.d.ts.  (The container has Node 12 / N-API 8 and no tsc, so the
+// host is JavaScript with hand-written typings.)
+"use strict";
+const addon = require("./rm_napi.node");
+
+const RM = {
+  MAX_BOUNCES: 10, MAX_LIGHTS: 10,
+  SCENE_TABLE: 0, SCENE_MANDELBULB: 1, SCENE_SPHERE_GRID: 2, SCENE_SPHERE_LATTICE: 3, SCENE_MENGER: 4, SCENE_KIFS_TREE: 5, SCENE_KIFS_BOX: 6,
+  PRIM_SPHERE: 0, PRIM_BOX: 1, OP_UNION: 0, OP_SMOOTH_UNION: 1, OP_SUBTRACT: 2, OP_INTERSECT: 3,
+  RENDER_STRICT: 0, RENDER_FAST: 1, RENDER_COLOR_ONLY: 2, RENDER_MEGAKERNEL: 4,
+};
+
+// ---- struct layouts (include/hip_raymarch.h; all fields are 4 bytes) ----------------
+const U_FIELDS = [
+  ["blendWithPreviousFactor", 1, "f"], ["randNoise", 2, "f"], ["position", 3, "f"], ["rotation", 16, "f"], ["dofAmount", 1, "f"],
+  ["dofFocalPlaneDistance", 1, "f"], ["cameraMode", 1, "i"], ["fov", 1, "f"], ["reflections", 1, "f"], ["raymarchingSteps", 1, "f"],
+  ["indirectLightingRaymarchingSteps", 1, "f"], ["aspect", 1, "f"], ["fogDensity", 1, "f"], ["exposure", 1, "f"],
+  ["raymarchingStepCountsArray", 10, "f"], ["blendMode", 1, "i"], ["renderMode", 1, "i"], ["lightPositions", 30, "f"],
+  ["lightColors", 30, "f"], ["lightSizes", 10, "f"], ["lightCount", 1, "i"], ["showDofFocalPlane", 1, "i"],
+];
+const U_OFFSET = {};
+let uSize = 0;
+for (const [name, n] of U_FIELDS) { U_OFFSET[name] = uSize; uSize += 4 * n; }
+if (uSize !== addon.sizes().RmUniforms) throw new Error("RmUniforms layout mismatch: " + uSize + " != " + addon.sizes().RmUniforms);
+
+function packUniforms(values) {
+  const buf = new ArrayBuffer(uSize);
+  const f = new Float32Array(buf), i = new Int32Array(buf);
+  for (const [name, n, t] of U_FIELDS) {
+    const v = values[name];
+    if (v === undefined) continue;
+    const at = U_OFFSET[name] / 4, arr = n === 1 && !Array.isArray(v) ? [v] : v;
+    for (let k = 0; k < arr.length && k < n; k++) (t === "f" ? f : i)[at + k] = arr[k];
+  }
+  return buf;
+}
+
+// ---- scene composition --------------------------------------------------------------
+const DEFAULT_MATERIAL = {  // Validate.tsx:18-51
+  diffuse: [0.6, 0.6, 0.6], diffuse_cutoff: 35, specular: [0.6, 0.6, 0.6], specular_cutoff: 35, roughness: 0.2, subsurface: 11111115,
+  subsurface_color: [1, 1, 1], ior: 100, sky_color: [0.7, 0.8, 1.0], sky_floor: 0.2, sky_scale: 2, sky_radius: 36, sky_axis: 1,
+};
+const glf = (x) => { const s = String(Math.fround(x)); return /[.e]/.test(s) ? s : s + ".0"; };
+const glv = (v) => `vec3(${glf(v[0])}, ${glf(v[1])}, ${glf(v[2])})`;
+
+class Scene {
+  constructor(kind, params, material) { this.kind = kind; this.params = params || []; this.material = Object.assign({}, DEFAULT_MATERIAL, material || {}); this.prims = []; }
+  // RmSceneDesc bytes: kind, nprims, prims pointer (8, filled natively), params[16], material (22 x 4)
+  desc() {
+    const buf = new ArrayBuffer(addon.sizes().RmSceneDesc);
+    const f = new Float32Array(buf), i = new Int32Array(buf);
+    i[0] = this.kind; i[1] = this.prims.length;
+    for (let k = 0; k < this.params.length; k++) f[4 + k] = this.params[k];
+    const m = this.material, at = 20;
+    f.set([...m.diffuse, m.diffuse_cutoff, ...m.specular, m.specular_cutoff, m.roughness, m.subsurface, ...m.subsurface_color, m.ior,
+           ...m.sky_color, m.sky_floor, m.sky_scale, m.sky_radius], at);
+    i[at + 20] = m.sky_axis;
+    let prims = null;
+    if (this.prims.length) {
+      prims = new ArrayBuffer(32 * this.prims.length);
+      const pf = new Float32Array(prims), pi = new Int32Array(prims);
+      this.prims.forEach((p, n) => { pi[8 * n] = p.prim | (p.op << 8); pf[8 * n + 1] = p.k; pf.set(p.center, 8 * n + 2); pf.set(p.size, 8 * n + 5); });
+    }
+    return { desc: buf, prims };
+  }
+  key() { const d = this.desc(); return Buffer.from(d.desc).toString("hex") + (d.prims ? Buffer.from(d.prims).toString("hex") : ""); }
+}
+
+class CsgScene extends Scene {
+  constructor(material) { super(RM.SCENE_TABLE, [], material); this._op = RM.OP_UNION; this._k = 0; }
+  union() { this._op = RM.OP_UNION; this._k = 0; return this; }
+  smoothUnion(k) { this._op = RM.OP_SMOOTH_UNION; this._k = k; return this; }
+  subtract() { this._op = RM.OP_SUBTRACT; this._k = 0; return this; }
+  intersect() { this._op = RM.OP_INTERSECT; this._k = 0; return this; }
+  sphere(center, radius) { this.prims.push({ prim: RM.PRIM_SPHERE, op: this._op, k: this._k, center, size: [radius, 0, 0] }); return this; }
+  box(center, half) { this.prims.push({ prim: RM.PRIM_BOX, op: this._op, k: this._k, center, size: half }); return this; }
+  glsl() {  // the reference's scene contract: float sdf(vec3); helpers sdfSphere/sdBox come from raymarcher.frag:74,108
+    const lines = [];
+    if (this.prims.slice(1).some((p) => p.op === RM.OP_SMOOTH_UNION))
+      lines.push("float rmSmoothUnion(float d1, float d2, float k) { float h = clamp(0.5 + 0.5 * (d2 - d1) / k, 0.0, 1.0); return mix(d2, d1, h) - k * h * (1.0 - h); }");
+    lines.push("float sdf(vec3 p) {");
+    this.prims.forEach((n, i) => {
+      const e = n.prim === RM.PRIM_SPHERE ? `sdfSphere(p, ${glv(n.center)}, ${glf(n.size[0])})` : `sdBox(p - ${glv(n.center)}, ${glv(n.size)})`;
+      if (i === 0) lines.push(`  float d = ${e};`);
+      else if (n.op === RM.OP_UNION) lines.push(`  d = min(d, ${e});`);
+      else if (n.op === RM.OP_SMOOTH_UNION) lines.push(`  d = rmSmoothUnion(d, ${e}, ${glf(n.k)});`);
+      else if (n.op === RM.OP_SUBTRACT) lines.push(`  d = max(d, -${e});`);
+      else lines.push(`  d = max(d, ${e});`);
+    });
+    lines.push("  return d;", "}");
+    return lines.join("\n");
+  }
+}
+const singleSphere = (center = [0, 0, 0], radius = 1, material) => new CsgScene(material).sphere(center, radius);
+class Mandelbulb extends Scene {
+  constructor(power = 8, iterations = 8, bailout = 2, material) { super(RM.SCENE_MANDELBULB, [power, iterations, bailout], material); }
+}
+
+// ---- host side of the job -------------------------------------------------------------
+function* halton(b) {  // util/Halton.tsx:1-19, value for value
+  for (let i = 1; ; i++) { let num = 0, den = 1; for (let k = i; k > 0; k = Math.floor(k / b)) { num = num * b + (k % b); den *= b; } yield num / den; }
+}
+let halton2 = halton(2), halton3 = halton(3);  // module-level like RenderJobExecutor.tsx:70-71: continues across jobs
+const resetHalton = () => { halton2 = halton(2); halton3 = halton(3); };
+
+function uniformsFromSchema(schema, randNoise) {  // RenderJobExecutor.tsx:212-297
+  const cam = schema.camera, r = schema.render, counts = schema.reflectionIterationCounts;
+  if (counts.length > RM.MAX_BOUNCES || schema.lights.length > RM.MAX_LIGHTS) throw new Error("at most 10 bounces / 10 lights");
+  const mode = cam.mode.type;
+  const pos = [], col = [], size = [];
+  for (const l of schema.lights) { pos.push(...(l.type === "point" ? l.position : l.direction)); col.push(...l.color); size.push(l.type === "point" ? l.size : 0); }
+  return packUniforms({
+    blendWithPreviousFactor: r.blendWithPreviousFrameFactor, randNoise, position: cam.position, rotation: Array.from(cam.rotation),
+    dofAmount: schema.dof.amount, dofFocalPlaneDistance: schema.dof.distance,
+    cameraMode: ["perspective", "orthographic", "panoramic"].indexOf(mode),
+    fov: mode === "perspective" ? cam.mode.fov : mode === "orthographic" ? cam.mode.size : 1,
+    reflections: counts.length, raymarchingSteps: counts[0], indirectLightingRaymarchingSteps: counts.length > 1 ? counts[1] : counts[0],
+    aspect: r.width / r.height, fogDensity: schema.fogDensity, exposure: r.exposure / r.samplesPerPixel,
+    raymarchingStepCountsArray: counts, blendMode: r.blendMode === "additive" ? 1 : 0, renderMode: r.renderMode === "preview" ? 1 : 0,
+    lightPositions: pos, lightColors: col, lightSizes: size, lightCount: schema.lights.length, showDofFocalPlane: schema.dof.showFocusedArea ? 1 : 0,
+  });
+}
+
+function tileRect(schema, xp, yp) {  // :167-180 (the intent of the scissor call, see DESIGN.md)
+  const r = schema.render, n = r.subdivisions;
+  const x1 = Math.floor((r.width / n) * xp), y1 = Math.floor((r.height / n) * yp);
+  const x2 = Math.ceil((r.width / n) * (xp + 1)), y2 = Math.ceil((r.height / n) * (yp + 1));
+  return new Int32Array([x1, y1, x2 - x1, y2 - y1]);
+}
+
+class RenderJobContext {  // RenderJobContext + loadRenderJobContext (LoadRenderJobContext.tsx:162-287)
+  constructor(device = 0, flags = RM.RENDER_STRICT) {
+    this.ctx = addon.ctxCreate(device); this.flags = flags; this.scenes = new Map(); this.live = new Map(); this.purgatory = [];
+  }
+  getScene(scene) {  // programCache.getProgram: results AND errors are cached (ShaderCache.tsx:91-119)
+    const key = scene.key();
+    if (!this.scenes.has(key)) {
+      try { const d = scene.desc(); this.scenes.set(key, addon.sceneCreate(this.ctx, d.desc, d.prims)); }
+      catch (e) { this.scenes.set(key, { type: "fragment", infoLog: String(e.message) }); }
+    }
+    return this.scenes.get(key);
+  }
+  fboCreate(w, h, frameid) {  // :186-223
+    const key = `${w}x${h}#${frameid}`;
+    if (this.live.has(key)) return this.live.get(key);
+    const i = this.purgatory.findIndex((e) => e.w === w && e.h === h);
+    let fb;
+    if (i >= 0) { const e = this.purgatory.splice(i, 1)[0]; if (e.frameid !== frameid) addon.fbClear(e.fb); fb = e.fb; }
+    else fb = addon.fbCreate(this.ctx, w, h, 0, h);
+    const info = { fb, width: w, height: h, frameid, download: (plane = 0) => { const out = new Float32Array(w * h * 4); addon.fbDownload(this.ctx, fb, plane, out); return out; } };
+    this.live.set(key, info);
+    return info;
+  }
+  fboDelete(w, h, frameid) {  // :227-248: parked in a <= 3 entry purgatory
+    const key = `${w}x${h}#${frameid}`, info = this.live.get(key);
+    if (!info) return;
+    this.live.delete(key);
+    this.purgatory.push({ w, h, frameid, fb: info.fb });
+    while (this.purgatory.length > 3) addon.fbDestroy(this.purgatory.shift().fb);
+  }
+  close() { for (const e of this.purgatory) addon.fbDestroy(e.fb); for (const v of this.live.values()) addon.fbDestroy(v.fb);
+            for (const s of this.scenes.values()) if (!(s && s.infoLog)) addon.sceneDestroy(s); addon.ctxDestroy(this.ctx); }
+}
+
+async function doRenderJob(schema, context) {  // RenderJobExecutor.tsx:77
+  const fail = (why) => function* () { return { success: false, why }; };
+  const r = schema.render;
+  let framebuffers;
+  try { framebuffers = context.fboCreate(r.width, r.height, r.frameid); }
+  catch (e) { return fail({ type: "general", infoLog: "Failed to load framebuffers. " + e.message }); }
+  if (!schema.sdfScene) return fail({ type: "fragment", infoLog: "no sdfScene: the HIP back end takes a composed scene, not GLSL text" });
+  const scene = context.getScene(schema.sdfScene);
+  if (scene && scene.infoLog !== undefined) return fail(scene);
+  let samples = 0;
+  return function* (present) {
+    for (let yp = 0; yp < r.subdivisions; yp++) for (let xp = 0; xp < r.subdivisions; xp++) {
+      const tile = tileRect(schema, xp, yp);
+      for (let s = 0; s < r.samplesPerPixel; s++) {
+        if (samples % r.sampleYieldInterval === 0) { addon.sync(context.ctx); present(schema, context, framebuffers, samples); yield; }
+        const u = uniformsFromSchema(schema, [halton2.next().value, halton3.next().value]);
+        addon.renderSample(context.ctx, scene, framebuffers.fb, u, tile, context.flags);
+        samples++;
+      }
+    }
+    context.fboDelete(r.width, r.height, r.frameid);
+    addon.sync(context.ctx);
+    present(schema, context, framebuffers, samples);
+    return { success: true };
+  };
+}
+
+module.exports = { RM, addon, Scene, CsgScene, Mandelbulb, singleSphere, DEFAULT_MATERIAL, halton, resetHalton, uniformsFromSchema, packUniforms,
+                   tileRect, RenderJobContext, doRenderJob, U_OFFSET };

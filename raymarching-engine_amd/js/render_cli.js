@@ -1,0 +1,36 @@
+// node render_cli.js <out.f32> -- renders a small job through doRenderJob and writes the colour plane (tests/test_js_host.py)
+"use strict";
+const fs = require("fs");
+const rm = require("./index.js");
+(async () => {
+  const out = process.argv[2];
+  const mode = process.argv[3] || "render";
+  const schema = {
+    reflectionIterationCounts: [48, 24], normalDelta: 1e-5, sdfShaderSource: "", customShaderParameters: {}, fogDensity: 0, time: 0, timeDelta: 0,
+    sdfScene: new rm.CsgScene().box([0, 0, 0], [1.0, 0.6, 0.8]).subtract().sphere([0.4, 0.3, -0.6], 0.7).smoothUnion(0.3).sphere([-1.2, 0.2, 0.0], 0.5),
+    dof: { amount: 0, distance: 1.5, showFocusedArea: false },
+    camera: { position: [0.3, 0.2, -4.0], motion: [0, 0, 0], rotation: [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1], mode: { type: "perspective", fov: 1.5 } },
+    render: { samplesPerPixel: 3, exposure: 0.5, subdivisions: 2, width: 64, height: 32, frameid: 1, blendWithPreviousFrameFactor: 0.9,
+              sampleYieldInterval: 2, blendMode: "additive", renderMode: "full" },
+    lights: [{ type: "point", position: [2, 3, -4], color: [255 * 3 / 256, 255 * 3 / 256, 255 * 3 / 256], size: 0 }],
+  };
+  if (mode === "layout") {  // no GPU needed: the uniform block bytes and the scene description
+    const u = rm.uniformsFromSchema(schema, [0.5, 1 / 3]);
+    const d = schema.sdfScene.desc();
+    process.stdout.write(JSON.stringify({ uniforms: Buffer.from(u).toString("hex"), desc: Buffer.from(d.desc).toString("hex"),
+      prims: Buffer.from(d.prims).toString("hex"), glsl: schema.sdfScene.glsl(), halton3: (() => { const g = rm.halton(3); return [g.next().value, g.next().value, g.next().value]; })() }));
+    return;
+  }
+  const ctx = new rm.RenderJobContext(0, rm.RM.RENDER_STRICT);
+  rm.resetHalton();
+  const seen = [];
+  const gen = (await rm.doRenderJob(schema, ctx))((s, c, fb, n) => seen.push(n));
+  let res;
+  for (;;) { const it = gen.next(); if (it.done) { res = it.value; break; } }
+  const fb = ctx.fboCreate(64, 32, 1);
+  fs.writeFileSync(out, Buffer.from(fb.download(0).buffer));
+  const bad = await rm.doRenderJob(Object.assign({}, schema, { sdfScene: new rm.CsgScene().smoothUnion(-1).sphere([0, 0, 0], 1).sphere([1, 0, 0], 1) }), ctx);
+  const badRes = bad(() => {}).next().value;
+  process.stdout.write(JSON.stringify({ res, seen, badRes }));
+  ctx.close();
+})().catch((e) => { console.error(e); process.exit(1); });

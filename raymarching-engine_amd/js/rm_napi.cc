@@ -1,0 +1,227 @@
+// rm_napi.cc -- Node N-API binding of libhip_raymarch.so (include/hip_raymarch.h).
+//
+// Deliberately thin: structs are laid out in JS ArrayBuffers (index.js knows
+// the byte offsets of RmUniforms / RmSceneDesc) and handed over as pointers;
+// handles travel as N-API externals.  Every function returns a value or
+// throws a JS Error carrying rm_last_error(); the render-job layer above
+// (index.js doRenderJob) turns those into the reference's error VALUES
+// ({success:false, why}), RenderJobExecutor.tsx:112-136.
+#include <node_api.h>
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+
+#include "../../include/hip_raymarch.h"
+
+#define NAPI_OK(call)                                             \
+  do {                                                            \
+    if ((call) != napi_ok) {                                      \
+      napi_throw_error(env, nullptr, "N-API call failed: " #call); \
+      return nullptr;                                             \
+    }                                                             \
+  } while (0)
+
+static napi_value throw_rm(napi_env env, rm_ctx* ctx, const char* what) {
+  std::string msg = std::string(what) + ": " + rm_last_error(ctx);
+  napi_throw_error(env, "RM_ERROR", msg.c_str());
+  return nullptr;
+}
+
+template <class T>
+static T* get_external(napi_env env, napi_value v) {
+  void* p = nullptr;
+  if (napi_get_value_external(env, v, &p) != napi_ok) return nullptr;
+  return static_cast<T*>(p);
+}
+
+static bool get_buffer(napi_env env, napi_value v, void** data, size_t* len) {
+  bool is_ab = false;
+  if (napi_is_arraybuffer(env, v, &is_ab) == napi_ok && is_ab) return napi_get_arraybuffer_info(env, v, data, len) == napi_ok;
+  bool is_ta = false;
+  if (napi_is_typedarray(env, v, &is_ta) == napi_ok && is_ta) {
+    napi_typedarray_type t;
+    size_t n, off;
+    napi_value ab;
+    if (napi_get_typedarray_info(env, v, &t, &n, data, &ab, &off) != napi_ok) return false;
+    static const size_t width[] = {1, 1, 1, 2, 2, 4, 4, 4, 8, 8, 8};
+    *len = n * width[t];
+    return true;
+  }
+  return false;
+}
+
+static napi_value CtxCreate(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  int32_t device = 0;
+  if (argc > 0) napi_get_value_int32(env, argv[0], &device);
+  rm_ctx* ctx = nullptr;
+  if (rm_ctx_create(device, &ctx) != RM_OK) return throw_rm(env, nullptr, "rm_ctx_create");
+  napi_value out;
+  NAPI_OK(napi_create_external(env, ctx, nullptr, nullptr, &out));
+  return out;
+}
+
+static napi_value CtxDestroy(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  rm_ctx_destroy(get_external<rm_ctx>(env, argv[0]));
+  return nullptr;
+}
+
+static napi_value Sync(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  rm_ctx* ctx = get_external<rm_ctx>(env, argv[0]);
+  if (rm_sync(ctx) != RM_OK) return throw_rm(env, ctx, "rm_sync");
+  return nullptr;
+}
+
+// sceneCreate(ctx, descBuffer /* RmSceneDesc bytes, prims pointer ignored */, primsBuffer | null)
+static napi_value SceneCreate(napi_env env, napi_callback_info info) {
+  size_t argc = 3;
+  napi_value argv[3];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  rm_ctx* ctx = get_external<rm_ctx>(env, argv[0]);
+  void* d = nullptr;
+  size_t n = 0;
+  if (!ctx || !get_buffer(env, argv[1], &d, &n) || n != sizeof(RmSceneDesc)) {
+    napi_throw_type_error(env, nullptr, "sceneCreate(ctx, desc: ArrayBuffer(sizeof RmSceneDesc), prims)");
+    return nullptr;
+  }
+  RmSceneDesc desc;
+  std::memcpy(&desc, d, sizeof desc);
+  desc.prims = nullptr;
+  void* p = nullptr;
+  size_t pn = 0;
+  if (argc > 2 && get_buffer(env, argv[2], &p, &pn)) {
+    if (pn != sizeof(RmPrim) * (size_t)desc.nprims) {
+      napi_throw_type_error(env, nullptr, "sceneCreate: prims buffer must hold nprims rows of 32 bytes");
+      return nullptr;
+    }
+    desc.prims = static_cast<const RmPrim*>(p);
+  }
+  rm_scene* scene = nullptr;
+  if (rm_scene_create(ctx, &desc, &scene) != RM_OK) return throw_rm(env, ctx, "rm_scene_create");
+  napi_value out;
+  NAPI_OK(napi_create_external(env, scene, nullptr, nullptr, &out));
+  return out;
+}
+
+static napi_value SceneDestroy(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  rm_scene_destroy(get_external<rm_scene>(env, argv[0]));
+  return nullptr;
+}
+
+// fbCreate(ctx, width, height, rowBegin, rowCount)
+static napi_value FbCreate(napi_env env, napi_callback_info info) {
+  size_t argc = 5;
+  napi_value argv[5];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  rm_ctx* ctx = get_external<rm_ctx>(env, argv[0]);
+  int32_t v[4] = {0, 0, 0, 0};
+  for (int i = 0; i < 4; i++) napi_get_value_int32(env, argv[1 + i], &v[i]);
+  rm_fb* fb = nullptr;
+  if (rm_fb_create(ctx, v[0], v[1], v[2], v[3], &fb) != RM_OK) return throw_rm(env, ctx, "rm_fb_create");
+  napi_value out;
+  NAPI_OK(napi_create_external(env, fb, nullptr, nullptr, &out));
+  return out;
+}
+
+static napi_value FbClear(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  rm_fb_clear(get_external<rm_fb>(env, argv[0]));
+  return nullptr;
+}
+
+static napi_value FbDestroy(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  rm_fb_destroy(get_external<rm_fb>(env, argv[0]));
+  return nullptr;
+}
+
+// fbDownload(ctx, fb, plane, out: Float32Array(rows*width*4))
+static napi_value FbDownload(napi_env env, napi_callback_info info) {
+  size_t argc = 4;
+  napi_value argv[4];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  rm_ctx* ctx = get_external<rm_ctx>(env, argv[0]);
+  rm_fb* fb = get_external<rm_fb>(env, argv[1]);
+  int32_t plane = 0;
+  napi_get_value_int32(env, argv[2], &plane);
+  void* d = nullptr;
+  size_t n = 0;
+  if (!fb || !get_buffer(env, argv[3], &d, &n)) {
+    napi_throw_type_error(env, nullptr, "fbDownload(ctx, fb, plane, out: Float32Array)");
+    return nullptr;
+  }
+  if (rm_fb_download(fb, plane, static_cast<float*>(d)) != RM_OK) return throw_rm(env, ctx, "rm_fb_download");
+  return nullptr;
+}
+
+// renderSample(ctx, scene, fb, uniforms: ArrayBuffer(sizeof RmUniforms), tile: Int32Array(4) | null, flags)
+static napi_value RenderSample(napi_env env, napi_callback_info info) {
+  size_t argc = 6;
+  napi_value argv[6];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  rm_ctx* ctx = get_external<rm_ctx>(env, argv[0]);
+  rm_scene* scene = get_external<rm_scene>(env, argv[1]);
+  rm_fb* fb = get_external<rm_fb>(env, argv[2]);
+  void* u = nullptr;
+  size_t un = 0;
+  if (!get_buffer(env, argv[3], &u, &un) || un != sizeof(RmUniforms)) {
+    napi_throw_type_error(env, nullptr, "renderSample: uniforms must be an ArrayBuffer of sizeof(RmUniforms) bytes");
+    return nullptr;
+  }
+  RmRect tile;
+  const RmRect* tp = nullptr;
+  void* t = nullptr;
+  size_t tn = 0;
+  if (argc > 4 && get_buffer(env, argv[4], &t, &tn) && tn == sizeof(RmRect)) {
+    std::memcpy(&tile, t, sizeof tile);
+    tp = &tile;
+  }
+  int32_t flags = 0;
+  if (argc > 5) napi_get_value_int32(env, argv[5], &flags);
+  if (rm_render_sample(ctx, scene, fb, static_cast<const RmUniforms*>(u), tp, flags) != RM_OK) return throw_rm(env, ctx, "rm_render_sample");
+  return nullptr;
+}
+
+static napi_value Sizes(napi_env env, napi_callback_info) {
+  napi_value o, v;
+  NAPI_OK(napi_create_object(env, &o));
+  const struct { const char* k; uint32_t v; } items[] = {
+      {"RmUniforms", (uint32_t)sizeof(RmUniforms)}, {"RmSceneDesc", (uint32_t)sizeof(RmSceneDesc)}, {"RmPrim", (uint32_t)sizeof(RmPrim)},
+      {"RmMaterial", (uint32_t)sizeof(RmMaterial)}, {"RmRect", (uint32_t)sizeof(RmRect)}, {"abi", (uint32_t)rm_abi_version()}};
+  for (const auto& it : items) {
+    NAPI_OK(napi_create_uint32(env, it.v, &v));
+    NAPI_OK(napi_set_named_property(env, o, it.k, v));
+  }
+  return o;
+}
+
+static napi_value Init(napi_env env, napi_value exports) {
+  const struct { const char* name; napi_callback fn; } fns[] = {
+      {"ctxCreate", CtxCreate}, {"ctxDestroy", CtxDestroy}, {"sync", Sync}, {"sceneCreate", SceneCreate}, {"sceneDestroy", SceneDestroy},
+      {"fbCreate", FbCreate}, {"fbClear", FbClear}, {"fbDestroy", FbDestroy}, {"fbDownload", FbDownload}, {"renderSample", RenderSample},
+      {"sizes", Sizes}};
+  for (const auto& f : fns) {
+    napi_value fn;
+    if (napi_create_function(env, f.name, NAPI_AUTO_LENGTH, f.fn, nullptr, &fn) != napi_ok) return nullptr;
+    if (napi_set_named_property(env, exports, f.name, fn) != napi_ok) return nullptr;
+  }
+  return exports;
+}
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, Init)

@@ -1,0 +1,77 @@
+"""The JavaScript host (raymarching-engine_amd/js): N-API addon + doRenderJob mirror."""
+import json
+import shutil
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import golden_cases as GC
+from oracle import oracle as O
+from raymarching_engine_amd import job as J
+from raymarching_engine_amd import scene as S
+
+ROOT = Path(__file__).resolve().parents[1]
+JS = ROOT / "raymarching-engine_amd" / "js"
+pytestmark = pytest.mark.skipif(shutil.which("node") is None or not (JS / "rm_napi.node").exists(), reason="node or the addon is missing")
+
+
+def _scene():
+    return S.CsgScene().box((0, 0, 0), (1.0, 0.6, 0.8)).subtract().sphere((0.4, 0.3, -0.6), 0.7).smooth_union(0.3).sphere((-1.2, 0.2, 0.0), 0.5)
+
+
+def _schema(sc):
+    return J.make_schema(sc, 64, 32, render_mode="full", counts=(48, 24), position=(0.3, 0.2, -4.0), lights=GC.LIGHT,
+                         samples_per_pixel=3, subdivisions=2, sample_yield_interval=2, frameid=1)
+
+
+def test_js_layouts_match_the_c_abi():
+    """The JS side lays out RmUniforms / RmSceneDesc / RmPrim by hand: byte for byte what ctypes produces."""
+    out = json.loads(subprocess.run(["node", str(JS / "render_cli.js"), "-", "layout"], capture_output=True, text=True, check=True).stdout)
+    sc = _scene()
+    schema = _schema(sc)
+    u = J.uniforms_from_schema(schema, (0.5, 1 / 3))
+    assert out["uniforms"] == bytes(u).hex()
+    d = sc.desc()
+    import ctypes as C
+    from raymarching_engine_amd import abi
+
+    raw = bytearray(bytes(d))
+    raw[8:16] = b"\0" * 8  # the prims pointer is filled natively
+    assert out["desc"] == bytes(raw).hex()
+    assert out["prims"] == bytes(C.string_at(d.prims, 32 * d.nprims)).hex()
+    assert out["glsl"].count("sdfSphere(") == 2 and "rmSmoothUnion(d," in out["glsl"]
+    g = J.halton(3)
+    assert out["halton3"] == [next(g), next(g), next(g)]
+
+
+def test_js_addon_fails_loudly_without_gpu():
+    r = subprocess.run(["node", "-e", "try{require('%s').ctxCreate(0);console.log('ok')}catch(e){console.log(e.message)}" % (JS / "rm_napi.node")],
+                       capture_output=True, text=True)
+    assert "ok" in r.stdout or "no CPU fallback" in r.stdout
+
+
+@pytest.mark.gpu
+def test_js_do_render_job_matches_oracle(tmp_path):
+    out = tmp_path / "c.f32"
+    r = subprocess.run(["node", str(JS / "render_cli.js"), str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    info = json.loads(r.stdout)
+    assert info["res"] == {"success": True} and info["seen"] == [0, 2, 4, 6, 8, 10, 12]  # 4 tiles x 3 samples, yield every 2
+    assert info["badRes"]["success"] is False and info["badRes"]["why"]["type"] == "fragment" and "smooth union" in info["badRes"]["why"]["infoLog"]
+    got = np.fromfile(out, np.float32).reshape(32, 64, 4)
+    sc = _scene()
+    schema = _schema(sc)
+    O.set_tan_mode(O.TAN_PORTABLE)
+    fr = O.Frame(64, 32)
+    h2, h3 = J.halton(2), J.halton(3)
+    for yp in range(2):
+        for xp in range(2):
+            t = J.tile_rect(schema, xp, yp)
+            for _ in range(3):
+                O.render(sc, J.uniforms_from_schema(schema, (next(h2), next(h3))), fr, tile=(t.x, t.y, t.w, t.h))
+    with np.errstate(invalid="ignore"):
+        d = np.abs(got - fr.color) / np.maximum(1, np.abs(fr.color))
+    d[np.isnan(got) & np.isnan(fr.color)] = 0
+    assert np.mean(~(d.max(-1) <= 1e-5)) <= 0.01
