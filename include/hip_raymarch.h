@@ -307,6 +307,19 @@ int rm_probe_camera(rm_ctx* ctx, const RmUniforms* uniforms, int width, int heig
  * out = height*width*count floats, HOST pointer. */
 int rm_probe_rng(rm_ctx* ctx, const RmUniforms* uniforms, int width, int height, int count, float* out);
 
+/* ---- present ----------------------------------------------------------- */
+
+/* The present pass of the reference (display.frag:16-64, driven from
+ * index.tsx:25-59): colour x 1/samples, Gaussian blur whose radius is the
+ * accumulated DoF radius (normal_dof.w / samples x 200, clamped to 16 pixels;
+ * NEAREST + REPEAT taps), gamma 1/2.2, RGBA8.  out_rgba8 = height*width*4
+ * bytes, HOST pointer, row 0 = bottom row.  The blur reads neighbouring rows,
+ * so rm_present needs a framebuffer holding the whole frame; for a sharded
+ * frame gather the planes first and use rm_present_planes (device pointers;
+ * normal_dof may be NULL = no blur). */
+int rm_present(rm_ctx* ctx, rm_fb* fb, int samples, uint8_t* out_rgba8);
+int rm_present_planes(rm_ctx* ctx, const void* color, const void* normal_dof, int width, int height, int samples, uint8_t* out_rgba8);
+
 #ifdef __cplusplus
 }
 #endif

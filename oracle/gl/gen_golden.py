@@ -183,7 +183,21 @@ def gen_stat():
     save("stat_sphere_full_native_tan", color_sum=r["planes"][0], samples=np.int32(n))
 
 
-GROUPS = {"texcoord": gen_texcoord, "sdf": gen_sdf, "cast": gen_cast, "misc": gen_misc, "rng": gen_rng, "image": gen_image, "stat": gen_stat}
+def gen_display():
+    """The present pass (display.frag:20-64): accumulated planes in, RGBA8 canvas out."""
+    sc = GC.build_scene("sphere")
+    # no lights: with them most pixels of the reference are NaN under SwiftShader's min/max (DESIGN.md "NaN convention")
+    for name, kw, n in (("dof", dict(render_mode="full", counts=(64, 32), dof_amount=0.15, dof_distance=2.4), 4),
+                        ("nodof", dict(render_mode="full", counts=(64, 32)), 2)):
+        schema = J.make_schema(sc, GC.IMG_W, GC.IMG_H, **kw)
+        noise = GC.halton_pairs(n)
+        base = glref.uniforms_from_schema(schema, noise[0])
+        draws = [{"randNoise": glref.u_float(*x)} for x in noise]
+        r = glref.run_gl(glref.with_portable_tan(glref.splice(sc.glsl())), GC.IMG_W, GC.IMG_H, base, draws=draws, read=(0, 1), display_brightness=1.0 / n)
+        save(f"display_{name}", color=r["planes"][0], normal_dof=r["planes"][1], samples=np.int32(n), rgba8=r["display"])
+
+
+GROUPS = {"display": gen_display, "texcoord": gen_texcoord, "sdf": gen_sdf, "cast": gen_cast, "misc": gen_misc, "rng": gen_rng, "image": gen_image, "stat": gen_stat}
 
 if __name__ == "__main__":
     if not glref.available():

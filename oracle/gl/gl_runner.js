@@ -149,7 +149,42 @@
       gl.readPixels(0, 0, w, h, gl.RGBA, gl.FLOAT, buf);
       out["plane" + planes[p]] = b64(new Uint8Array(buf.buffer));
     }
-    return { ok: true, info: info, timings_ms: timings, planes: out, err: gl.getError() };
+    var display = null;
+    if (job.display) {
+      // present pass (client/src/index.tsx:25-59): the display program samples the
+      // three accumulated textures and writes the RGBA8 canvas image
+      var dprog = gl.createProgram();
+      gl.attachShader(dprog, compile(gl, gl.VERTEX_SHADER, job.display.vert));
+      gl.attachShader(dprog, compile(gl, gl.FRAGMENT_SHADER, job.display.frag));
+      gl.linkProgram(dprog);
+      if (!gl.getProgramParameter(dprog, gl.LINK_STATUS)) throw new Error("link display: " + gl.getProgramInfoLog(dprog));
+      gl.useProgram(dprog);
+      var dloc = gl.getAttribLocation(dprog, "vertex_position");
+      gl.vertexAttribPointer(dloc, 2, gl.FLOAT, false, 8, 0);
+      gl.enableVertexAttribArray(dloc);
+      var names = ["color", "normalAndDofRadiusTex", "albedoAndDepthTex"];
+      for (var t = 0; t < 3; t++) {
+        gl.activeTexture(gl.TEXTURE0 + t);
+        gl.bindTexture(gl.TEXTURE_2D, prev.tex[t]);
+        setUniform(gl, dprog, names[t], { type: "i", count: 1, data: [t] });
+      }
+      setUniform(gl, dprog, "brightness", { type: "f", count: 1, data: [job.display.brightness] });
+      var dfbo = gl.createFramebuffer();
+      var dtex = gl.createTexture();
+      gl.activeTexture(gl.TEXTURE0 + 3);
+      gl.bindTexture(gl.TEXTURE_2D, dtex);
+      gl.texStorage2D(gl.TEXTURE_2D, 1, gl.RGBA8, w, h);
+      gl.bindFramebuffer(gl.FRAMEBUFFER, dfbo);
+      gl.framebufferTexture2D(gl.FRAMEBUFFER, gl.COLOR_ATTACHMENT0, gl.TEXTURE_2D, dtex, 0);
+      gl.drawBuffers([gl.COLOR_ATTACHMENT0]);
+      gl.viewport(0, 0, w, h);
+      gl.drawArrays(gl.TRIANGLES, 0, 6);
+      gl.readBuffer(gl.COLOR_ATTACHMENT0);
+      var bytes8 = new Uint8Array(w * h * 4);
+      gl.readPixels(0, 0, w, h, gl.RGBA, gl.UNSIGNED_BYTE, bytes8);
+      display = b64(bytes8);
+    }
+    return { ok: true, info: info, timings_ms: timings, planes: out, display: display, err: gl.getError() };
   }
 
   window.Plotly = {

@@ -191,7 +191,7 @@ def uniforms_from_schema(schema: dict, rand_noise) -> dict:
     return u
 
 
-def run_gl(frag: str, width: int, height: int, uniforms: dict, draws=None, read=(0,), time=False, init_prev0=None) -> dict:
+def run_gl(frag: str, width: int, height: int, uniforms: dict, draws=None, read=(0,), time=False, init_prev0=None, display_brightness=None) -> dict:
     job = {
         "vert": reference_text("raymarcher.vert"),
         "frag": frag,
@@ -202,6 +202,8 @@ def run_gl(frag: str, width: int, height: int, uniforms: dict, draws=None, read=
         "read": list(read),
         "time": bool(time),
     }
+    if display_brightness is not None:  # also run the reference's present pass (display.vert/.frag)
+        job["display"] = {"vert": reference_text("display.vert"), "frag": reference_text("display.frag"), "brightness": float(display_brightness)}
     if init_prev0 is not None:
         a = np.ascontiguousarray(init_prev0, np.float32)
         assert a.shape == (height, width, 4)
@@ -217,6 +219,8 @@ def run_gl(frag: str, width: int, height: int, uniforms: dict, draws=None, read=
         a = np.frombuffer(base64.b64decode(b), dtype=np.float32).reshape(height, width, 4)
         planes[int(key[len("plane"):])] = a.copy()
     res["planes"] = planes
+    if res.get("display"):
+        res["display"] = np.frombuffer(base64.b64decode(res["display"]), dtype=np.uint8).reshape(height, width, 4).copy()
     return res
 
 

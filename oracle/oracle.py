@@ -44,6 +44,7 @@ def _lib(count: bool = False):
         lib.or_camera.argtypes = [C.POINTER(abi.RmUniforms), C.c_int, C.c_int, fp]
         lib.or_rng.argtypes = [C.POINTER(abi.RmUniforms), C.c_int, C.c_int, C.c_int, fp]
         lib.or_material_default.argtypes = [C.POINTER(abi.RmMaterial)]
+        lib.or_present.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8)]
         lib.or_set_nan_mode.argtypes = [C.c_int]
         lib.or_set_tan_mode.argtypes = [C.c_int]
         _libs[key] = lib
@@ -139,6 +140,16 @@ def camera(uniforms: abi.RmUniforms, width: int, height: int) -> np.ndarray:
 def rng(uniforms: abi.RmUniforms, width: int, height: int, count: int) -> np.ndarray:
     out = np.empty((height, width, count), np.float32)
     _lib().or_rng(C.byref(uniforms), width, height, count, _fp(out))
+    return out
+
+
+def present(color: np.ndarray, normal_dof, samples: int) -> np.ndarray:
+    """display.frag: accumulated planes -> RGBA8 image (row 0 = bottom)."""
+    h, w = color.shape[:2]
+    out = np.empty((h, w, 4), np.uint8)
+    c = np.ascontiguousarray(color, np.float32)
+    n = np.ascontiguousarray(normal_dof, np.float32) if normal_dof is not None else None
+    _lib().or_present(_fp(c), _fp(n) if n is not None else None, w, h, int(samples), out.ctypes.data_as(C.POINTER(C.c_uint8)))
     return out
 
 

@@ -741,6 +741,46 @@ void or_rng(const RmUniforms* u, int W, int H, int count, float* out) {
     }
 }
 
+/* ---- present pass: client/public/shader/display.frag:16-64 (+ index.tsx:25-59) ----
+ * color / normal_dof: H x W x 4 floats, row 0 = bottom row; out: H x W x 4 bytes.
+ * Textures are NEAREST + REPEAT (LoadRenderJobContext.tsx:28-37). */
+static float gaussian_blur_factor(float ox, float oy, float sigma) {
+  const float PI = 3.1415926535f; /* display.frag:14 */
+  return 1.0f / (2.0f * PI * sigma * sigma) * expf(-((ox * ox + oy * oy) / (2.0f * sigma * sigma)));
+}
+
+static int wrap_texel(float coord, int size) { /* NEAREST + REPEAT */
+  float t = coord - floorf(coord);
+  int i = (int)floorf(t * (float)size);
+  return i >= size ? size - 1 : i;
+}
+
+void or_present(const float* color, const float* normal_dof, int W, int H, int samples, uint8_t* out) {
+  const float brightness = 1.0f / (float)samples; /* index.tsx:39 */
+  for (int y = 0; y < H; y++)
+    for (int x = 0; x < W; x++) {
+      const float tcx = ((float)x + 0.5f) / (float)W, tcy = ((float)y + 0.5f) / (float)H;
+      const float dof = normal_dof ? normal_dof[((size_t)y * W + x) * 4 + 3] * brightness : 0.0f;
+      const float kernel = gl_clamp(dof * 200.0f, 0.0f, 16.0f);
+      float acc[4] = {0, 0, 0, 0}, count = 0.0f;
+      for (float oy = -kernel; oy <= kernel; oy += 1.0f)
+        for (float ox = -kernel; ox <= kernel; ox += 1.0f) {
+          const float f = gaussian_blur_factor(ox, oy, gl_max(kernel, 1.0f) * 0.3f);
+          count += f;
+          const int sx = wrap_texel(tcx + ox / (float)W, W), sy = wrap_texel(tcy + oy / (float)H, H);
+          const float* c = color + ((size_t)sy * W + sx) * 4;
+          for (int k = 0; k < 4; k++) acc[k] += c[k] * f;
+        }
+      uint8_t* o = out + ((size_t)y * W + x) * 4;
+      for (int k = 0; k < 3; k++) {
+        float v = gl_pow(acc[k] / count * brightness, 1.0f / 2.2f);
+        v = v != v ? 0.0f : (v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v)); /* UNORM8 conversion of the canvas */
+        o[k] = (uint8_t)floorf(v * 255.0f + 0.5f);
+      }
+      o[3] = 255; /* pow(1.0, 1/2.2) */
+    }
+}
+
 /* Validate.tsx:18-51 */
 void or_material_default(RmMaterial* m) {
   memset(m, 0, sizeof *m);

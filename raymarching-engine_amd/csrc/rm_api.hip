@@ -548,6 +548,31 @@ int rm_render_timed(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* u
   return RM_OK;
 }
 
+// ---- present ---------------------------------------------------------------------
+
+int rm_present_planes(rm_ctx* ctx, const void* color, const void* normal_dof, int width, int height, int samples, uint8_t* out_rgba8) {
+  if (!ctx || !color || !out_rgba8) return fail(ctx, RM_ERR_INVALID, "rm_present_planes: NULL argument");
+  if (width < 1 || height < 1 || samples < 1) return fail(ctx, RM_ERR_INVALID, "rm_present_planes: width, height and samples must be >= 1");
+  RM_HIP(ctx, hipSetDevice(ctx->device));
+  uchar4* d_out = nullptr;
+  const size_t bytes = (size_t)width * (size_t)height * 4;
+  RM_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&d_out), bytes));
+  hipError_t e = rm::launch_present(static_cast<const float4*>(color), static_cast<const float4*>(normal_dof), width, height,
+                                    1.0f / (float)samples, d_out, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(out_rgba8, d_out, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_out);
+  if (e != hipSuccess) return fail(ctx, RM_ERR_DEVICE, std::string("rm_present_planes: ") + hipGetErrorString(e));
+  return RM_OK;
+}
+
+int rm_present(rm_ctx* ctx, rm_fb* fb, int samples, uint8_t* out_rgba8) {
+  if (!ctx || !fb) return fail(ctx, RM_ERR_INVALID, "rm_present: NULL argument");
+  if (fb->stripe_rows > 0 || fb->row_begin != 0 || fb->row_count != fb->height)
+    return fail(ctx, RM_ERR_INVALID, "rm_present: the blur reads neighbouring rows, so it needs the whole frame: gather the planes and use rm_present_planes");
+  return rm_present_planes(ctx, fb->plane[0], fb->plane[1], fb->width, fb->height, samples, out_rgba8);
+}
+
 // ---- probes ----------------------------------------------------------------------
 
 int rm_probe(rm_ctx* ctx, rm_scene* scene, int what, const float* in, int n, float param, int flags, float* out) {

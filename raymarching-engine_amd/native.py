@@ -24,7 +24,7 @@ EXPORTS = [
     "rm_abi_version", "rm_material_default", "rm_ctx_create", "rm_ctx_destroy", "rm_last_error", "rm_ctx_set_stream",
     "rm_ctx_set_retire_eps", "rm_debug_counters", "rm_sync", "rm_scene_create", "rm_scene_destroy", "rm_fb_create", "rm_fb_create_striped", "rm_fb_rows", "rm_fb_wrap", "rm_fb_clear", "rm_fb_destroy",
     "rm_fb_download", "rm_fb_upload", "rm_fb_device_ptr", "rm_render_sample", "rm_render_samples", "rm_render_timed",
-    "rm_probe", "rm_probe_camera", "rm_probe_rng",
+    "rm_probe", "rm_probe_camera", "rm_probe_rng", "rm_present", "rm_present_planes",
 ]
 
 
@@ -74,6 +74,8 @@ def load_library():
         "rm_probe": (ip, [vp, vp, ip, fp, ip, C.c_float, ip, fp]),
         "rm_probe_camera": (ip, [vp, C.POINTER(abi.RmUniforms), ip, ip, fp]),
         "rm_probe_rng": (ip, [vp, C.POINTER(abi.RmUniforms), ip, ip, ip, fp]),
+        "rm_present": (ip, [vp, vp, ip, C.POINTER(C.c_uint8)]),
+        "rm_present_planes": (ip, [vp, vp, vp, ip, ip, ip, C.POINTER(C.c_uint8)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -226,3 +228,9 @@ class Framebuffer:
 
     def device_ptr(self, plane: int = abi.RM_PLANE_COLOR) -> int:
         return int(self.ctx.lib.rm_fb_device_ptr(self.h, plane) or 0)
+
+    def present(self, samples: int) -> np.ndarray:
+        """Tone-mapped RGBA8 image of the whole frame (display.frag:16-64), row 0 = bottom."""
+        out = np.empty((self.row_count, self.width, 4), np.uint8)
+        self.ctx._check(self.ctx.lib.rm_present(self.ctx.h, self.h, int(samples), out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out

@@ -367,6 +367,28 @@ def test_c4_c5_configs_run_and_match_on_a_crop(ctx):
         assert np.mean(d > 1e-5) <= 0.03
 
 
+@pytest.mark.parametrize("name", ["display_dof", "display_nodof"])
+def test_present_pass(ctx, name):
+    """rm_present (display.frag:16-64) on the golden's accumulated planes: within one
+    code value of the oracle and of the reference's canvas; and on a rendered frame."""
+    z = load(name)
+    h, w = z["color"].shape[:2]
+    fb = ctx.create_framebuffer(w, h)
+    fb.upload(0, z["color"])
+    fb.upload(1, z["normal_dof"])
+    got = fb.present(int(z["samples"]))
+    for want in (O.present(z["color"], z["normal_dof"], int(z["samples"])), z["rgba8"]):
+        d = np.abs(got.astype(int) - want.astype(int))
+        assert d.max() <= 1 and np.mean(d == 0) >= 0.99
+    fb.destroy()
+    from raymarching_engine_amd import native
+
+    win = ctx.create_framebuffer(w, h, 8, 8)
+    with pytest.raises(native.RmError):
+        win.present(1)
+    win.destroy()
+
+
 # ---- boundary behaviour -----------------------------------------------------------
 
 
