@@ -23,13 +23,21 @@ struct rm_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float retire_eps = 4.76837158203125e-07f;  // 2^-21
   int cu_count = 256;
-  int pass2_blocks_per_cu = 3;
+  // persistent-grid sizes in workgroups per CU, from a sweep on the headline frame (tools/sweep.sh):
+  // the Mandelbulb passes want FEW waves (every wave ends in a tail of a few long rays), the table march wants all slots
+  int pass2_blocks_per_cu = 2;
+  int pass1_blocks_per_cu = 2;
   // wavefront pipeline workspace (per-ray state + queue heads), grown on demand
   float4* ws = nullptr;
   size_t ws_rays = 0;
   unsigned int* heads = nullptr;  // 3 counters per march launch: head(pass 0/1), head(pass 2), parked count
   unsigned int* ws_list = nullptr;  // parked ray ids
   unsigned long long* stats = nullptr;  // 16 counters, filled by RM_WF_STATS builds only
+  hipStream_t wf_stream[4] = {nullptr, nullptr, nullptr, nullptr};  // side streams of the banded wavefront pipeline
+  hipEvent_t wf_join[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t wf_fork = nullptr;
+  int wf_bands = 0;  // bands of rows in flight on side streams; 0 = automatic (2 for large tiles: measured best)
+  int wf_blocks_per_cu = 8;
   std::string error;
 };
 
@@ -105,6 +113,9 @@ int rm_ctx_create(int device, rm_ctx** out) {
   ctx->stream = ctx->own_stream;
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->cu_count = cus;
+  if (const char* v = std::getenv("RM_PASS1_BLOCKS_PER_CU")) { int n = std::atoi(v); if (n >= 1 && n <= 8) ctx->pass1_blocks_per_cu = n; }
+  if (const char* v = std::getenv("RM_WF_BLOCKS_PER_CU")) { int n = std::atoi(v); if (n >= 1 && n <= 8) ctx->wf_blocks_per_cu = n; }
+  if (const char* v = std::getenv("RM_WF_BANDS")) { int n = std::atoi(v); if (n >= 1 && n <= 8) ctx->wf_bands = n; }
   if (const char* v = std::getenv("RM_PASS2_BLOCKS_PER_CU")) { int n = std::atoi(v); if (n >= 1 && n <= 8) ctx->pass2_blocks_per_cu = n; }
   *out = ctx;
   return RM_OK;
@@ -118,6 +129,11 @@ void rm_ctx_destroy(rm_ctx* ctx) {
   if (ctx->heads) (void)hipFree(ctx->heads);
   if (ctx->ws_list) (void)hipFree(ctx->ws_list);
   if (ctx->stats) (void)hipFree(ctx->stats);
+  for (int s = 0; s < 4; s++) {
+    if (ctx->wf_stream[s]) { (void)hipStreamSynchronize(ctx->wf_stream[s]); (void)hipStreamDestroy(ctx->wf_stream[s]); }
+    if (ctx->wf_join[s]) (void)hipEventDestroy(ctx->wf_join[s]);
+  }
+  if (ctx->wf_fork) (void)hipEventDestroy(ctx->wf_fork);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -416,59 +432,47 @@ static int build_params(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniform
 #define RM_MAX_MARCHES (RM_MAX_BOUNCES * (1 + RM_MAX_LIGHTS))
 
 // One sample through the wavefront pipeline (rm_wavefront.inc).
-static hipError_t launch_wavefront(rm_ctx* ctx, const KParams& P, int flags) {
-  hipStream_t stream = ctx->stream;
+#define RM_WF_STREAMS 4
+#define RM_WF_MAX_BANDS 8
+
+// One band of rows through the wavefront pipeline (rm_wavefront.inc) on `stream`.
+static hipError_t launch_wavefront_band(rm_ctx* ctx, const KParams& P, int flags, hipStream_t stream, float4* ws,
+                                        unsigned int* list, unsigned int* heads) {
   const bool fast = (flags & RM_RENDER_FAST) != 0;
   rm::WfParams W{};
   W.k = P;
   W.tiles_x = (P.tw + 7) / 8;
   const int tiles_y = (P.th + 7) / 8;
   W.n_rays = W.tiles_x * tiles_y * 64;
-  hipError_t e;
-  if (!ctx->heads) {
-    if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->heads), sizeof(unsigned int) * 3 * RM_MAX_MARCHES)) != hipSuccess) return e;
-    if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->stats), sizeof(unsigned long long) * 16)) != hipSuccess) return e;
-    if ((e = hipMemset(ctx->stats, 0, sizeof(unsigned long long) * 16)) != hipSuccess) return e;
-  }
-  if (ctx->ws_rays < (size_t)W.n_rays) {
-    if (ctx->ws) {
-      if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
-      (void)hipFree(ctx->ws);
-      (void)hipFree(ctx->ws_list);
-      ctx->ws = nullptr;
-      ctx->ws_list = nullptr;
-      ctx->ws_rays = 0;
-    }
-    if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->ws), sizeof(float4) * (size_t)rm::WF_ARRAYS * (size_t)W.n_rays)) != hipSuccess) return e;
-    if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->ws_list), sizeof(unsigned int) * (size_t)W.n_rays)) != hipSuccess) return e;
-    ctx->ws_rays = (size_t)W.n_rays;
-  }
-  for (int i = 0; i < rm::WF_ARRAYS; i++) W.a[i] = ctx->ws + (size_t)i * ctx->ws_rays;
-  if ((e = hipMemsetAsync(ctx->heads, 0, sizeof(unsigned int) * 3 * RM_MAX_MARCHES, stream)) != hipSuccess) return e;
-  W.list = ctx->ws_list;
+  for (int i = 0; i < rm::WF_ARRAYS; i++) W.a[i] = ws + (size_t)i * (size_t)W.n_rays;
+  W.list = list;
   W.stats = ctx->stats;
+  hipError_t e;
   const bool classes = rm::wf_kind_has_cost_classes(P.scene.kind) && !(flags & RM_RENDER_NO_COST_CLASSES);
   // persistent march grid: every SIMD slot of the chip, or fewer when there are few rays
-  int blocks = ctx->cu_count * 8;
+  int blocks = ctx->cu_count * ctx->wf_blocks_per_cu;
   const int needed = (W.n_rays + 255) / 256;
   if (blocks > needed) blocks = needed;
   int march = 0;
   auto do_march = [&](int pos_array, int dir_array, bool preview) -> hipError_t {
     W.pos_array = pos_array;
     W.dir_array = dir_array;
-    unsigned int* c = ctx->heads + 3 * march++;
+    unsigned int* c = heads + 3 * march++;
     auto go = [&](int pass) { return fast ? rm::wf_launch_march_fast(W, preview, pass, blocks, stream) : rm::wf_launch_march_strict(W, preview, pass, blocks, stream); };
     W.head = c;
     W.list_count = c + 2;
     if (!classes) return go(0);
-    hipError_t e1 = go(1);  // cheap evaluations; parks the rays that need the deep one
+    const int saved1 = blocks;
+    const int pass1 = ctx->cu_count * ctx->pass1_blocks_per_cu;
+    if (blocks > pass1) blocks = pass1;
+    hipError_t e1 = go(1);
+    blocks = saved1;  // cheap evaluations; parks the rays that need the deep one
     if (e1 != hipSuccess) return e1;
     W.head = c + 1;
-    // the parked rays, compacted.  Fewer waves than SIMD slots on purpose: the
-    // list is short (the rays near the surface) and every wave ends with a tail
-    // in which a few never-settling rays run alone, so the idle-lane cost grows
-    // with the number of waves; 2-3 waves per SIMD already saturate the VALU of
-    // this dependent-chain code (measured: DESIGN.md)
+    // the parked rays, compacted.  Fewer waves than SIMD slots on purpose: every
+    // wave ends with a tail in which a few never-settling rays run alone, so the
+    // idle-lane cost grows with the number of waves, and 2 waves per SIMD already
+    // keep the VALU of this dependent-chain code busy (sweep: DESIGN.md)
     const int saved = blocks;
     const int pass2 = ctx->cu_count * ctx->pass2_blocks_per_cu;
     if (blocks > pass2) blocks = pass2;
@@ -494,6 +498,66 @@ static hipError_t launch_wavefront(rm_ctx* ctx, const KParams& P, int flags) {
       if ((e = do_march(rm::WF_SPOS, rm::WF_SDIR, false)) != hipSuccess) return e;
       if ((e = rm::wf_launch_stage(W, 3, stream)) != hipSuccess) return e;  // light
     }
+  }
+  return hipSuccess;
+}
+
+// One sample through the wavefront pipeline.  A large tile is cut into bands of
+// rows that go down the pipeline on RM_WF_STREAMS side streams: every kernel of
+// the pipeline ends with a tail in which the chip drains (a few long rays, the
+// last workgroups), and the next band's kernels fill those holes.  Bands are
+// independent (every pixel is), so this changes nothing in the results.
+static hipError_t launch_wavefront(rm_ctx* ctx, const KParams& P, int flags) {
+  hipStream_t stream = ctx->stream;
+  const int tiles_x = (P.tw + 7) / 8, tiles_y = (P.th + 7) / 8;
+  int bands = ctx->wf_bands > 0 ? ctx->wf_bands : (tiles_y >= 32 ? 2 : 1);
+  if (bands > RM_WF_MAX_BANDS) bands = RM_WF_MAX_BANDS;
+  if (bands > tiles_y) bands = tiles_y;
+  const size_t total_rays = (size_t)tiles_x * (size_t)tiles_y * 64;
+  hipError_t e;
+  if (!ctx->heads) {
+    if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->heads), sizeof(unsigned int) * 3 * RM_MAX_MARCHES * RM_WF_MAX_BANDS)) != hipSuccess) return e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->stats), sizeof(unsigned long long) * 16)) != hipSuccess) return e;
+    if ((e = hipMemset(ctx->stats, 0, sizeof(unsigned long long) * 16)) != hipSuccess) return e;
+    for (int s = 0; s < RM_WF_STREAMS; s++) {
+      if ((e = hipStreamCreateWithFlags(&ctx->wf_stream[s], hipStreamNonBlocking)) != hipSuccess) return e;
+      if ((e = hipEventCreateWithFlags(&ctx->wf_join[s], hipEventDisableTiming)) != hipSuccess) return e;
+    }
+    if ((e = hipEventCreateWithFlags(&ctx->wf_fork, hipEventDisableTiming)) != hipSuccess) return e;
+  }
+  if (ctx->ws_rays < total_rays) {
+    if (ctx->ws) {
+      if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
+      (void)hipFree(ctx->ws);
+      (void)hipFree(ctx->ws_list);
+      ctx->ws = nullptr;
+      ctx->ws_list = nullptr;
+      ctx->ws_rays = 0;
+    }
+    if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->ws), sizeof(float4) * (size_t)rm::WF_ARRAYS * total_rays)) != hipSuccess) return e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->ws_list), sizeof(unsigned int) * total_rays)) != hipSuccess) return e;
+    ctx->ws_rays = total_rays;
+  }
+  if ((e = hipMemsetAsync(ctx->heads, 0, sizeof(unsigned int) * 3 * RM_MAX_MARCHES * RM_WF_MAX_BANDS, stream)) != hipSuccess) return e;
+  if (bands == 1) return launch_wavefront_band(ctx, P, flags, stream, ctx->ws, ctx->ws_list, ctx->heads);
+  if ((e = hipEventRecord(ctx->wf_fork, stream)) != hipSuccess) return e;
+  for (int s = 0; s < RM_WF_STREAMS; s++)
+    if ((e = hipStreamWaitEvent(ctx->wf_stream[s], ctx->wf_fork, 0)) != hipSuccess) return e;
+  size_t rays_before = 0;
+  for (int b = 0; b < bands; b++) {
+    const int t0 = (int)((long long)tiles_y * b / bands), t1 = (int)((long long)tiles_y * (b + 1) / bands);
+    KParams B = P;
+    B.ty = P.ty + t0 * 8;
+    B.th = (t1 * 8 < P.th ? t1 * 8 : P.th) - t0 * 8;
+    const size_t band_rays = (size_t)tiles_x * (size_t)(t1 - t0) * 64;
+    if ((e = launch_wavefront_band(ctx, B, flags, ctx->wf_stream[b % RM_WF_STREAMS], ctx->ws + (size_t)rm::WF_ARRAYS * rays_before,
+                                   ctx->ws_list + rays_before, ctx->heads + (size_t)3 * RM_MAX_MARCHES * b)) != hipSuccess)
+      return e;
+    rays_before += band_rays;
+  }
+  for (int s = 0; s < RM_WF_STREAMS; s++) {
+    if ((e = hipEventRecord(ctx->wf_join[s], ctx->wf_stream[s])) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(stream, ctx->wf_join[s], 0)) != hipSuccess) return e;
   }
   return hipSuccess;
 }
