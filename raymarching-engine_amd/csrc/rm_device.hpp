@@ -171,8 +171,10 @@ RM_DEV void box_muller(Rng& r, float& ox, float& oy) {
   const float u2 = gold_noise(r, b - floorf(b));
   const float two_pi_u2 = 2.0f * 3.141592f * u2;
   const float rad = sqrtf(-2.0f * logf(u1));
-  ox = rad * cosf(two_pi_u2);
-  oy = rad * sinf(two_pi_u2);
+  float sn, cs;
+  sincosf(two_pi_u2, &sn, &cs);  // one range reduction for both
+  ox = rad * cs;
+  oy = rad * sn;
 }
 
 // :96-101
@@ -217,6 +219,9 @@ struct Sdf;
 template <>
 struct Sdf<RM_SCENE_TABLE> {
   static constexpr bool has_cost_classes = false;  // every evaluation costs the same
+  // sdf of a point with a non-finite coordinate is +-Inf or NaN (|p - c| is), so the forward-difference
+  // normal there is (NaN, NaN, NaN) whatever the table holds: sceneNormal may skip its four evaluations
+  static constexpr bool nonfinite_normal_is_nan = true;
   static RM_DEV void stage(const DevScene& sc, SceneLds& lds) {
     const float4* src = reinterpret_cast<const float4*>(sc.prims);
     for (int i = threadIdx.x; i < sc.nprims * 2; i += blockDim.x) lds.rows[i] = src[i];
@@ -279,21 +284,23 @@ struct Sdf<RM_SCENE_MANDELBULB> {
   // each by three complex squarings.  The same function as eval_generic up to
   // rounding; 2 sqrt + 1 rcp per iteration instead of 12 transcendentals.
   static RM_DEV void pow8_round(v3& z, float& dr, v3 pos, float rho2, float r2) {
+    // 2 transcendentals per round: r = sqrt(r2) and q = 1/rho = rsq(rho2); rho = rho2*q, 1/rho^8 = q^8
     const float r = FM::sqrt(r2);
-    const float rho = FM::sqrt(rho2);
+    const float q = __builtin_amdgcn_rsqf(rho2);
+    const float rho = rho2 * q;
     const float r4 = r2 * r2;
     dr = FM::fma((r4 * r2 * r) * 8.0f, dr, 1.0f);
-    // (A + iB) = (z.z + i rho)^8, (C + iD) = (z.x + i z.y)^8
+    // (A + iB) = (z.z + i rho)^8, (C + iD) = (z.x + i z.y)^8: three complex squarings each,
+    // re' = re^2 - im^2 (one mul + one fma), im' = 2 re im
     float A = z.z, B = rho, C = z.x, D = z.y, t;
 #pragma unroll
     for (int s = 0; s < 3; s++) {
-      t = (A + B) * (A - B); B = 2.0f * A * B; A = t;
-      t = (C + D) * (C - D); D = 2.0f * C * D; C = t;
+      t = FM::fma(A, A, -(B * B)); B = (A + A) * B; A = t;
+      t = FM::fma(C, C, -(D * D)); D = (C + C) * D; C = t;
     }
-    const float rho4 = rho2 * rho2;
-    const float rho8 = rho4 * rho4;
-    const bool on_axis = !(rho8 > 0.0f);  // phi = atan(0, 0) = 0 there: cos 8phi = 1, sin 8theta = 0
-    const float s8 = on_axis ? 0.0f : B * FM::rcp(rho8);  // r^8 sin(8 theta) / rho^8
+    const float q2 = q * q, q4 = q2 * q2, q8 = q4 * q4;
+    const bool on_axis = !(rho2 > 0.0f) || !(q8 < __builtin_inff());  // phi = atan(0, 0) = 0 there: cos 8phi = 1, sin 8theta = 0
+    const float s8 = on_axis ? 0.0f : B * q8;  // r^8 sin(8 theta) / rho^8
     z = V(FM::fma(s8, C, pos.x), FM::fma(s8, D, pos.y), A + pos.z);
   }
   static RM_DEV float eval_pow8(const DevScene& sc, v3 pos) {
@@ -322,6 +329,7 @@ struct Sdf<RM_SCENE_MANDELBULB> {
   // more than `cap` rounds; otherwise the same bits as eval().  The wavefront
   // march uses it to keep cheap and expensive rays in separate waves.
   static constexpr bool has_cost_classes = true;
+  static constexpr bool nonfinite_normal_is_nan = true;  // |z| is Inf or NaN there: the estimate is Inf or NaN
   static constexpr int cheap_cap = 2;
   template <class M>
   static RM_DEV bool eval_cheap(const DevScene& sc, const SceneLds& lds, v3 p, float& d) {
@@ -371,6 +379,7 @@ RM_DEV void stage_pow_table(SceneLds& lds, float base, float first) {
 template <>
 struct Sdf<RM_SCENE_SPHERE_GRID> {
   static constexpr bool has_cost_classes = false;  // every evaluation costs the same
+  static constexpr bool nonfinite_normal_is_nan = false;  // not shown for this kind: always evaluate
   static RM_DEV void stage(const DevScene& sc, SceneLds& lds) { stage_pow_table(lds, sc.p[RM_P_GRID_SCALE], -1.0f); }
   template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds& lds, v3 p) {
@@ -394,6 +403,7 @@ struct Sdf<RM_SCENE_SPHERE_GRID> {
 template <>
 struct Sdf<RM_SCENE_SPHERE_LATTICE> {
   static constexpr bool has_cost_classes = false;  // every evaluation costs the same
+  static constexpr bool nonfinite_normal_is_nan = false;  // not shown for this kind: always evaluate
   static RM_DEV void stage(const DevScene&, SceneLds&) {}
   template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds&, v3 p) {
@@ -407,6 +417,7 @@ struct Sdf<RM_SCENE_SPHERE_LATTICE> {
 template <>
 struct Sdf<RM_SCENE_MENGER> {
   static constexpr bool has_cost_classes = false;  // every evaluation costs the same
+  static constexpr bool nonfinite_normal_is_nan = false;  // not shown for this kind: always evaluate
   static RM_DEV void stage(const DevScene&, SceneLds& lds) { stage_pow_table(lds, 0.33333333333333f, 1.0f); }
   template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds& lds, v3 p) {
@@ -448,6 +459,7 @@ RM_DEV v3 kifs_rotate(v3 t, const KifsTrig& g) {
 template <>
 struct Sdf<RM_SCENE_KIFS_TREE> {
   static constexpr bool has_cost_classes = false;  // every evaluation costs the same
+  static constexpr bool nonfinite_normal_is_nan = false;  // not shown for this kind: always evaluate
   static RM_DEV void stage(const DevScene& sc, SceneLds& lds) { stage_pow_table(lds, sc.p[RM_P_KIFS_SCALE], 0.0f); }
   template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds& lds, v3 p) {
@@ -474,6 +486,7 @@ struct Sdf<RM_SCENE_KIFS_TREE> {
 template <>
 struct Sdf<RM_SCENE_KIFS_BOX> {
   static constexpr bool has_cost_classes = false;  // every evaluation costs the same
+  static constexpr bool nonfinite_normal_is_nan = false;  // not shown for this kind: always evaluate
   static RM_DEV void stage(const DevScene&, SceneLds&) {}
   template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds&, v3 p) {
