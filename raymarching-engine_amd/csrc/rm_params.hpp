@@ -54,7 +54,8 @@ enum {
   WF_DIF,       // xyz diffuseCol
   WF_SPC,       // xyz specularCol
   WF_PALB,      // xyz prevAlbedo
-  WF_ADJ,       // xyz adjustedLightPosition
+  WF_ADJ,       // xyz adjustedLightPosition, w = distance(rayPosition, adjustedLightPosition)
+  WF_CONTRIB,   // xyz what the current light adds if its shadow test passes (:368-371)
   WF_SPOS,      // shadow ray position (march in/out), w = step budget
   WF_SDIR,      // shadow ray direction
   WF_AUX,       // preview: x = stepsTaken, y = depth
