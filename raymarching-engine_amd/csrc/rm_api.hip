@@ -27,17 +27,21 @@ struct rm_ctx {
   // the Mandelbulb passes want FEW waves (every wave ends in a tail of a few long rays), the table march wants all slots
   int pass2_blocks_per_cu = 2;
   int pass1_blocks_per_cu = 2;
+  int pass2_rounds = 1;  // launches over the parked rays (the last one runs every ray to its end); >1 measured slower
+  int repark = 24;       // a drained pass-2 wave with this many active lanes or fewer hands them to the next round
   // wavefront pipeline workspace (per-ray state + queue heads), grown on demand
   float4* ws = nullptr;
   size_t ws_rays = 0;
   unsigned int* heads = nullptr;  // 3 counters per march launch: head(pass 0/1), head(pass 2), parked count
-  unsigned int* ws_list = nullptr;  // parked ray ids
+  unsigned int* ws_list = nullptr;  // parked ray ids (two lists, ping-pong between pass-2 rounds)
+  unsigned int* ws_list2 = nullptr;
   unsigned long long* stats = nullptr;  // 16 counters, filled by RM_WF_STATS builds only
   hipStream_t wf_stream[4] = {nullptr, nullptr, nullptr, nullptr};  // side streams of the banded wavefront pipeline
   hipEvent_t wf_join[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t wf_fork = nullptr;
   int wf_bands = 0;  // bands of rows in flight on side streams; 0 = automatic (2 for large tiles: measured best)
   int wf_blocks_per_cu = 8;
+  int claims_per_wave = 8;
   std::string error;
 };
 
@@ -114,6 +118,9 @@ int rm_ctx_create(int device, rm_ctx** out) {
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->cu_count = cus;
   if (const char* v = std::getenv("RM_PASS1_BLOCKS_PER_CU")) { int n = std::atoi(v); if (n >= 1 && n <= 8) ctx->pass1_blocks_per_cu = n; }
+  if (const char* v = std::getenv("RM_PASS2_ROUNDS")) { int n = std::atoi(v); if (n >= 1 && n <= 3) ctx->pass2_rounds = n; }
+  if (const char* v = std::getenv("RM_REPARK")) { int n = std::atoi(v); if (n >= 0 && n <= 63) ctx->repark = n; }
+  if (const char* v = std::getenv("RM_WF_CLAIMS")) { int n = std::atoi(v); if (n >= 1 && n <= 64) ctx->claims_per_wave = n; }
   if (const char* v = std::getenv("RM_WF_BLOCKS_PER_CU")) { int n = std::atoi(v); if (n >= 1 && n <= 8) ctx->wf_blocks_per_cu = n; }
   if (const char* v = std::getenv("RM_WF_BANDS")) { int n = std::atoi(v); if (n >= 1 && n <= 8) ctx->wf_bands = n; }
   if (const char* v = std::getenv("RM_PASS2_BLOCKS_PER_CU")) { int n = std::atoi(v); if (n >= 1 && n <= 8) ctx->pass2_blocks_per_cu = n; }
@@ -128,6 +135,7 @@ void rm_ctx_destroy(rm_ctx* ctx) {
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->heads) (void)hipFree(ctx->heads);
   if (ctx->ws_list) (void)hipFree(ctx->ws_list);
+  if (ctx->ws_list2) (void)hipFree(ctx->ws_list2);
   if (ctx->stats) (void)hipFree(ctx->stats);
   for (int s = 0; s < 4; s++) {
     if (ctx->wf_stream[s]) { (void)hipStreamSynchronize(ctx->wf_stream[s]); (void)hipStreamDestroy(ctx->wf_stream[s]); }
@@ -430,6 +438,7 @@ static int build_params(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniform
 }
 
 #define RM_MAX_MARCHES (RM_MAX_BOUNCES * (1 + RM_MAX_LIGHTS))
+#define RM_COUNTERS_PER_MARCH 8  // queue heads and parked counts of the launches of one march
 
 // One sample through the wavefront pipeline (rm_wavefront.inc).
 #define RM_WF_STREAMS 4
@@ -437,7 +446,7 @@ static int build_params(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniform
 
 // One band of rows through the wavefront pipeline (rm_wavefront.inc) on `stream`.
 static hipError_t launch_wavefront_band(rm_ctx* ctx, const KParams& P, int flags, hipStream_t stream, float4* ws,
-                                        unsigned int* list, unsigned int* heads) {
+                                        unsigned int* list, unsigned int* list2, unsigned int* heads) {
   const bool fast = (flags & RM_RENDER_FAST) != 0;
   rm::WfParams W{};
   W.k = P;
@@ -445,7 +454,6 @@ static hipError_t launch_wavefront_band(rm_ctx* ctx, const KParams& P, int flags
   const int tiles_y = (P.th + 7) / 8;
   W.n_rays = W.tiles_x * tiles_y * 64;
   for (int i = 0; i < rm::WF_ARRAYS; i++) W.a[i] = ws + (size_t)i * (size_t)W.n_rays;
-  W.list = list;
   W.stats = ctx->stats;
   hipError_t e;
   const bool classes = rm::wf_kind_has_cost_classes(P.scene.kind) && !(flags & RM_RENDER_NO_COST_CLASSES);
@@ -457,28 +465,48 @@ static hipError_t launch_wavefront_band(rm_ctx* ctx, const KParams& P, int flags
   auto do_march = [&](int pos_array, int dir_array, bool preview) -> hipError_t {
     W.pos_array = pos_array;
     W.dir_array = dir_array;
-    unsigned int* c = heads + 3 * march++;
+    unsigned int* c = heads + RM_COUNTERS_PER_MARCH * march++;  // [0] head of pass 0/1, [1] parked by pass 1, [2..] heads/counts of the pass-2 rounds
     auto go = [&](int pass) { return fast ? rm::wf_launch_march_fast(W, preview, pass, blocks, stream) : rm::wf_launch_march_strict(W, preview, pass, blocks, stream); };
     W.head = c;
-    W.list_count = c + 2;
+    W.claims_per_wave = ctx->claims_per_wave;
+    W.repark = 0;
+    W.list_in = nullptr;
+    W.list_in_count = nullptr;
+    W.list_out = list;
+    W.list_out_count = c + 1;
     if (!classes) return go(0);
-    const int saved1 = blocks;
+    const int saved = blocks;
     const int pass1 = ctx->cu_count * ctx->pass1_blocks_per_cu;
     if (blocks > pass1) blocks = pass1;
-    hipError_t e1 = go(1);
-    blocks = saved1;  // cheap evaluations; parks the rays that need the deep one
-    if (e1 != hipSuccess) return e1;
-    W.head = c + 1;
-    // the parked rays, compacted.  Fewer waves than SIMD slots on purpose: every
-    // wave ends with a tail in which a few never-settling rays run alone, so the
-    // idle-lane cost grows with the number of waves, and 2 waves per SIMD already
-    // keep the VALU of this dependent-chain code busy (sweep: DESIGN.md)
-    const int saved = blocks;
-    const int pass2 = ctx->cu_count * ctx->pass2_blocks_per_cu;
-    if (blocks > pass2) blocks = pass2;
-    hipError_t e2 = go(2);
+    hipError_t e1 = go(1);  // cheap evaluations; parks the rays that need the deep one
     blocks = saved;
-    return e2;
+    if (e1 != hipSuccess) return e1;
+    // The parked rays, compacted, in up to three rounds.  Fewer waves than SIMD
+    // slots on purpose (2 per SIMD keep the VALU of this dependent-chain code
+    // busy), and a round whose queue has drained does not let its waves thin
+    // out to a few never-settling rays each: a wave with <= repark active lanes
+    // parks them again and the next, smaller round re-compacts the survivors.
+    unsigned int* in = list;
+    unsigned int* outl = list2;
+    unsigned int* in_count = c + 1;
+    int round_blocks = ctx->cu_count * ctx->pass2_blocks_per_cu;
+    for (int round = 0; round < ctx->pass2_rounds; round++) {
+      const bool last = round == ctx->pass2_rounds - 1;
+      W.head = c + 2 + 2 * round;
+      W.list_in = in;
+      W.list_in_count = in_count;
+      W.list_out = outl;
+      W.list_out_count = c + 3 + 2 * round;
+      W.repark = last ? 0 : ctx->repark;
+      blocks = round_blocks < saved ? round_blocks : saved;
+      hipError_t e2 = go(2);
+      if (e2 != hipSuccess) { blocks = saved; return e2; }
+      in_count = W.list_out_count;
+      unsigned int* t = in; in = outl; outl = t;
+      round_blocks = round_blocks / 4 > ctx->cu_count / 4 ? round_blocks / 4 : ctx->cu_count / 4;
+    }
+    blocks = saved;
+    return hipSuccess;
   };
   if ((e = rm::wf_launch_stage(W, 0, stream)) != hipSuccess) return e;  // setup
   if (P.u.renderMode == 1) {
@@ -516,7 +544,7 @@ static hipError_t launch_wavefront(rm_ctx* ctx, const KParams& P, int flags) {
   const size_t total_rays = (size_t)tiles_x * (size_t)tiles_y * 64;
   hipError_t e;
   if (!ctx->heads) {
-    if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->heads), sizeof(unsigned int) * 3 * RM_MAX_MARCHES * RM_WF_MAX_BANDS)) != hipSuccess) return e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->heads), sizeof(unsigned int) * RM_COUNTERS_PER_MARCH * RM_MAX_MARCHES * RM_WF_MAX_BANDS)) != hipSuccess) return e;
     if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->stats), sizeof(unsigned long long) * 16)) != hipSuccess) return e;
     if ((e = hipMemset(ctx->stats, 0, sizeof(unsigned long long) * 16)) != hipSuccess) return e;
     for (int s = 0; s < RM_WF_STREAMS; s++) {
@@ -530,16 +558,19 @@ static hipError_t launch_wavefront(rm_ctx* ctx, const KParams& P, int flags) {
       if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
       (void)hipFree(ctx->ws);
       (void)hipFree(ctx->ws_list);
+      (void)hipFree(ctx->ws_list2);
       ctx->ws = nullptr;
       ctx->ws_list = nullptr;
+      ctx->ws_list2 = nullptr;
       ctx->ws_rays = 0;
     }
     if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->ws), sizeof(float4) * (size_t)rm::WF_ARRAYS * total_rays)) != hipSuccess) return e;
     if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->ws_list), sizeof(unsigned int) * total_rays)) != hipSuccess) return e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->ws_list2), sizeof(unsigned int) * total_rays)) != hipSuccess) return e;
     ctx->ws_rays = total_rays;
   }
-  if ((e = hipMemsetAsync(ctx->heads, 0, sizeof(unsigned int) * 3 * RM_MAX_MARCHES * RM_WF_MAX_BANDS, stream)) != hipSuccess) return e;
-  if (bands == 1) return launch_wavefront_band(ctx, P, flags, stream, ctx->ws, ctx->ws_list, ctx->heads);
+  if ((e = hipMemsetAsync(ctx->heads, 0, sizeof(unsigned int) * RM_COUNTERS_PER_MARCH * RM_MAX_MARCHES * RM_WF_MAX_BANDS, stream)) != hipSuccess) return e;
+  if (bands == 1) return launch_wavefront_band(ctx, P, flags, stream, ctx->ws, ctx->ws_list, ctx->ws_list2, ctx->heads);
   if ((e = hipEventRecord(ctx->wf_fork, stream)) != hipSuccess) return e;
   for (int s = 0; s < RM_WF_STREAMS; s++)
     if ((e = hipStreamWaitEvent(ctx->wf_stream[s], ctx->wf_fork, 0)) != hipSuccess) return e;
@@ -551,7 +582,7 @@ static hipError_t launch_wavefront(rm_ctx* ctx, const KParams& P, int flags) {
     B.th = (t1 * 8 < P.th ? t1 * 8 : P.th) - t0 * 8;
     const size_t band_rays = (size_t)tiles_x * (size_t)(t1 - t0) * 64;
     if ((e = launch_wavefront_band(ctx, B, flags, ctx->wf_stream[b % RM_WF_STREAMS], ctx->ws + (size_t)rm::WF_ARRAYS * rays_before,
-                                   ctx->ws_list + rays_before, ctx->heads + (size_t)3 * RM_MAX_MARCHES * b)) != hipSuccess)
+                                   ctx->ws_list + rays_before, ctx->ws_list2 + rays_before, ctx->heads + (size_t)RM_COUNTERS_PER_MARCH * RM_MAX_MARCHES * b)) != hipSuccess)
       return e;
     rays_before += band_rays;
   }

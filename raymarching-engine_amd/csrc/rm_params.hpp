@@ -66,8 +66,11 @@ struct WfParams {
   KParams k;
   float4* a[WF_ARRAYS];
   unsigned int* head;  // queue head of THIS march launch (zeroed by the host)
-  unsigned int* list;        // ray ids parked by the cheap pass for the full pass
-  unsigned int* list_count;  // number of parked rays (zeroed by the host)
+  const unsigned int* list_in;        // pass 2: the queue is list_in[0 .. *list_in_count)
+  const unsigned int* list_in_count;
+  unsigned int* list_out;             // where this launch parks rays (pass 1: rays that need the deep evaluation;
+  unsigned int* list_out_count;       //   pass 2 with repark > 0: the survivors of thinned-out waves); zeroed by the host
+  int repark;                         // pass 2: once the queue is drained, a wave with <= repark active lanes parks them and exits
   unsigned long long* stats;  // RM_WF_STATS builds: [shadow?][pass2?][rays, lane-steps, wave-steps, -]
   int n_rays;          // tiles_x * tiles_y * 64
   int tiles_x;
@@ -75,6 +78,7 @@ struct WfParams {
   int light;           // current light index
   int last_bounce;     // 1: this is the last bounce of the sample
   int pos_array, dir_array;  // which arrays the march kernel works on
+  int claims_per_wave;       // queue chunks a wave claims over a launch, on average
 };
 
 // pass 0: single pass; 1: cheap pass (parks rays that need the deep evaluation); 2: full pass over the parked list
