@@ -103,7 +103,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3b", choices=list(WORKLOADS))
     ap.add_argument("--strict", action="store_true", help="parity build instead of the fast build")
-    ap.add_argument("--megakernel", action="store_true", help="one-thread-one-pixel kernel instead of the wavefront pipeline")
+    ap.add_argument("--megakernel", action="store_true", help="force the one-thread-one-pixel kernel (default: the library picks per job)")
+    ap.add_argument("--wavefront", action="store_true", help="force the wavefront pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -131,6 +132,8 @@ def main():
     flags = abi.RM_RENDER_STRICT if args.strict else abi.RM_RENDER_FAST
     if args.megakernel:
         flags |= abi.RM_RENDER_MEGAKERNEL
+    if args.wavefront:
+        flags |= abi.RM_RENDER_WAVEFRONT
 
     ctx = native.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # launches ordered with torch / RCCL work
@@ -181,10 +184,17 @@ def main():
         nominal_px = {"c3b": 145.5e3, "c3a": 71.7e3, "c2": 2.2e3, "c4": 403e3, "c5": 817e3}[args.workload]
         px_launch = row_count * W
         roof = None
+        traffic = None
+        try:  # measured in a separate rocprofv3 --pmc run (profiles/r01_traffic.json says how)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if args.workload == "c3b" and not args.strict:
+                traffic = (tj["megakernel_hbm_bytes_per_frame"] if args.megakernel else tj["hbm_bytes_per_frame"]) * px_launch / (3840 * 2160)
+        except Exception:
+            pass
         if flops_px is not None:
             achieved = flops_px * px_launch / (kernel_ms * 1e-3) / 1e12
             roof = {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+                    "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,
                     "flops_per_pixel_sample_instrumented": flops_px, "flops_per_pixel_sample_nominal": nominal_px,
                     "frac_nominal": nominal_px * px_launch / (kernel_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
                     "kernel_ms": kernel_ms, "pixels_per_launch": px_launch,
@@ -195,7 +205,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["name"], "build": "strict" if args.strict else "fast",
-                       "rows_per_gpu": row_count, "pipeline": "megakernel" if args.megakernel else "wavefront",
+                       "rows_per_gpu": row_count, "pipeline": "megakernel" if args.megakernel else "wavefront" if args.wavefront else "auto (wavefront for this workload)" if args.workload in ("c3b", "c4", "c5") else "auto (megakernel for this workload)",
                        "sharding": f"{shard.STRIPE_ROWS}-row stripes round-robin over ranks, colour plane gathered to rank 0 and re-ordered every step" if world > 1 else "none",
                        "planes": "color+normal_dof+albedo_depth fp32, accumulated in place"},
             "roofline": roof, "cpu_baseline": cpu,

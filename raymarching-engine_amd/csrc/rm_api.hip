@@ -593,9 +593,25 @@ static hipError_t launch_wavefront(rm_ctx* ctx, const KParams& P, int flags) {
   return hipSuccess;
 }
 
+// Which implementation of the per-pixel program runs a job (same results either way).
+// Measured on MI355X (tools/time_all.py): the wavefront pipeline wins on large
+// full-mode frames whose rays are expensive and of very unequal length (64-primitive CSG
+// 4096^2: 73 vs 92 ms; Mandelbulb 4K lit: 4.7 vs 4.9 ms); its per-ray state traffic and
+// launch chain lose on cheap or short rays (sphere 1080p preview: 1.5 vs 0.11 ms; 5-bounce
+// sphere-grid fractal 720p: 6.3 vs 3.3 ms; any preview).
+static bool prefer_wavefront(const KParams& P) {
+  if (P.u.renderMode == 1) return false;
+  if ((long long)P.tw * (long long)P.th < (1ll << 20)) return false;
+  switch (P.scene.kind) {
+    case RM_SCENE_TABLE: return P.scene.nprims >= 16;
+    case RM_SCENE_MANDELBULB: return P.scene.p[RM_P_BULB_ITERATIONS] >= 6.0f;
+    default: return false;
+  }
+}
+
 static hipError_t launch(rm_ctx* ctx, const KParams& P, int flags) {
-  if (flags & RM_RENDER_MEGAKERNEL)
-    return (flags & RM_RENDER_FAST) ? rm::launch_pixels_fast(P, ctx->stream) : rm::launch_pixels_strict(P, ctx->stream);
+  const bool wavefront = (flags & RM_RENDER_WAVEFRONT) ? true : (flags & RM_RENDER_MEGAKERNEL) ? false : prefer_wavefront(P);
+  if (!wavefront) return (flags & RM_RENDER_FAST) ? rm::launch_pixels_fast(P, ctx->stream) : rm::launch_pixels_strict(P, ctx->stream);
   return launch_wavefront(ctx, P, flags);
 }
 

@@ -23,6 +23,7 @@ pytestmark = pytest.mark.gpu
 
 GOLD = GC.__file__.rsplit("/", 1)[0] + "/golden/"
 STRICT, FAST = abi.RM_RENDER_STRICT, abi.RM_RENDER_FAST
+MK, WF = abi.RM_RENDER_MEGAKERNEL, abi.RM_RENDER_WAVEFRONT  # force one implementation (the default picks per job)
 
 
 def load(name):
@@ -165,12 +166,13 @@ IMAGE_BARS = {"mandelbulb_preview": 0.03, "mandelbulb_full_light": 0.08, "fracta
               "sphere_full_dof_fog": 0.02, "csg_mixed_full_2b": 0.02}
 
 
+@pytest.mark.parametrize("pipeline", [MK, WF], ids=["megakernel", "wavefront"])
 @pytest.mark.parametrize("case", list(GC.IMAGES))
-def test_whole_main_image_vs_oracle(ctx, case):
+def test_whole_main_image_vs_oracle(ctx, case, pipeline):
     sc, samples, schema = GC.image_schema(case)
     z = load("image_" + case)
     noises = z["rand_noise"]
-    got = render_gpu(ctx, sc, schema, noises)
+    got = render_gpu(ctx, sc, schema, noises, STRICT | pipeline)
     want = render_oracle(sc, schema, noises, nan_mode=O.NAN_IEEE)
     full = schema["render"]["renderMode"] == "full"
     bar = IMAGE_BARS.get(case, 0.005)
@@ -202,9 +204,11 @@ def test_fast_build_close_to_strict(ctx, case):
     branch/silhouette/highlight flips), and the image mean within 1 %."""
     sc, samples, schema = GC.image_schema(case)
     noises = load("image_" + case)["rand_noise"]
-    a = render_gpu(ctx, sc, schema, noises, STRICT)[0]
-    b = render_gpu(ctx, sc, schema, noises, FAST)[0]
-    d = rel_diff(a, b).max(-1)
+    a = render_gpu(ctx, sc, schema, noises, STRICT | MK)[0]
+    d = 0
+    for pipeline in (MK, WF):
+        b = render_gpu(ctx, sc, schema, noises, FAST | pipeline)[0]
+        d = np.maximum(d, rel_diff(a, b).max(-1))
     fin = np.isfinite(a).all(-1) & np.isfinite(b).all(-1)
     ma, mb = a[fin][:, :3].mean(), b[fin][:, :3].mean()
     # 3-bounce soft-light sphere: most pixels are sky whose later bounces cast
@@ -220,23 +224,24 @@ def test_fast_build_close_to_strict(ctx, case):
 def test_wavefront_pipeline_equals_megakernel(ctx, case):
     """The default wavefront pipeline (ray-compacting persistent march,
     rm_wavefront.inc) and the one-thread-one-pixel kernel run the same
-    per-pixel program: bit-identical in the strict build, and in the fast
-    build when only the exact retire is enabled (eps = 0)."""
+    per-pixel program and every ray stops by its own settle test: bit-identical
+    in the strict build and in the fast build (default tolerance and eps = 0)."""
     sc, samples, schema = GC.image_schema(case)
     noises = load("image_" + case)["rand_noise"]
-    a = render_gpu(ctx, sc, schema, noises, STRICT)
-    b = render_gpu(ctx, sc, schema, noises, STRICT | abi.RM_RENDER_MEGAKERNEL)
+    a = render_gpu(ctx, sc, schema, noises, STRICT | WF)
+    b = render_gpu(ctx, sc, schema, noises, STRICT | MK)
     full = schema["render"]["renderMode"] == "full"
     for k in range(3 if full else 1):
         assert same_bits(a[k], b[k]).all(), f"plane {k}"
-    ctx.set_retire_eps(0.0)
-    try:
-        a = render_gpu(ctx, sc, schema, noises, FAST)
-        b = render_gpu(ctx, sc, schema, noises, FAST | abi.RM_RENDER_MEGAKERNEL)
-    finally:
-        ctx.set_retire_eps(2.0 ** -21)
-    for k in range(3 if full else 1):
-        assert same_bits(a[k], b[k]).all(), f"fast plane {k}"
+    for eps in (2.0 ** -21, 0.0):
+        ctx.set_retire_eps(eps)
+        try:
+            a = render_gpu(ctx, sc, schema, noises, FAST | WF)
+            b = render_gpu(ctx, sc, schema, noises, FAST | MK)
+        finally:
+            ctx.set_retire_eps(2.0 ** -21)
+        for k in range(3 if full else 1):
+            assert same_bits(a[k], b[k]).all(), f"fast plane {k} eps {eps}"
 
 
 def test_wavefront_odd_sizes_and_tiles(ctx):
@@ -246,13 +251,14 @@ def test_wavefront_odd_sizes_and_tiles(ctx):
     schema = J.make_schema(sc, 37, 21, render_mode="full", counts=(24, 12), position=(0.3, 0.2, -4.0), lights=GC.LIGHT)
     noises = GC.halton_pairs(2)
     for rows, tile in ((None, None), ((5, 11), None), (None, abi.RmRect(3, 2, 17, 13)), ((5, 11), abi.RmRect(30, 0, 20, 40))):
-        a = render_gpu(ctx, sc, schema, noises, STRICT, rows=rows, tile=tile)
-        b = render_gpu(ctx, sc, schema, noises, STRICT | abi.RM_RENDER_MEGAKERNEL, rows=rows, tile=tile)
+        a = render_gpu(ctx, sc, schema, noises, STRICT | WF, rows=rows, tile=tile)
+        b = render_gpu(ctx, sc, schema, noises, STRICT | MK, rows=rows, tile=tile)
         for k in range(3):
             assert same_bits(a[k], b[k]).all()
     one = J.make_schema(sc, 1, 1, render_mode="preview", counts=(16,), position=(0.3, 0.2, -4.0))
-    a = render_gpu(ctx, sc, one, noises, STRICT)[0]
-    assert same_bits(a, render_oracle(sc, one, noises)[0]).all()
+    for pipeline in (MK, WF):
+        a = render_gpu(ctx, sc, one, noises, STRICT | pipeline)[0]
+        assert same_bits(a, render_oracle(sc, one, noises)[0]).all()
 
 
 # ---- full-size properties (BASELINE.json sizes) -----------------------------------
@@ -278,7 +284,7 @@ def test_c3b_crop_matches_oracle(ctx, flags):
     x0, y0, w, h = 1100, 1064, 128, 32
     tile = abi.RmRect(x0, y0, w, h)
     noises = GC.halton_pairs(1)
-    got = render_gpu(ctx, sc, schema, noises, flags, rows=(y0, h), tile=tile)[0][:, x0 : x0 + w]
+    got = render_gpu(ctx, sc, schema, noises, flags | WF, rows=(y0, h), tile=tile)[0][:, x0 : x0 + w]
     want = render_oracle(sc, schema, noises, rows=(y0, h), tile=(x0, y0, w, h))[0][:, x0 : x0 + w]
     d = rel_diff(want, got).max(-1)
     sky = np.abs(want[..., :3] - want[0, 0, :3]).max(-1) < 1e-6  # same colour as the crop's corner = sky
@@ -327,7 +333,7 @@ def test_striped_row_sharding_equals_single_frame(ctx, parts):
     noises = GC.halton_pairs(1)
     flags = FAST
     h = ctx.create_scene(sc)
-    for mk in (abi.RM_RENDER_MEGAKERNEL, 0):  # each pipeline against its own single-frame render
+    for mk in (MK, WF):  # each pipeline against its own single-frame render
         whole = render_gpu(ctx, sc, schema, noises, flags | mk)
         pieces = [[], [], []]
         for part in range(parts):
