@@ -147,20 +147,33 @@ def main():
 
     h2, h3 = J.halton(2), J.halton(3)
 
+    pending = [None]
+
     def step():
+        # render sample n, then start the gather of its (snapshotted) colour plane; the gather runs over
+        # RCCL while sample n+1 renders, and frame n is assembled on rank 0 at the start of step n+1
         u = J.uniforms_from_schema(schema, (next(h2), next(h3)))
         ctx.render_sample(scene, fb, u, None, flags)
         if world > 1:
-            gatherer.gather(planes[0], dist)
+            if pending[0] is not None:
+                gatherer.finish(pending[0])
+            pending[0] = gatherer.start(planes[0], dist)
+
+    def drain():
+        if world > 1 and pending[0] is not None:
+            gatherer.finish(pending[0])
+            pending[0] = None
 
     for _ in range(args.warmup):
         step()
+    drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()  # the last frame is assembled inside the timed region: K samples rendered, K frames assembled
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -206,7 +219,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["name"], "build": "strict" if args.strict else "fast",
                        "rows_per_gpu": row_count, "pipeline": "megakernel" if args.megakernel else "wavefront" if args.wavefront else "auto (wavefront for this workload)" if args.workload in ("c3b", "c4", "c5") else "auto (megakernel for this workload)",
-                       "sharding": f"{shard.STRIPE_ROWS}-row stripes round-robin over ranks, colour plane gathered to rank 0 and re-ordered every step" if world > 1 else "none",
+                       "sharding": f"{shard.STRIPE_ROWS}-row stripes round-robin over ranks, colour plane gathered to rank 0 over RCCL every step (overlapped with the next sample's render) and put back in image order" if world > 1 else "none",
                        "planes": "color+normal_dof+albedo_depth fp32, accumulated in place"},
             "roofline": roof, "cpu_baseline": cpu,
         }

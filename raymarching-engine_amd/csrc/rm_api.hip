@@ -601,7 +601,7 @@ static hipError_t launch_wavefront(rm_ctx* ctx, const KParams& P, int flags) {
 // sphere-grid fractal 720p: 6.3 vs 3.3 ms; any preview).
 static bool prefer_wavefront(const KParams& P) {
   if (P.u.renderMode == 1) return false;
-  if ((long long)P.tw * (long long)P.th < (1ll << 20)) return false;
+  if ((long long)P.tw * (long long)P.th < (1ll << 21)) return false;  // small tiles/shards: one launch beats a launch chain
   switch (P.scene.kind) {
     case RM_SCENE_TABLE: return P.scene.nprims >= 16;
     case RM_SCENE_MANDELBULB: return P.scene.p[RM_P_BULB_ITERATIONS] >= 6.0f;

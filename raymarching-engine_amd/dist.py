@@ -36,6 +36,27 @@ class FrameGatherer:
             self.frame = torch.empty((height, width, channels), dtype=torch.float32, device=device)
             self.index = [torch.as_tensor(shard.owned_rows(height, world, p, stripe_rows), device=device) for p in range(world)]
 
+    def start(self, plane, dist):
+        """Begin gathering a SNAPSHOT of `plane` (the render of the next sample may start at once:
+        the plane is accumulated in place).  Returns a handle for finish()."""
+        if self.world == 1:
+            return plane[: self.rows]
+        snap = plane.clone()
+        work = dist.gather(snap, self.recv if self.rank == self.dst else None, dst=self.dst, async_op=True)
+        return (work, snap)
+
+    def finish(self, handle):
+        """Wait for start()'s gather and put the stripes in image order (on dst; None elsewhere)."""
+        if self.world == 1:
+            return handle
+        work, _snap = handle
+        work.wait()
+        if self.rank != self.dst:
+            return None
+        for p in range(self.world):
+            self.frame.index_copy_(0, self.index[p], self.recv[p][: self.counts[p]])
+        return self.frame
+
     def gather(self, plane, dist):
         """plane: [max_rows, W, C] tensor of this rank (first self.rows rows valid).
         Returns the assembled [H, W, C] frame on dst, None elsewhere."""

@@ -47,6 +47,13 @@ def _worker(rank, world, port, width, height, out_path):
             O.render(sc, J.uniforms_from_schema(schema, nz), fr)
         plane[k : k + n] = torch.from_numpy(fr.color)
     frame = g.gather(plane, dist)
+    first = frame.clone() if rank == 0 else None
+    # the overlapped form bench.py uses: snapshot + async gather, finished later
+    handle = g.start(plane, dist)
+    plane.zero_()  # the next sample may already be overwriting the plane
+    frame2 = g.finish(handle)
+    if rank == 0:
+        assert torch.equal(frame2, first)
     if rank == 0:
         np.save(out_path, frame.numpy())
     else:
