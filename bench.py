@@ -121,7 +121,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("RM_BENCH_FORCE_DIST") == "1"  # exercise the RCCL path with one rank (testing aid)
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -137,7 +138,7 @@ def main():
 
     ctx = native.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # launches ordered with torch / RCCL work
-    gatherer = rmdist.FrameGatherer(H, W, world, rank, dev)
+    gatherer = rmdist.FrameGatherer(H, W, world, rank, dev, force=force_dist)
     row_count = gatherer.rows
     # planes live in torch memory (padded to the largest shard so that the gather is regular)
     planes = [torch.zeros((gatherer.max_rows, W, 4), dtype=torch.float32, device=dev) for _ in range(3)]
@@ -148,19 +149,20 @@ def main():
     h2, h3 = J.halton(2), J.halton(3)
 
     pending = [None]
+    u_step = J.uniforms_from_schema(schema, (0.5, 1.0 / 3.0))  # only randNoise changes from sample to sample
 
     def step():
         # render sample n, then start the gather of its (snapshotted) colour plane; the gather runs over
         # RCCL while sample n+1 renders, and frame n is assembled on rank 0 at the start of step n+1
-        u = J.uniforms_from_schema(schema, (next(h2), next(h3)))
-        ctx.render_sample(scene, fb, u, None, flags)
-        if world > 1:
+        u_step.randNoise[0], u_step.randNoise[1] = next(h2), next(h3)
+        ctx.render_sample(scene, fb, u_step, None, flags)
+        if world > 1 or force_dist:
             if pending[0] is not None:
                 gatherer.finish(pending[0])
             pending[0] = gatherer.start(planes[0], dist)
 
     def drain():
-        if world > 1 and pending[0] is not None:
+        if (world > 1 or force_dist) and pending[0] is not None:
             gatherer.finish(pending[0])
             pending[0] = None
 
@@ -226,7 +228,7 @@ def main():
     fb.destroy()
     scene.destroy()
     ctx.close()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:
