@@ -308,11 +308,22 @@ struct Sdf<RM_SCENE_MANDELBULB> {
     const float bail2 = sc.p[RM_P_BULB_BAILOUT] * sc.p[RM_P_BULB_BAILOUT];
     v3 z = pos;
     float dr = 1.0f, r2 = 0.0f;
-    for (int i = 0; i < iterations; i++) {
-      const float rho2 = FM::fma(z.y, z.y, z.x * z.x);
-      r2 = FM::fma(z.z, z.z, rho2);
-      if (r2 > bail2) break;
-      pow8_round(z, dr, pos, rho2, r2);
+    if (iterations == 8) {
+      // the usual round count, unrolled: no loop bookkeeping between the exec-mask regions (11 % on the headline frame)
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const float rho2 = FM::fma(z.y, z.y, z.x * z.x);
+        r2 = FM::fma(z.z, z.z, rho2);
+        if (r2 > bail2) break;
+        pow8_round(z, dr, pos, rho2, r2);
+      }
+    } else {
+      for (int i = 0; i < iterations; i++) {
+        const float rho2 = FM::fma(z.y, z.y, z.x * z.x);
+        r2 = FM::fma(z.z, z.z, rho2);
+        if (r2 > bail2) break;
+        pow8_round(z, dr, pos, rho2, r2);
+      }
     }
     const float r = FM::sqrt(r2);
     return 0.5f * FM::log(r) * r * FM::rcp(dr);
