@@ -228,6 +228,14 @@ int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out) {
   s->ctx = ctx;
   s->dev.kind = desc->kind;
   s->dev.nprims = desc->kind == RM_SCENE_TABLE ? desc->nprims : 0;
+  if (desc->kind == RM_SCENE_TABLE) {
+    bool spheres_smooth = true;
+    for (int i = 0; i < desc->nprims; i++) {
+      const int type = desc->prims[i].type & 0xff, op = (desc->prims[i].type >> 8) & 0xff;
+      if (type != RM_PRIM_SPHERE || (i > 0 && op != RM_OP_SMOOTH_UNION)) spheres_smooth = false;
+    }
+    s->dev.table_flags = spheres_smooth ? RM_TABLE_SPHERES_SMOOTH : 0;
+  }
   std::memcpy(s->dev.p, desc->params, sizeof s->dev.p);
   s->dev.mat = desc->material;
   (void)hipSetDevice(ctx->device);

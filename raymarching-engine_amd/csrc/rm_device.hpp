@@ -224,10 +224,45 @@ struct Sdf<RM_SCENE_TABLE> {
   static constexpr bool nonfinite_normal_is_nan = true;
   static RM_DEV void stage(const DevScene& sc, SceneLds& lds) {
     const float4* src = reinterpret_cast<const float4*>(sc.prims);
-    for (int i = threadIdx.x; i < sc.nprims * 2; i += blockDim.x) lds.rows[i] = src[i];
+    for (int i = threadIdx.x; i < sc.nprims * 2; i += blockDim.x) {
+      float4 v = src[i];
+      if ((sc.table_flags & RM_TABLE_SPHERES_SMOOTH) && (i & 1)) {  // second half-row of a sphere: size[1] := 1/k
+        const float k = reinterpret_cast<const float*>(sc.prims)[(i >> 1) * 8 + 1];
+        v.z = 1.0f / k;
+      }
+      lds.rows[i] = v;
+    }
+  }
+  // Fast-policy path for the common table "spheres folded with smooth unions" (BASELINE configs[3]/[4]):
+  // no per-row dispatch, 1/k read from the row (a sphere does not use size[1]; stage() puts 1/k there),
+  // two rows per trip so that the LDS reads of the next rows are in flight during the arithmetic.
+  static RM_DEV float sphere_row(const float4 a, const float4 b, v3 p) {
+    const v3 q = p - V(a.z, a.w, b.x);
+    return FM::sqrt(FM::fma(q.z, q.z, FM::fma(q.y, q.y, q.x * q.x))) - b.y;
+  }
+  static RM_DEV float smooth_row(float d, float di, float k, float inv_k) {
+    const float h = gclamp(FM::fma(0.5f * inv_k, di - d, 0.5f), 0.0f, 1.0f);
+    return FM::fma(h, d - di, di) - k * h * (1.0f - h);
+  }
+  static RM_DEV float eval_spheres_smooth(const DevScene& sc, const SceneLds& lds, v3 p) {
+    const int n = sc.nprims;
+    float d = sphere_row(lds.rows[0], lds.rows[1], p);
+    int i = 1;
+    for (; i + 1 < n; i += 2) {
+      const float4 a0 = lds.rows[2 * i], b0 = lds.rows[2 * i + 1], a1 = lds.rows[2 * i + 2], b1 = lds.rows[2 * i + 3];
+      const float d0 = sphere_row(a0, b0, p), d1 = sphere_row(a1, b1, p);
+      d = smooth_row(d, d0, a0.y, b0.z);
+      d = smooth_row(d, d1, a1.y, b1.z);
+    }
+    if (i < n) {
+      const float4 a0 = lds.rows[2 * i], b0 = lds.rows[2 * i + 1];
+      d = smooth_row(d, sphere_row(a0, b0, p), a0.y, b0.z);
+    }
+    return d;
   }
   template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds& lds, v3 p) {
+    if (M::fast && (sc.table_flags & RM_TABLE_SPHERES_SMOOTH)) return eval_spheres_smooth(sc, lds, p);
     float d = 0.0f;
     const int n = sc.nprims;
     for (int i = 0; i < n; i++) {

@@ -5,9 +5,14 @@
 
 #include "../../include/hip_raymarch.h"
 
+// table_flags of DevScene (set by rm_scene_create)
+#define RM_TABLE_SPHERES_SMOOTH 1  /* every row is a sphere and every fold after the first a smooth union */
+
 struct DevScene {
   int kind;
   int nprims;
+  int table_flags;
+  int reserved;
   const RmPrim* prims;  // device pointer (RM_SCENE_TABLE)
   float p[16];
   RmMaterial mat;
