@@ -203,7 +203,7 @@ def main():
         try:  # measured in a separate rocprofv3 --pmc run (profiles/r01_traffic.json says how)
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
             if args.workload == "c3b" and not args.strict:
-                traffic = (tj["megakernel_hbm_bytes_per_frame"] if args.megakernel else tj["hbm_bytes_per_frame"]) * px_launch / (3840 * 2160)
+                traffic = (tj["hbm_bytes_per_frame"] if args.wavefront else tj["megakernel_hbm_bytes_per_frame"]) * px_launch / (3840 * 2160)
         except Exception:
             pass
         if flops_px is not None:
@@ -220,7 +220,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["name"], "build": "strict" if args.strict else "fast",
-                       "rows_per_gpu": row_count, "pipeline": "megakernel" if args.megakernel else "wavefront" if args.wavefront else "auto (wavefront for this workload)" if args.workload in ("c3b", "c4", "c5") else "auto (megakernel for this workload)",
+                       "rows_per_gpu": row_count, "pipeline": "megakernel" if args.megakernel else "wavefront" if args.wavefront else "auto (wavefront)" if (args.strict and args.workload in ("c3b", "c4", "c5")) else "auto (megakernel)",
                        "sharding": f"{shard.STRIPE_ROWS}-row stripes round-robin over ranks, colour plane gathered to rank 0 over RCCL every step (overlapped with the next sample's render) and put back in image order" if world > 1 else "none",
                        "planes": "color+normal_dof+albedo_depth fp32, accumulated in place"},
             "roofline": roof, "cpu_baseline": cpu,

@@ -175,9 +175,8 @@ enum {
   RM_RENDER_COLOR_ONLY = 2,  /* do not read/write the two G-buffer planes (benchmark "single colour frame" mode) */
   RM_RENDER_MEGAKERNEL = 4,  /* force the one-thread-one-pixel kernel (whole main() per thread) */
   RM_RENDER_WAVEFRONT = 16,  /* force the wavefront pipeline (ray-compacting persistent march).  With neither flag the
-                                library picks per job: the pipeline pays for large full-mode frames of costly scenes
-                                (big primitive tables, the Mandelbulb), the single kernel for everything else
-                                (measured table: DESIGN.md).  Same results either way. */
+                                library picks per job from a measured table: the single kernel, except for
+                                large full-mode frames of costly scenes in the strict build.  Same results either way. */
   RM_RENDER_NO_COST_CLASSES = 8 /* wavefront march in one pass even for scene kinds whose sdf cost depends on the
                                    point (Mandelbulb); a measurement switch, same results */
 };

@@ -602,12 +602,14 @@ static hipError_t launch_wavefront(rm_ctx* ctx, const KParams& P, int flags) {
 }
 
 // Which implementation of the per-pixel program runs a job (same results either way).
-// Measured on MI355X (tools/time_all.py): the wavefront pipeline wins on large
-// full-mode frames whose rays are expensive and of very unequal length (64-primitive CSG
-// 4096^2: 73 vs 92 ms; Mandelbulb 4K lit: 4.7 vs 4.9 ms); its per-ray state traffic and
-// launch chain lose on cheap or short rays (sphere 1080p preview: 1.5 vs 0.11 ms; 5-bounce
-// sphere-grid fractal 720p: 6.3 vs 3.3 ms; any preview).
-static bool prefer_wavefront(const KParams& P) {
+// Measured on MI355X at the end of round 1 (tools/time_all.py): in the fast build the
+// one-kernel form is as fast or faster everywhere (Mandelbulb 4K lit 4.04 vs 4.02 ms, CSG-64 4096^2
+// 49.2 vs 49.2, sphere 1080p preview 0.11 vs 1.7): once the distance estimators were lean, the
+// pipeline's per-ray state traffic and launch chain cost what its ray compaction saves.  In the
+// strict build, whose evaluations are 5-10x more expensive, compaction still pays on large full-mode
+// frames of costly scenes (Mandelbulb 4K lit 31 vs 38 ms, CSG-64 4096^2 132 vs 164 ms).
+static bool prefer_wavefront(const KParams& P, int flags) {
+  if (flags & RM_RENDER_FAST) return false;
   if (P.u.renderMode == 1) return false;
   if ((long long)P.tw * (long long)P.th < (1ll << 21)) return false;  // small tiles/shards: one launch beats a launch chain
   switch (P.scene.kind) {
@@ -618,7 +620,7 @@ static bool prefer_wavefront(const KParams& P) {
 }
 
 static hipError_t launch(rm_ctx* ctx, const KParams& P, int flags) {
-  const bool wavefront = (flags & RM_RENDER_WAVEFRONT) ? true : (flags & RM_RENDER_MEGAKERNEL) ? false : prefer_wavefront(P);
+  const bool wavefront = (flags & RM_RENDER_WAVEFRONT) ? true : (flags & RM_RENDER_MEGAKERNEL) ? false : prefer_wavefront(P, flags);
   if (!wavefront) return (flags & RM_RENDER_FAST) ? rm::launch_pixels_fast(P, ctx->stream) : rm::launch_pixels_strict(P, ctx->stream);
   return launch_wavefront(ctx, P, flags);
 }
