@@ -21,7 +21,7 @@ struct rm_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  float retire_eps = 4.76837158203125e-07f;  // 2^-21
+  float retire_eps = 0.0f;  // opt-in (rm_ctx_set_retire_eps): any tolerance brightens lit pixels, see the header
   int cu_count = 256;
   // persistent-grid sizes in workgroups per CU, from a sweep on the headline frame (tools/sweep.sh):
   // the Mandelbulb passes want FEW waves (every wave ends in a tail of a few long rays), the table march wants all slots
@@ -528,7 +528,7 @@ static hipError_t launch_wavefront_band(rm_ctx* ctx, const KParams& P, int flags
     W.bounce = b;
     W.last_bounce = b == bounces - 1;
     if ((e = do_march(rm::WF_POS, rm::WF_DIR, false)) != hipSuccess) return e;
-    if ((e = rm::wf_launch_stage(W, 4, stream)) != hipSuccess) return e;  // shade
+    if ((e = fast ? rm::wf_launch_shade_fast(W, stream) : rm::wf_launch_shade_strict(W, stream)) != hipSuccess) return e;
     for (int j = 0; j < P.u.lightCount; j++) {
       W.light = j;
       if ((e = do_march(rm::WF_SPOS, rm::WF_SDIR, false)) != hipSuccess) return e;

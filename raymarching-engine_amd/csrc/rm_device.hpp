@@ -27,6 +27,10 @@
 #include "rm_params.hpp"
 
 namespace rm {
+#ifdef RM_LANE_STATS
+static __device__ unsigned long long g_lane_stats[4];
+#endif
+
 
 #define RM_DEV __device__ __forceinline__
 
@@ -56,6 +60,8 @@ struct PM {
   static RM_DEV float cos(float x) { return cosf(x); }
   static RM_DEV float acos(float x) { return acosf(x); }
   static RM_DEV float atan2(float y, float x) { return atan2f(y, x); }
+  static RM_DEV void sincos(float x, float& s, float& c) { sincosf(x, &s, &c); }  // the bits of sinf and cosf
+  static RM_DEV void pow_pair(float r, float n, float& r_nm1, float& r_n) { r_nm1 = pow(r, n - 1.0f); r_n = pow(r, n); }
 };
 
 struct FM {
@@ -70,6 +76,8 @@ struct FM {
   static RM_DEV float cos(float x) { return __builtin_amdgcn_cosf(x * 0.15915494309189535f); }
   static RM_DEV float acos(float x) { return acosf(x); }
   static RM_DEV float atan2(float y, float x) { return atan2f(y, x); }
+  static RM_DEV void sincos(float x, float& s, float& c) { s = sin(x); c = cos(x); }
+  static RM_DEV void pow_pair(float r, float n, float& r_nm1, float& r_n) { r_nm1 = pow(r, n - 1.0f); r_n = pow(r, n); }
 };
 
 // ---- vector helpers / GLSL built-ins (semantics pinned in oracle/rm_oracle.c)
@@ -293,11 +301,15 @@ struct Sdf<RM_SCENE_MANDELBULB> {
   static RM_DEV void generic_round(v3& z, float& dr, v3 pos, float r, float power) {
     float theta = M::acos(M::div(z.z, r));
     float phi = M::atan2(z.y, z.x);
-    dr = M::pow(r, power - 1.0f) * power * dr + 1.0f;
-    float zr = M::pow(r, power);
+    float r_nm1, zr;
+    M::pow_pair(r, power, r_nm1, zr);
+    dr = r_nm1 * power * dr + 1.0f;
     theta = theta * power;
     phi = phi * power;
-    z = V(M::sin(theta) * M::cos(phi), M::sin(phi) * M::sin(theta), M::cos(theta)) * zr;
+    float st, ct, sp, cp;
+    M::sincos(theta, st, ct);
+    M::sincos(phi, sp, cp);
+    z = V(st * cp, sp * st, ct) * zr;
     z = z + pos;
   }
   template <class M>
@@ -345,13 +357,36 @@ struct Sdf<RM_SCENE_MANDELBULB> {
     float dr = 1.0f, r2 = 0.0f;
     if (iterations == 8) {
       // the usual round count, unrolled: no loop bookkeeping between the exec-mask regions (11 % on the headline frame)
+#ifdef RM_LANE_STATS
+      int rounds = 0;
+#endif
 #pragma unroll
       for (int i = 0; i < 8; i++) {
         const float rho2 = FM::fma(z.y, z.y, z.x * z.x);
         r2 = FM::fma(z.z, z.z, rho2);
         if (r2 > bail2) break;
         pow8_round(z, dr, pos, rho2, r2);
+#ifdef RM_LANE_STATS
+        rounds++;
+#endif
       }
+#ifdef RM_LANE_STATS
+      {  // diagnostic build (tools/lane_stats.py): lanes x rounds used against lanes x rounds issued
+        const unsigned long long act = __ballot(1);
+        unsigned long long lane_rounds = 0, wave_rounds = 0;
+        for (int r = 1; r <= 8; r++) {
+          const unsigned long long m = __ballot(rounds >= r);
+          lane_rounds += __popcll(m);
+          wave_rounds += m != 0ull ? 1 : 0;
+        }
+        if ((int)__lane_id() == __ffsll((long long)act) - 1) {
+          atomicAdd(&g_lane_stats[0], lane_rounds);
+          atomicAdd(&g_lane_stats[1], wave_rounds * 64ull);
+          atomicAdd(&g_lane_stats[2], (unsigned long long)__popcll(act));
+          atomicAdd(&g_lane_stats[3], 64ull);
+        }
+      }
+#endif
     } else {
       for (int i = 0; i < iterations; i++) {
         const float rho2 = FM::fma(z.y, z.y, z.x * z.x);

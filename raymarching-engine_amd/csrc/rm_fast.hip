@@ -6,3 +6,15 @@
 #include "rm_device.hpp"
 #include "rm_kernels.inc"
 #include "rm_wavefront.inc"
+
+#ifdef RM_LANE_STATS
+// diagnostic build only: Mandelbulb evaluations of this TU, {lane-rounds used, lane-rounds issued, lanes active, lanes issued}
+extern "C" int rm_fast_lane_stats(unsigned long long* out4, int reset) {
+  if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(rm::g_lane_stats), 32) != hipSuccess) return 1;
+  if (reset) {
+    const unsigned long long z[4] = {0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(rm::g_lane_stats), z, 32) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif

@@ -89,6 +89,8 @@ struct WfParams {
 // pass 0: single pass; 1: cheap pass (parks rays that need the deep evaluation); 2: full pass over the parked list
 hipError_t wf_launch_march_strict(const WfParams& W, bool preview, int pass, int blocks, hipStream_t stream);
 hipError_t wf_launch_march_fast(const WfParams& W, bool preview, int pass, int blocks, hipStream_t stream);
+hipError_t wf_launch_shade_strict(const WfParams& W, hipStream_t stream);
+hipError_t wf_launch_shade_fast(const WfParams& W, hipStream_t stream);
 bool wf_kind_has_cost_classes(int kind);
 hipError_t launch_present(const float4* color, const float4* normal_dof, int W, int H, float brightness, uchar4* out, hipStream_t stream);
 hipError_t wf_launch_stage(const WfParams& W, int stage, hipStream_t stream);
