@@ -346,7 +346,9 @@ struct Sdf<RM_SCENE_MANDELBULB> {
       t = FM::fma(C, C, -(D * D)); D = (C + C) * D; C = t;
     }
     const float q2 = q * q, q4 = q2 * q2, q8 = q4 * q4;
-    const bool on_axis = !(rho2 > 0.0f) || !(q8 < __builtin_inff());  // phi = atan(0, 0) = 0 there: cos 8phi = 1, sin 8theta = 0
+    // on the axis (rho2 = 0: q = rsq(0) = Inf; also a rho so small that q^8 overflows, or NaN) phi = atan(0, 0) = 0:
+    // cos 8phi = 1, sin 8theta = 0.  One test covers them all.
+    const bool on_axis = !(q8 < __builtin_inff());
     const float s8 = on_axis ? 0.0f : B * q8;  // r^8 sin(8 theta) / rho^8
     z = V(FM::fma(s8, C, pos.x), FM::fma(s8, D, pos.y), A + pos.z);
   }
