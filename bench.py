@@ -106,6 +106,10 @@ def main():
     ap.add_argument("--megakernel", action="store_true", help="force the one-thread-one-pixel kernel (default: the library picks per job)")
     ap.add_argument("--wavefront", action="store_true", help="force the wavefront pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="consecutive samples that may overlap on one GPU (rm_ctx_set_samples_in_flight); default: 1 on one GPU, "
+                         "so that a kernel's duration in a rocprofv3 trace is the time of a step, 3 when the frame is sharded "
+                         "(a shard's launch is too small to fill the chip: a ray is a ~1 ms serial chain)")
     args = ap.parse_args()
 
     import numpy as np
@@ -126,6 +130,9 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if force_dist and world == 1:
+            for key, val in (("MASTER_PORT", "29511"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+                os.environ.setdefault(key, val)
         dist.init_process_group("nccl", device_id=dev)
 
     wl, sc, schema = make_workload(args.workload)
@@ -138,6 +145,8 @@ def main():
 
     ctx = native.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # launches ordered with torch / RCCL work
+    in_flight = args.in_flight if args.in_flight > 0 else (1 if world == 1 else 3)
+    ctx.set_samples_in_flight(in_flight)
     gatherer = rmdist.FrameGatherer(H, W, world, rank, dev, force=force_dist)
     row_count = gatherer.rows
     # planes live in torch memory (padded to the largest shard so that the gather is regular)
@@ -192,7 +201,7 @@ def main():
     if rank == 0:
         # kernel time of this rank's launch, HIP events on the launch stream
         u = J.uniforms_from_schema(schema, (0.5, 1.0 / 3.0))
-        kernel_ms = ctx.render_timed(scene, fb, u, max(3, min(args.steps, 10)), None, flags)
+        kernel_ms = ctx.render_timed(scene, fb, u, max(3, min(args.steps, 10)), None, flags | abi.RM_RENDER_NO_OVERLAP)
         cpu, flops_px = (None, None)
         if world == 1 and not args.no_cpu_baseline:
             cpu, flops_px = cpu_baseline(sc, schema)
@@ -222,7 +231,7 @@ def main():
             "config": {"workload": wl["name"], "build": "strict" if args.strict else "fast",
                        "rows_per_gpu": row_count, "pipeline": "megakernel" if args.megakernel else "wavefront" if args.wavefront else "auto (wavefront)" if (args.strict and args.workload in ("c3b", "c4", "c5")) else "auto (megakernel)",
                        "sharding": f"{shard.STRIPE_ROWS}-row stripes round-robin over ranks, colour plane gathered to rank 0 over RCCL every step (overlapped with the next sample's render) and put back in image order" if world > 1 else "none",
-                       "planes": "color+normal_dof+albedo_depth fp32, accumulated in place"},
+                       "planes": "color+normal_dof+albedo_depth fp32, accumulated in place", "samples_in_flight": in_flight},
             "roofline": roof, "cpu_baseline": cpu,
         }
     fb.destroy()

@@ -177,8 +177,10 @@ enum {
   RM_RENDER_WAVEFRONT = 16,  /* force the wavefront pipeline (ray-compacting persistent march).  With neither flag the
                                 library picks per job from a measured table: the single kernel, except for
                                 large full-mode frames of costly scenes in the strict build.  Same results either way. */
-  RM_RENDER_NO_COST_CLASSES = 8 /* wavefront march in one pass even for scene kinds whose sdf cost depends on the
+  RM_RENDER_NO_COST_CLASSES = 8, /* wavefront march in one pass even for scene kinds whose sdf cost depends on the
                                    point (Mandelbulb); a measurement switch, same results */
+  RM_RENDER_NO_OVERLAP = 32  /* this sample runs alone on the context's stream and blends in its own kernel (see
+                                rm_ctx_set_samples_in_flight); for timing one launch.  Same results. */
 };
 
 enum { RM_PLANE_COLOR = 0, RM_PLANE_NORMAL_DOF = 1, RM_PLANE_ALBEDO_DEPTH = 2 };
@@ -196,6 +198,14 @@ const char* rm_last_error(const rm_ctx* ctx);
 /* Use an externally owned hipStream_t (e.g. torch's current stream) for all
  * later launches; NULL restores the context's own stream. */
 int rm_ctx_set_stream(rm_ctx* ctx, void* hip_stream);
+/* Samples in flight (default 3, 1 = off; environment RM_SAMPLES_IN_FLIGHT).  The reference submits its draw calls
+ * back to back (RenderJobExecutor.tsx:240-260) and the GPU overlaps them; here a full-mode sample of the pixel
+ * kernel renders on an internal side stream into a staging buffer (it reads no plane) and a small kernel on the
+ * context's stream blends it into the planes, in call order, so up to n consecutive rm_render_sample(s) calls
+ * overlap.  Every call is still ordered on the context's stream as far as the planes are concerned: work enqueued
+ * there afterwards sees the sample blended.  The planes receive the same bits as without overlap.  Costs 3 planes
+ * of staging per sample in flight. */
+int rm_ctx_set_samples_in_flight(rm_ctx* ctx, int n);
 /* RM_RENDER_FAST only, opt-in: a marching lane counts as settled once its step
  * |d| <= eps * max(1, |p|_inf).  The default is 0: only the exact test
  * (position bitwise unchanged), which is what RM_RENDER_STRICT always uses.

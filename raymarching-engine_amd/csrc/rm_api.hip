@@ -16,6 +16,8 @@
 #include "../../include/hip_raymarch.h"
 #include "rm_params.hpp"
 
+#define RM_SP_MAX 8
+
 struct rm_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
@@ -42,6 +44,17 @@ struct rm_ctx {
   int wf_bands = 0;  // bands of rows in flight on side streams; 0 = automatic (2 for large tiles: measured best)
   int wf_blocks_per_cu = 8;
   int claims_per_wave = 8;
+  // Samples in flight (pixel-kernel path, full mode): sample n renders on side stream n % depth into a staging
+  // buffer and is blended into the planes, in order, by a small kernel on the context's stream; the next samples
+  // render meanwhile.  One sample alone leaves the chip partly idle: a ray is a serial chain of ~2e5 instructions
+  // (~1 ms), so every launch ends in a tail and a small shard never fills the SIMDs.
+  int samples_in_flight = 3;
+  hipStream_t sp_stream[RM_SP_MAX] = {};
+  hipEvent_t sp_done[RM_SP_MAX] = {}, sp_free[RM_SP_MAX] = {};
+  float4* sp_stage[RM_SP_MAX] = {};
+  size_t sp_capacity = 0;  // float4 elements per staged plane
+  unsigned int sp_next = 0;
+  bool sp_ready = false;
   std::string error;
 };
 
@@ -120,6 +133,7 @@ int rm_ctx_create(int device, rm_ctx** out) {
   if (const char* v = std::getenv("RM_PASS1_BLOCKS_PER_CU")) { int n = std::atoi(v); if (n >= 1 && n <= 8) ctx->pass1_blocks_per_cu = n; }
   if (const char* v = std::getenv("RM_PASS2_ROUNDS")) { int n = std::atoi(v); if (n >= 1 && n <= 3) ctx->pass2_rounds = n; }
   if (const char* v = std::getenv("RM_REPARK")) { int n = std::atoi(v); if (n >= 0 && n <= 63) ctx->repark = n; }
+  if (const char* v = std::getenv("RM_SAMPLES_IN_FLIGHT")) { int n = std::atoi(v); if (n >= 1 && n <= RM_SP_MAX) ctx->samples_in_flight = n; }
   if (const char* v = std::getenv("RM_WF_CLAIMS")) { int n = std::atoi(v); if (n >= 1 && n <= 64) ctx->claims_per_wave = n; }
   if (const char* v = std::getenv("RM_WF_BLOCKS_PER_CU")) { int n = std::atoi(v); if (n >= 1 && n <= 8) ctx->wf_blocks_per_cu = n; }
   if (const char* v = std::getenv("RM_WF_BANDS")) { int n = std::atoi(v); if (n >= 1 && n <= 8) ctx->wf_bands = n; }
@@ -142,6 +156,12 @@ void rm_ctx_destroy(rm_ctx* ctx) {
     if (ctx->wf_join[s]) (void)hipEventDestroy(ctx->wf_join[s]);
   }
   if (ctx->wf_fork) (void)hipEventDestroy(ctx->wf_fork);
+  for (int s = 0; s < RM_SP_MAX; s++) {
+    if (ctx->sp_stream[s]) { (void)hipStreamSynchronize(ctx->sp_stream[s]); (void)hipStreamDestroy(ctx->sp_stream[s]); }
+    if (ctx->sp_done[s]) (void)hipEventDestroy(ctx->sp_done[s]);
+    if (ctx->sp_free[s]) (void)hipEventDestroy(ctx->sp_free[s]);
+    if (ctx->sp_stage[s]) (void)hipFree(ctx->sp_stage[s]);
+  }
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -152,7 +172,17 @@ const char* rm_last_error(const rm_ctx* ctx) { return ctx ? ctx->error.c_str() :
 
 int rm_ctx_set_stream(rm_ctx* ctx, void* hip_stream) {
   if (!ctx) return RM_ERR_INVALID;
+  // samples in flight are blended in order on the current stream: let them land before the order moves elsewhere
+  if (ctx->sp_ready) RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  return RM_OK;
+}
+
+int rm_ctx_set_samples_in_flight(rm_ctx* ctx, int n) {
+  if (!ctx) return RM_ERR_INVALID;
+  if (n < 1 || n > RM_SP_MAX) return fail(ctx, RM_ERR_INVALID, "rm_ctx_set_samples_in_flight: n must be in 1..8");
+  if (ctx->sp_ready) RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->samples_in_flight = n;
   return RM_OK;
 }
 
@@ -442,6 +472,8 @@ static int build_params(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniform
   P->stripe_rows = fb->stripe_rows; P->parts = fb->parts; P->part = fb->part;
   P->tx = x0; P->ty = l0; P->tw = x1 - x0; P->th = l1 - l0;
   P->retire_eps = (flags & RM_RENDER_FAST) ? ctx->retire_eps : 0.0f;
+  P->stage = nullptr;
+  P->stage_stride = 0;
   return RM_OK;
 }
 
@@ -619,10 +651,54 @@ static bool prefer_wavefront(const KParams& P, int flags) {
   }
 }
 
+// The pixel kernel of one sample on a side stream, staged, and its blend on the context's stream (see rm_ctx).
+static hipError_t launch_pixels_in_flight(rm_ctx* ctx, const KParams& P, int flags) {
+  hipError_t e;
+  const int depth = ctx->samples_in_flight;
+  if (!ctx->sp_ready) {
+    for (int s = 0; s < RM_SP_MAX; s++) {
+      if ((e = hipStreamCreateWithFlags(&ctx->sp_stream[s], hipStreamNonBlocking)) != hipSuccess) return e;
+      if ((e = hipEventCreateWithFlags(&ctx->sp_done[s], hipEventDisableTiming)) != hipSuccess) return e;
+      if ((e = hipEventCreateWithFlags(&ctx->sp_free[s], hipEventDisableTiming)) != hipSuccess) return e;
+    }
+    ctx->sp_ready = true;
+  }
+  const size_t need = (size_t)(P.ty + P.th) * (size_t)P.W;  // staged values sit at the plane index of their pixel
+  if (ctx->sp_capacity < need) {
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
+    for (int s = 0; s < RM_SP_MAX; s++) {
+      if (ctx->sp_stage[s]) (void)hipFree(ctx->sp_stage[s]);
+      ctx->sp_stage[s] = nullptr;
+    }
+    ctx->sp_capacity = 0;
+    for (int s = 0; s < depth; s++)
+      if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->sp_stage[s]), sizeof(float4) * 3 * need)) != hipSuccess) return e;
+    ctx->sp_capacity = need;
+  }
+  const int slot = (int)(ctx->sp_next++ % (unsigned int)depth);
+  if (!ctx->sp_stage[slot]) {  // the depth was raised after the buffers were made
+    if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->sp_stage[slot]), sizeof(float4) * 3 * ctx->sp_capacity)) != hipSuccess) return e;
+  }
+  KParams Q = P;
+  Q.stage = ctx->sp_stage[slot];
+  Q.stage_stride = (long long)ctx->sp_capacity;
+  hipStream_t side = ctx->sp_stream[slot];
+  // the render reads no plane: it only has to wait until the blend that last used this staging buffer is done
+  if ((e = hipStreamWaitEvent(side, ctx->sp_free[slot], 0)) != hipSuccess) return e;
+  if ((e = (flags & RM_RENDER_FAST) ? rm::launch_pixels_fast(Q, side) : rm::launch_pixels_strict(Q, side)) != hipSuccess) return e;
+  if ((e = hipEventRecord(ctx->sp_done[slot], side)) != hipSuccess) return e;
+  if ((e = hipStreamWaitEvent(ctx->stream, ctx->sp_done[slot], 0)) != hipSuccess) return e;
+  if ((e = rm::launch_combine(Q, ctx->stream)) != hipSuccess) return e;
+  return hipEventRecord(ctx->sp_free[slot], ctx->stream);
+}
+
 static hipError_t launch(rm_ctx* ctx, const KParams& P, int flags) {
   const bool wavefront = (flags & RM_RENDER_WAVEFRONT) ? true : (flags & RM_RENDER_MEGAKERNEL) ? false : prefer_wavefront(P, flags);
-  if (!wavefront) return (flags & RM_RENDER_FAST) ? rm::launch_pixels_fast(P, ctx->stream) : rm::launch_pixels_strict(P, ctx->stream);
-  return launch_wavefront(ctx, P, flags);
+  if (wavefront) return launch_wavefront(ctx, P, flags);
+  // full mode with at least one bounce: the kernel's only use of the planes is the final blend, which can be split off
+  if (ctx->samples_in_flight > 1 && !(flags & RM_RENDER_NO_OVERLAP) && P.u.renderMode == 0 && P.u.reflections > 0.0f)
+    return launch_pixels_in_flight(ctx, P, flags);
+  return (flags & RM_RENDER_FAST) ? rm::launch_pixels_fast(P, ctx->stream) : rm::launch_pixels_strict(P, ctx->stream);
 }
 
 int rm_render_sample(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* uniforms, const RmRect* tile, int flags) {

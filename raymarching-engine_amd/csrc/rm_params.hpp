@@ -29,6 +29,11 @@ struct KParams {
   int stripe_rows, parts, part;  // striped window (stripe_rows > 0): rows r with (r / stripe_rows) % parts == part
   int tx, ty, tw, th;  // tile clipped to the window; ty/th count LOCAL rows (rows of the planes)
   float retire_eps;    // 0 = exact (fixed-point) retire only
+  // Staged output (full mode, samples in flight): the pixel kernel does not touch the planes; it leaves what
+  // the sample adds -- (light * exposure, -), (normal, dofRadius), (albedo, depth) -- in stage[0..2][pixel] and
+  // rm_combine_kernel applies the blend afterwards, in sample order.  nullptr = blend in the kernel.
+  float4* stage;
+  long long stage_stride;  // elements between the three staged planes
 };
 
 // image row of a local (plane) row
@@ -89,6 +94,7 @@ struct WfParams {
 // pass 0: single pass; 1: cheap pass (parks rays that need the deep evaluation); 2: full pass over the parked list
 hipError_t wf_launch_march_strict(const WfParams& W, bool preview, int pass, int blocks, hipStream_t stream);
 hipError_t wf_launch_march_fast(const WfParams& W, bool preview, int pass, int blocks, hipStream_t stream);
+hipError_t launch_combine(const KParams& P, hipStream_t stream);
 hipError_t wf_launch_shade_strict(const WfParams& W, hipStream_t stream);
 hipError_t wf_launch_shade_fast(const WfParams& W, hipStream_t stream);
 bool wf_kind_has_cost_classes(int kind);

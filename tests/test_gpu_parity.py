@@ -455,3 +455,33 @@ def test_do_render_job_generator_semantics(ctx):
     bad = dict(schema, sdfScene=S.CsgScene().smooth_union(0.0).sphere((0, 0, 0), 1).sphere((1, 0, 0), 1))
     res = J.drain(J.do_render_job(bad, jc)(lambda *a: None))
     assert res["success"] is False and res["why"]["type"] == "fragment"
+
+
+@pytest.mark.parametrize("case", ["sphere_full_3b_soft_4spp", "sphere_full_mix_2spp", "csg_mixed_full_2b", "mandelbulb_full_light", "fractal1_full_2b"])
+def test_samples_in_flight_leave_the_same_bits(ctx, case):
+    """Consecutive full-mode samples overlap on the GPU (each renders into a staging
+    buffer on a side stream, a small kernel blends them into the planes in call order,
+    rm_ctx_set_samples_in_flight): every plane ends up with exactly the bits of the
+    one-sample-at-a-time run, in both builds, for whole frames, tiles, colour-only
+    renders and more samples than staging buffers."""
+    sc, samples, schema = GC.image_schema(case)
+    noises = GC.halton_pairs(7)
+    NO = abi.RM_RENDER_NO_OVERLAP
+    for build in (STRICT, FAST):
+        alone = render_gpu(ctx, sc, schema, noises, build | MK | NO)
+        for depth in (2, 3, 8):
+            ctx.set_samples_in_flight(depth)
+            try:
+                got = render_gpu(ctx, sc, schema, noises, build | MK)
+            finally:
+                ctx.set_samples_in_flight(3)
+            for k in range(3):
+                assert same_bits(got[k], alone[k]).all(), f"build {build} depth {depth} plane {k}"
+        tile = abi.RmRect(5, 3, 41, 22)
+        a = render_gpu(ctx, sc, schema, noises[:3], build | MK | NO, tile=tile)
+        b = render_gpu(ctx, sc, schema, noises[:3], build | MK, tile=tile)
+        for k in range(3):
+            assert same_bits(a[k], b[k]).all(), f"tile, plane {k}"
+        a = render_gpu(ctx, sc, schema, noises[:3], build | MK | NO | abi.RM_RENDER_COLOR_ONLY)
+        b = render_gpu(ctx, sc, schema, noises[:3], build | MK | abi.RM_RENDER_COLOR_ONLY)
+        assert same_bits(a[0], b[0]).all() and not b[1].any() and not b[2].any()
