@@ -2,9 +2,9 @@
 radian628/raymarching-engine.  The compute path is
 csrc/ -> libhip_raymarch.so (C ABI, include/hip_raymarch.h); this package is
 the host side above it."""
-from . import abi, scene, job, shard, params  # noqa: F401
+from . import abi, scene, job, shard, params, capture  # noqa: F401
 
-__all__ = ["abi", "scene", "job", "shard", "params", "native"]
+__all__ = ["abi", "scene", "job", "shard", "params", "capture", "native"]
 
 
 def __getattr__(name):

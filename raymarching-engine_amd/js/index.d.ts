@@ -38,7 +38,13 @@ export type RenderJobSchema = {
   };
   lights: RenderJobLight[];
 };
-export type RenderJobFramebufferInfo = { width: number; height: number; frameid: number; download(plane?: 0 | 1 | 2): Float32Array };
+export type RenderJobFramebufferInfo = {
+  width: number; height: number; frameid: number; download(plane?: 0 | 1 | 2): Float32Array;
+  /** display.frag on the GPU: RGBA8, row 0 = bottom */
+  present(samples: number): Uint8Array;
+  /** canvas.toDataURL("image/png") of the presented frame (index.tsx:470-476) */
+  toDataURL(samples: number): string;
+};
 export type ShaderError = { type: "vertex" | "fragment" | "program"; infoLog: string };
 export class RenderJobContext {
   constructor(device?: number, flags?: number);
@@ -53,4 +59,5 @@ export function doRenderJob(schema: RenderJobSchema, context: RenderJobContext):
 export function uniformsFromSchema(schema: RenderJobSchema, randNoise: [number, number]): ArrayBuffer;
 export function halton(base: number): Generator<number, never, unknown>;
 export function resetHalton(): void;
+export function encodePng(rgba: Uint8Array, width: number, height: number, bottomUp?: boolean): Buffer;
 export const RM: { [name: string]: number };

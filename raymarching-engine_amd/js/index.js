@@ -157,7 +157,11 @@ class RenderJobContext {  // RenderJobContext + loadRenderJobContext (LoadRender
     let fb;
     if (i >= 0) { const e = this.purgatory.splice(i, 1)[0]; if (e.frameid !== frameid) addon.fbClear(e.fb); fb = e.fb; }
     else fb = addon.fbCreate(this.ctx, w, h, 0, h);
-    const info = { fb, width: w, height: h, frameid, download: (plane = 0) => { const out = new Float32Array(w * h * 4); addon.fbDownload(this.ctx, fb, plane, out); return out; } };
+    const info = { fb, width: w, height: h, frameid, download: (plane = 0) => { const out = new Float32Array(w * h * 4); addon.fbDownload(this.ctx, fb, plane, out); return out; },
+                   // the present pass (display.frag) on the GPU: RGBA8, row 0 = bottom
+                   present: (samples) => { const out = new Uint8Array(w * h * 4); addon.present(this.ctx, fb, samples, out); return out; },
+                   // canvas.toDataURL("image/png"), index.tsx:470-476
+                   toDataURL: (samples) => "data:image/png;base64," + encodePng(info.present(samples), w, h).toString("base64") };
     this.live.set(key, info);
     return info;
   }
@@ -199,5 +203,28 @@ async function doRenderJob(schema, context) {  // RenderJobExecutor.tsx:77
   };
 }
 
-module.exports = { RM, addon, Scene, CsgScene, Mandelbulb, singleSphere, DEFAULT_MATERIAL, halton, resetHalton, uniformsFromSchema, packUniforms,
+// ---- PNG capture (index.tsx:470-476 canvas.toDataURL): RGBA8, filter 0, rows flipped to top-down ----
+const zlib = require("zlib");
+const CRC_TABLE = (() => { const t = new Uint32Array(256); for (let n = 0; n < 256; n++) { let c = n; for (let k = 0; k < 8; k++) c = c & 1 ? 0xedb88320 ^ (c >>> 1) : c >>> 1; t[n] = c >>> 0; } return t; })();
+function crc32(buf) { let c = 0xffffffff; for (let i = 0; i < buf.length; i++) c = CRC_TABLE[(c ^ buf[i]) & 0xff] ^ (c >>> 8); return (c ^ 0xffffffff) >>> 0; }
+function pngChunk(tag, data) {
+  const out = Buffer.alloc(12 + data.length);
+  out.writeUInt32BE(data.length, 0); out.write(tag, 4, "ascii"); data.copy(out, 8);
+  out.writeUInt32BE(crc32(out.slice(4, 8 + data.length)), 8 + data.length);
+  return out;
+}
+function encodePng(rgba, width, height, bottomUp = true) {
+  if (rgba.length !== width * height * 4) throw new RangeError("encodePng: rgba must hold width * height * 4 bytes");
+  const raw = Buffer.alloc(height * (1 + width * 4));
+  for (let y = 0; y < height; y++) {
+    const src = (bottomUp ? height - 1 - y : y) * width * 4;
+    raw[y * (1 + width * 4)] = 0;
+    Buffer.from(rgba.buffer, rgba.byteOffset + src, width * 4).copy(raw, y * (1 + width * 4) + 1);
+  }
+  const ihdr = Buffer.alloc(13);
+  ihdr.writeUInt32BE(width, 0); ihdr.writeUInt32BE(height, 4); ihdr[8] = 8; ihdr[9] = 6;
+  return Buffer.concat([Buffer.from([0x89, 0x50, 0x4e, 0x47, 0x0d, 0x0a, 0x1a, 0x0a]), pngChunk("IHDR", ihdr), pngChunk("IDAT", zlib.deflateSync(raw)), pngChunk("IEND", Buffer.alloc(0))]);
+}
+
+module.exports = { RM, addon, encodePng, Scene, CsgScene, Mandelbulb, singleSphere, DEFAULT_MATERIAL, halton, resetHalton, uniformsFromSchema, packUniforms,
                    tileRect, RenderJobContext, doRenderJob, U_OFFSET };

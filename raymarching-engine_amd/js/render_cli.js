@@ -14,6 +14,12 @@ const rm = require("./index.js");
               sampleYieldInterval: 2, blendMode: "additive", renderMode: "full" },
     lights: [{ type: "point", position: [2, 3, -4], color: [255 * 3 / 256, 255 * 3 / 256, 255 * 3 / 256], size: 0 }],
   };
+  if (mode === "png") {  // no GPU needed: the PNG writer on a synthetic image
+    const w = 5, h = 3, px = new Uint8Array(w * h * 4);
+    for (let i = 0; i < px.length; i++) px[i] = (i * 37 + 11) & 255;
+    fs.writeFileSync(out, rm.encodePng(px, w, h));
+    return;
+  }
   if (mode === "layout") {  // no GPU needed: the uniform block bytes and the scene description
     const u = rm.uniformsFromSchema(schema, [0.5, 1 / 3]);
     const d = schema.sdfScene.desc();
@@ -29,6 +35,7 @@ const rm = require("./index.js");
   for (;;) { const it = gen.next(); if (it.done) { res = it.value; break; } }
   const fb = ctx.fboCreate(64, 32, 1);
   fs.writeFileSync(out, Buffer.from(fb.download(0).buffer));
+  fs.writeFileSync(out + ".png", rm.encodePng(fb.present(3), 64, 32));  // what canvas.toDataURL would hold
   const bad = await rm.doRenderJob(Object.assign({}, schema, { sdfScene: new rm.CsgScene().smoothUnion(-1).sphere([0, 0, 0], 1).sphere([1, 0, 0], 1) }), ctx);
   const badRes = bad(() => {}).next().value;
   process.stdout.write(JSON.stringify({ res, seen, badRes }));

@@ -170,6 +170,25 @@ static napi_value FbDownload(napi_env env, napi_callback_info info) {
   return nullptr;
 }
 
+// present(ctx, fb, samples, out: Uint8Array(width * height * 4)): display.frag on the GPU, RGBA8, row 0 = bottom
+static napi_value Present(napi_env env, napi_callback_info info) {
+  size_t argc = 4;
+  napi_value argv[4];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  rm_ctx* ctx = get_external<rm_ctx>(env, argv[0]);
+  rm_fb* fb = get_external<rm_fb>(env, argv[1]);
+  int32_t samples = 1;
+  napi_get_value_int32(env, argv[2], &samples);
+  void* d = nullptr;
+  size_t n = 0;
+  if (!ctx || !fb || !get_buffer(env, argv[3], &d, &n)) {
+    napi_throw_type_error(env, nullptr, "present(ctx, fb, samples, out: Uint8Array)");
+    return nullptr;
+  }
+  if (rm_present(ctx, fb, samples, static_cast<uint8_t*>(d)) != RM_OK) return throw_rm(env, ctx, "rm_present");
+  return nullptr;
+}
+
 // renderSample(ctx, scene, fb, uniforms: ArrayBuffer(sizeof RmUniforms), tile: Int32Array(4) | null, flags)
 static napi_value RenderSample(napi_env env, napi_callback_info info) {
   size_t argc = 6;
@@ -214,7 +233,7 @@ static napi_value Sizes(napi_env env, napi_callback_info) {
 static napi_value Init(napi_env env, napi_value exports) {
   const struct { const char* name; napi_callback fn; } fns[] = {
       {"ctxCreate", CtxCreate}, {"ctxDestroy", CtxDestroy}, {"sync", Sync}, {"sceneCreate", SceneCreate}, {"sceneDestroy", SceneDestroy},
-      {"fbCreate", FbCreate}, {"fbClear", FbClear}, {"fbDestroy", FbDestroy}, {"fbDownload", FbDownload}, {"renderSample", RenderSample},
+      {"fbCreate", FbCreate}, {"fbClear", FbClear}, {"fbDestroy", FbDestroy}, {"fbDownload", FbDownload}, {"present", Present}, {"renderSample", RenderSample},
       {"sizes", Sizes}};
   for (const auto& f : fns) {
     napi_value fn;

@@ -10,6 +10,9 @@ Bars:
     (a last-bit difference at a silhouette or a branch pick is a different
     pixel), plus bit-exact invariances at full size.
 """
+import os
+import tempfile
+
 import numpy as np
 import pytest
 
@@ -386,8 +389,12 @@ def test_present_pass(ctx, name):
     for want in (O.present(z["color"], z["normal_dof"], int(z["samples"])), z["rgba8"]):
         d = np.abs(got.astype(int) - want.astype(int))
         assert d.max() <= 1 and np.mean(d == 0) >= 0.99
+    from raymarching_engine_amd import capture, native
+
+    path = os.path.join(tempfile.mkdtemp(), "frame.png")  # the capture of index.tsx:470-476
+    capture.save_png(fb, int(z["samples"]), path)
+    assert (capture.decode_png(open(path, "rb").read()) == got[::-1]).all()
     fb.destroy()
-    from raymarching_engine_amd import native
 
     win = ctx.create_framebuffer(w, h, 8, 8)
     with pytest.raises(native.RmError):

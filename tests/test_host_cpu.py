@@ -165,3 +165,34 @@ def test_oracle_flop_counter_matches_survey_order_of_magnitude():
     flops = O.render(sc, J.uniforms_from_schema(schema, (0.5, 1 / 3)), fr, count_flops=True)
     per_px = flops / (32 * 16)
     assert 5e3 < per_px < 3e5
+
+
+def test_png_capture_round_trip_and_container():
+    """capture.encode_png (the canvas.toDataURL of index.tsx:470-476): valid container
+    (signature, IHDR, CRCs), rows flipped from GL order to top-down, lossless."""
+    import base64
+    import struct
+    import zlib
+
+    from raymarching_engine_amd import capture
+
+    rng = np.random.default_rng(7)
+    for h, w in ((1, 1), (3, 5), (32, 64), (17, 301)):
+        img = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        png = capture.encode_png(img)
+        assert png[:8] == b"\x89PNG\r\n\x1a\n" and png[12:16] == b"IHDR" and png[-8:-4] == b"IEND"
+        assert struct.unpack(">IIBBBBB", png[16:29]) == (w, h, 8, 6, 0, 0, 0)
+        assert struct.unpack(">I", png[29:33])[0] == zlib.crc32(png[12:29]) & 0xFFFFFFFF
+        back = capture.decode_png(png)
+        assert (back == img[::-1]).all()  # PNG row 0 is the TOP row of the GL image
+        assert (capture.decode_png(capture.encode_png(img, bottom_up=False)) == img).all()
+        url = capture.to_data_url(img)
+        assert url.startswith("data:image/png;base64,") and base64.b64decode(url.split(",", 1)[1]) == png
+    with pytest.raises(ValueError):
+        capture.encode_png(np.zeros((4, 4, 3), np.uint8))
+    with pytest.raises(ValueError):
+        capture.decode_png(b"not a png at all")
+    bad = bytearray(capture.encode_png(np.zeros((2, 2, 4), np.uint8)))
+    bad[20] ^= 1
+    with pytest.raises(ValueError):
+        capture.decode_png(bytes(bad))

@@ -46,6 +46,18 @@ def test_js_layouts_match_the_c_abi():
     assert out["halton3"] == [next(g), next(g), next(g)]
 
 
+def test_js_png_writer(tmp_path):
+    """encodePng of the JS host writes the same picture as the Python writer reads: same
+    container rules (RGBA8, filter 0, rows flipped to top-down)."""
+    from raymarching_engine_amd import capture
+
+    out = tmp_path / "t.png"
+    subprocess.run(["node", str(JS / "render_cli.js"), str(out), "png"], check=True, timeout=60)
+    w, h = 5, 3
+    px = ((np.arange(w * h * 4) * 37 + 11) & 255).astype(np.uint8).reshape(h, w, 4)
+    assert (capture.decode_png(out.read_bytes()) == px[::-1]).all()
+
+
 def test_js_addon_fails_loudly_without_gpu():
     r = subprocess.run(["node", "-e", "try{require('%s').ctxCreate(0);console.log('ok')}catch(e){console.log(e.message)}" % (JS / "rm_napi.node")],
                        capture_output=True, text=True)
@@ -75,3 +87,11 @@ def test_js_do_render_job_matches_oracle(tmp_path):
         d = np.abs(got - fr.color) / np.maximum(1, np.abs(fr.color))
     d[np.isnan(got) & np.isnan(fr.color)] = 0
     assert np.mean(~(d.max(-1) <= 1e-5)) <= 0.01
+    # the captured PNG = the present pass of that frame (display.frag), rows top-down
+    from raymarching_engine_amd import capture
+
+    shown = capture.decode_png((tmp_path / "c.f32.png").read_bytes())[::-1]
+    planes = np.fromfile(out, np.float32).reshape(32, 64, 4)
+    want = O.present(planes, None, 3)  # dof amount 0: no blur, so the colour plane alone decides
+    dd = np.abs(shown.astype(int) - want.astype(int))
+    assert dd.max() <= 1 and np.mean(dd == 0) >= 0.99
