@@ -8,7 +8,7 @@ from raymarching_engine_amd import abi, job as J, native, scene as S
 ctx = native.Context(0)
 sc = S.Mandelbulb(); h = ctx.create_scene(sc)
 W, H = 3840, 2160
-schema = J.make_schema(sc, W, H, counts=(256,), render_mode="full", position=(0, 0, -1.6), lights=GC.LIGHT, fov=float(os.environ.get("FOV", "0.5")))
+schema = J.make_schema(sc, W, H, counts=(256,), render_mode="full", position=(0, 0, float(os.environ.get("CAMZ", "-2.5"))), lights=GC.LIGHT, fov=float(os.environ.get("FOV", "0.35")))
 fb = ctx.create_framebuffer(W, H)
 u = J.uniforms_from_schema(schema, (0.5, 1 / 3))
 ctx.render_timed(h, fb, u, 1, None, 1)
