@@ -4,4 +4,5 @@
 #include <type_traits>
 #include "rm_device.hpp"
 #include "rm_kernels.inc"
+#include "rm_stream.inc"
 #include "rm_wavefront.inc"
