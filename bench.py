@@ -105,7 +105,6 @@ def main():
     ap.add_argument("--strict", action="store_true", help="parity build instead of the fast build")
     ap.add_argument("--megakernel", action="store_true", help="force the one-thread-one-pixel kernel (default: the library picks per job)")
     ap.add_argument("--wavefront", action="store_true", help="force the wavefront pipeline")
-    ap.add_argument("--stream", action="store_true", help="force the persistent lane-refilling kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="consecutive samples that may overlap on one GPU (rm_ctx_set_samples_in_flight); default: 1 on one GPU, "
@@ -143,8 +142,6 @@ def main():
         flags |= abi.RM_RENDER_MEGAKERNEL
     if args.wavefront:
         flags |= abi.RM_RENDER_WAVEFRONT
-    if args.stream:
-        flags |= abi.RM_RENDER_STREAM
 
     ctx = native.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # launches ordered with torch / RCCL work

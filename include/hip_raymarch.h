@@ -179,8 +179,6 @@ enum {
                                 large full-mode frames of costly scenes in the strict build.  Same results either way. */
   RM_RENDER_NO_COST_CLASSES = 8, /* wavefront march in one pass even for scene kinds whose sdf cost depends on the
                                    point (Mandelbulb); a measurement switch, same results */
-  RM_RENDER_STREAM = 64,     /* force the persistent lane-refilling form of the pixel kernel (full mode only;
-                                rm_stream.inc): same results */
   RM_RENDER_NO_OVERLAP = 32  /* this sample runs alone on the context's stream and blends in its own kernel (see
                                 rm_ctx_set_samples_in_flight); for timing one launch.  Same results. */
 };

@@ -55,8 +55,6 @@ struct rm_ctx {
   size_t sp_capacity = 0;  // float4 elements per staged plane
   unsigned int sp_next = 0;
   bool sp_ready = false;
-  unsigned int* stream_counters = nullptr;  // pixel-queue heads of the lane-refilling kernel: one per sample in flight + one
-  int stream_blocks_per_cu = 0;             // 0 = as many workgroups as a CU holds
   std::string error;
 };
 
@@ -135,7 +133,6 @@ int rm_ctx_create(int device, rm_ctx** out) {
   if (const char* v = std::getenv("RM_PASS1_BLOCKS_PER_CU")) { int n = std::atoi(v); if (n >= 1 && n <= 8) ctx->pass1_blocks_per_cu = n; }
   if (const char* v = std::getenv("RM_PASS2_ROUNDS")) { int n = std::atoi(v); if (n >= 1 && n <= 3) ctx->pass2_rounds = n; }
   if (const char* v = std::getenv("RM_REPARK")) { int n = std::atoi(v); if (n >= 0 && n <= 63) ctx->repark = n; }
-  if (const char* v = std::getenv("RM_STREAM_BLOCKS_PER_CU")) { int n = std::atoi(v); if (n >= 0 && n <= 16) ctx->stream_blocks_per_cu = n; }
   if (const char* v = std::getenv("RM_SAMPLES_IN_FLIGHT")) { int n = std::atoi(v); if (n >= 1 && n <= RM_SP_MAX) ctx->samples_in_flight = n; }
   if (const char* v = std::getenv("RM_WF_CLAIMS")) { int n = std::atoi(v); if (n >= 1 && n <= 64) ctx->claims_per_wave = n; }
   if (const char* v = std::getenv("RM_WF_BLOCKS_PER_CU")) { int n = std::atoi(v); if (n >= 1 && n <= 8) ctx->wf_blocks_per_cu = n; }
@@ -159,7 +156,6 @@ void rm_ctx_destroy(rm_ctx* ctx) {
     if (ctx->wf_join[s]) (void)hipEventDestroy(ctx->wf_join[s]);
   }
   if (ctx->wf_fork) (void)hipEventDestroy(ctx->wf_fork);
-  if (ctx->stream_counters) (void)hipFree(ctx->stream_counters);
   for (int s = 0; s < RM_SP_MAX; s++) {
     if (ctx->sp_stream[s]) { (void)hipStreamSynchronize(ctx->sp_stream[s]); (void)hipStreamDestroy(ctx->sp_stream[s]); }
     if (ctx->sp_done[s]) (void)hipEventDestroy(ctx->sp_done[s]);
@@ -655,26 +651,6 @@ static bool prefer_wavefront(const KParams& P, int flags) {
   }
 }
 
-// Which form of the one-kernel pixel program runs: the lane-refilling persistent kernel (rm_stream.inc) or one thread
-// per pixel (rm_kernels.inc).  Same results.
-static bool prefer_stream(const KParams& P, int flags) {
-  if (P.u.renderMode != 0 || !(P.u.reflections > 0.0f)) return false;  // the persistent form implements the full mode
-  if (flags & RM_RENDER_STREAM) return true;
-  if (flags & RM_RENDER_MEGAKERNEL) return false;
-  return false;
-}
-
-static hipError_t launch_pixel_program(rm_ctx* ctx, const KParams& P, int flags, hipStream_t stream, int counter_slot) {
-  const bool fast = (flags & RM_RENDER_FAST) != 0;
-  if (!prefer_stream(P, flags)) return fast ? rm::launch_pixels_fast(P, stream) : rm::launch_pixels_strict(P, stream);
-  hipError_t e;
-  if (!ctx->stream_counters && (e = hipMalloc(reinterpret_cast<void**>(&ctx->stream_counters), sizeof(unsigned int) * RM_STREAM_QUEUES * (RM_SP_MAX + 1))) != hipSuccess) return e;
-  unsigned int* counter = ctx->stream_counters + (size_t)counter_slot * RM_STREAM_QUEUES;
-  if ((e = hipMemsetAsync(counter, 0, sizeof(unsigned int) * RM_STREAM_QUEUES, stream)) != hipSuccess) return e;
-  return fast ? rm::launch_stream_fast(P, counter, ctx->stream_blocks_per_cu, ctx->cu_count, stream)
-              : rm::launch_stream_strict(P, counter, ctx->stream_blocks_per_cu, ctx->cu_count, stream);
-}
-
 // The pixel kernel of one sample on a side stream, staged, and its blend on the context's stream (see rm_ctx).
 static hipError_t launch_pixels_in_flight(rm_ctx* ctx, const KParams& P, int flags) {
   hipError_t e;
@@ -709,7 +685,7 @@ static hipError_t launch_pixels_in_flight(rm_ctx* ctx, const KParams& P, int fla
   hipStream_t side = ctx->sp_stream[slot];
   // the render reads no plane: it only has to wait until the blend that last used this staging buffer is done
   if ((e = hipStreamWaitEvent(side, ctx->sp_free[slot], 0)) != hipSuccess) return e;
-  if ((e = launch_pixel_program(ctx, Q, flags, side, slot)) != hipSuccess) return e;
+  if ((e = (flags & RM_RENDER_FAST) ? rm::launch_pixels_fast(Q, side) : rm::launch_pixels_strict(Q, side)) != hipSuccess) return e;
   if ((e = hipEventRecord(ctx->sp_done[slot], side)) != hipSuccess) return e;
   if ((e = hipStreamWaitEvent(ctx->stream, ctx->sp_done[slot], 0)) != hipSuccess) return e;
   if ((e = rm::launch_combine(Q, ctx->stream)) != hipSuccess) return e;
@@ -722,7 +698,7 @@ static hipError_t launch(rm_ctx* ctx, const KParams& P, int flags) {
   // full mode with at least one bounce: the kernel's only use of the planes is the final blend, which can be split off
   if (ctx->samples_in_flight > 1 && !(flags & RM_RENDER_NO_OVERLAP) && P.u.renderMode == 0 && P.u.reflections > 0.0f)
     return launch_pixels_in_flight(ctx, P, flags);
-  return launch_pixel_program(ctx, P, flags, ctx->stream, RM_SP_MAX);
+  return (flags & RM_RENDER_FAST) ? rm::launch_pixels_fast(P, ctx->stream) : rm::launch_pixels_strict(P, ctx->stream);
 }
 
 int rm_render_sample(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* uniforms, const RmRect* tile, int flags) {

@@ -5,7 +5,6 @@
 #include <type_traits>
 #include "rm_device.hpp"
 #include "rm_kernels.inc"
-#include "rm_stream.inc"
 #include "rm_wavefront.inc"
 
 #ifdef RM_LANE_STATS

@@ -102,9 +102,6 @@ hipError_t launch_present(const float4* color, const float4* normal_dof, int W, 
 hipError_t wf_launch_stage(const WfParams& W, int stage, hipStream_t stream);
 hipError_t launch_pixels_strict(const KParams& P, hipStream_t stream);
 hipError_t launch_pixels_fast(const KParams& P, hipStream_t stream);
-#define RM_STREAM_QUEUES 16  // counter words of the lane-refilling kernel's tile queue (rm_stream.inc)
-hipError_t launch_stream_strict(const KParams& P, unsigned int* counter, int blocks_per_cu, int cus, hipStream_t stream);
-hipError_t launch_stream_fast(const KParams& P, unsigned int* counter, int blocks_per_cu, int cus, hipStream_t stream);
 hipError_t launch_probe_strict(const ProbeParams& P, hipStream_t stream);
 hipError_t launch_probe_fast(const ProbeParams& P, hipStream_t stream);
 hipError_t launch_camera_rng(const RmUniforms& u, int W, int H, int what, int count, float* out, hipStream_t stream);

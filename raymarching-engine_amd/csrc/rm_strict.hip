@@ -4,5 +4,4 @@
 #include <type_traits>
 #include "rm_device.hpp"
 #include "rm_kernels.inc"
-#include "rm_stream.inc"
 #include "rm_wavefront.inc"
