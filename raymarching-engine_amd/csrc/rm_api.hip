@@ -634,21 +634,15 @@ static hipError_t launch_wavefront(rm_ctx* ctx, const KParams& P, int flags) {
 }
 
 // Which implementation of the per-pixel program runs a job (same results either way).
-// Measured on MI355X at the end of round 1 (tools/time_all.py): in the fast build the
-// one-kernel form is as fast or faster everywhere (Mandelbulb 4K lit 4.04 vs 4.02 ms, CSG-64 4096^2
-// 49.2 vs 49.2, sphere 1080p preview 0.11 vs 1.7): once the distance estimators were lean, the
-// pipeline's per-ray state traffic and launch chain cost what its ray compaction saves.  In the
-// strict build, whose evaluations are 5-10x more expensive, compaction still pays on large full-mode
-// frames of costly scenes (Mandelbulb 4K lit 31 vs 38 ms, CSG-64 4096^2 132 vs 164 ms).
+// Measured on MI355X at the end of round 1 (tools/time_all.py): the one-kernel form wins everywhere
+// (Mandelbulb 4K lit 3.11 vs 4.52 ms fast, 26.1 vs 28.3 strict; sphere 1080p preview 0.12 vs 1.4) except on the
+// largest full-mode frames of long primitive tables (CSG-64 4096^2: 50.0 vs 54.1 ms fast, 131 vs 146 strict), where the
+// pipeline's global ray compaction still pays for its per-ray state traffic and launch chain.
 static bool prefer_wavefront(const KParams& P, int flags) {
-  if (flags & RM_RENDER_FAST) return false;
+  (void)flags;
   if (P.u.renderMode == 1) return false;
-  if ((long long)P.tw * (long long)P.th < (1ll << 21)) return false;  // small tiles/shards: one launch beats a launch chain
-  switch (P.scene.kind) {
-    case RM_SCENE_TABLE: return P.scene.nprims >= 16;
-    case RM_SCENE_MANDELBULB: return P.scene.p[RM_P_BULB_ITERATIONS] >= 6.0f;
-    default: return false;
-  }
+  if ((long long)P.tw * (long long)P.th < (1ll << 24)) return false;
+  return P.scene.kind == RM_SCENE_TABLE && P.scene.nprims >= 16;
 }
 
 // The pixel kernel of one sample on a side stream, staged, and its blend on the context's stream (see rm_ctx).

@@ -16,6 +16,8 @@ for wl, sc, kw in (("c3b", S.Mandelbulb(), dict(width=3840, height=2160, counts=
                    ("live", S.SphereGridFractal(), dict(width=1280, height=720, counts=(128, 128, 64, 32, 32), render_mode="full", position=(0, 0, 0))),
                    ("menger", S.MengerSponge(), dict(width=1920, height=1080, counts=(128, 64), render_mode="full", position=(0, 0, -3.0), lights=GC.LIGHT)),
                    ("kifs", S.KifsTree(), dict(width=1920, height=1080, counts=(128, 64), render_mode="full", position=(0, 0, -3.0), lights=GC.LIGHT)),
+                   ("lattice", S.SphereLattice(), dict(width=1920, height=1080, counts=(128, 64), render_mode="full", position=(0, 0, -3.0), lights=GC.LIGHT)),
+                   ("kbox", S.KifsBox(), dict(width=1920, height=1080, counts=(128, 64), render_mode="full", position=(0, 0, -3.0), lights=GC.LIGHT)),
                    ("c4/8", S.csg64(), dict(width=4096, height=512, counts=(128,), render_mode="full", position=(0, 0, -5.0), lights=GC.LIGHT))):
     schema = J.make_schema(sc, **kw); h = ctx.create_scene(sc); fb = ctx.create_framebuffer(kw["width"], kw["height"])
     u = J.uniforms_from_schema(schema, (0.5, 1 / 3))
