@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--megakernel", action="store_true", help="force the one-thread-one-pixel kernel (default: the library picks per job)")
     ap.add_argument("--wavefront", action="store_true", help="force the wavefront pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap-leg", action="store_true",
+                    help="also time the same K steps with 3 samples in flight on this one GPU (reported as `overlap`, never as `value`)")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="consecutive samples that may overlap on one GPU (rm_ctx_set_samples_in_flight); default: 1 on one GPU, "
                          "so that a kernel's duration in a rocprofv3 trace is the time of a step, 3 when the frame is sharded "
@@ -197,6 +199,21 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = W * H * args.steps / elapsed / 1e6
 
+    overlap = None
+    if world == 1 and not force_dist and in_flight == 1 and args.overlap_leg:
+        # for information: the same K steps with consecutive samples overlapping on the device (what a sharded run uses)
+        ctx.set_samples_in_flight(3)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        e1 = time.perf_counter() - t1
+        ctx.set_samples_in_flight(in_flight)
+        overlap = {"samples_in_flight": 3, "value": W * H * args.steps / e1 / 1e6, "ms_per_step": e1 / args.steps * 1e3}
+
     out = None
     if rank == 0:
         # kernel time of this rank's launch, HIP events on the launch stream
@@ -232,7 +249,7 @@ def main():
                        "rows_per_gpu": row_count, "pipeline": "megakernel" if args.megakernel else "wavefront" if args.wavefront else "auto (wavefront)" if (args.workload == "c4" and world == 1) else "auto (megakernel)",
                        "sharding": f"{shard.STRIPE_ROWS}-row stripes round-robin over ranks, colour plane gathered to rank 0 over RCCL every step (overlapped with the next sample's render) and put back in image order" if world > 1 else "none",
                        "planes": "color+normal_dof+albedo_depth fp32, accumulated in place", "samples_in_flight": in_flight},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "overlap": overlap,
         }
     fb.destroy()
     scene.destroy()
