@@ -55,6 +55,18 @@ struct rm_ctx {
   size_t sp_capacity = 0;  // float4 elements per staged plane
   unsigned int sp_next = 0;
   bool sp_ready = false;
+  // Cost-ordered dispatch of the pixel kernel when samples run one at a time: the tiles of a job in the order of their
+  // cost in the previous sample of the same job (same framebuffer window, tile and scene kind), most expensive first.
+  // One set per stream the kernel runs on (the side streams of the samples in flight, and the context's stream): a
+  // launch orders by the costs the previous launch ON ITS STREAM left, so no ordering between streams is needed.
+  struct Lpt {
+    unsigned int* cost = nullptr;
+    unsigned int* order = nullptr;
+    int capacity = 0;   // tiles the buffers hold
+    long long key[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // the job the costs belong to
+    bool have_cost = false;
+  } lpt[RM_SP_MAX + 1];
+  bool lpt_enabled = true;
   std::string error;
 };
 
@@ -133,6 +145,7 @@ int rm_ctx_create(int device, rm_ctx** out) {
   if (const char* v = std::getenv("RM_PASS1_BLOCKS_PER_CU")) { int n = std::atoi(v); if (n >= 1 && n <= 8) ctx->pass1_blocks_per_cu = n; }
   if (const char* v = std::getenv("RM_PASS2_ROUNDS")) { int n = std::atoi(v); if (n >= 1 && n <= 3) ctx->pass2_rounds = n; }
   if (const char* v = std::getenv("RM_REPARK")) { int n = std::atoi(v); if (n >= 0 && n <= 63) ctx->repark = n; }
+  if (const char* v = std::getenv("RM_COST_ORDER")) ctx->lpt_enabled = std::atoi(v) != 0;
   if (const char* v = std::getenv("RM_SAMPLES_IN_FLIGHT")) { int n = std::atoi(v); if (n >= 1 && n <= RM_SP_MAX) ctx->samples_in_flight = n; }
   if (const char* v = std::getenv("RM_WF_CLAIMS")) { int n = std::atoi(v); if (n >= 1 && n <= 64) ctx->claims_per_wave = n; }
   if (const char* v = std::getenv("RM_WF_BLOCKS_PER_CU")) { int n = std::atoi(v); if (n >= 1 && n <= 8) ctx->wf_blocks_per_cu = n; }
@@ -156,6 +169,10 @@ void rm_ctx_destroy(rm_ctx* ctx) {
     if (ctx->wf_join[s]) (void)hipEventDestroy(ctx->wf_join[s]);
   }
   if (ctx->wf_fork) (void)hipEventDestroy(ctx->wf_fork);
+  for (auto& l : ctx->lpt) {
+    if (l.cost) (void)hipFree(l.cost);
+    if (l.order) (void)hipFree(l.order);
+  }
   for (int s = 0; s < RM_SP_MAX; s++) {
     if (ctx->sp_stream[s]) { (void)hipStreamSynchronize(ctx->sp_stream[s]); (void)hipStreamDestroy(ctx->sp_stream[s]); }
     if (ctx->sp_done[s]) (void)hipEventDestroy(ctx->sp_done[s]);
@@ -474,6 +491,8 @@ static int build_params(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniform
   P->retire_eps = (flags & RM_RENDER_FAST) ? ctx->retire_eps : 0.0f;
   P->stage = nullptr;
   P->stage_stride = 0;
+  P->block_order = nullptr;
+  P->block_cost = nullptr;
   return RM_OK;
 }
 
@@ -645,6 +664,8 @@ static bool prefer_wavefront(const KParams& P, int flags) {
   return P.scene.kind == RM_SCENE_TABLE && P.scene.nprims >= 16;
 }
 
+static hipError_t launch_pixels_ordered(rm_ctx* ctx, const KParams& P, int flags, hipStream_t stream, int slot);
+
 // The pixel kernel of one sample on a side stream, staged, and its blend on the context's stream (see rm_ctx).
 static hipError_t launch_pixels_in_flight(rm_ctx* ctx, const KParams& P, int flags) {
   hipError_t e;
@@ -679,11 +700,50 @@ static hipError_t launch_pixels_in_flight(rm_ctx* ctx, const KParams& P, int fla
   hipStream_t side = ctx->sp_stream[slot];
   // the render reads no plane: it only has to wait until the blend that last used this staging buffer is done
   if ((e = hipStreamWaitEvent(side, ctx->sp_free[slot], 0)) != hipSuccess) return e;
-  if ((e = (flags & RM_RENDER_FAST) ? rm::launch_pixels_fast(Q, side) : rm::launch_pixels_strict(Q, side)) != hipSuccess) return e;
+  if ((e = launch_pixels_ordered(ctx, Q, flags, side, slot)) != hipSuccess) return e;
   if ((e = hipEventRecord(ctx->sp_done[slot], side)) != hipSuccess) return e;
   if ((e = hipStreamWaitEvent(ctx->stream, ctx->sp_done[slot], 0)) != hipSuccess) return e;
   if ((e = rm::launch_combine(Q, ctx->stream)) != hipSuccess) return e;
   return hipEventRecord(ctx->sp_free[slot], ctx->stream);
+}
+
+// The pixel kernel on `stream`, its tiles in the order of their cost in the previous launch of the same job on that stream
+// (slot = which of the context's streams: a sample-in-flight slot, or RM_SP_MAX for the context's own stream).
+static hipError_t launch_pixels_ordered(rm_ctx* ctx, const KParams& P, int flags, hipStream_t stream, int slot) {
+  const bool fast = (flags & RM_RENDER_FAST) != 0;
+  int gx = 0, gy = 0;
+  rm::pixel_grid(P, &gx, &gy);
+  const long long tiles = (long long)gx * gy;
+  if (!ctx->lpt_enabled || tiles < 512 || tiles > (1ll << 22))  // small jobs end on launch latency, not on a tail
+    return fast ? rm::launch_pixels_fast(P, stream) : rm::launch_pixels_strict(P, stream);
+  rm_ctx::Lpt& L = ctx->lpt[slot];
+  hipError_t e;
+  const long long key[8] = {P.W, P.H, ((long long)P.tx << 32) | (unsigned int)P.ty, ((long long)P.tw << 32) | (unsigned int)P.th,
+                            ((long long)P.stripe_rows << 40) | ((long long)P.parts << 20) | P.part, P.row_begin,
+                            ((long long)P.scene.kind << 8) | P.u.renderMode, tiles};
+  if (L.capacity < tiles) {
+    if (L.cost) { (void)hipStreamSynchronize(stream); (void)hipFree(L.cost); (void)hipFree(L.order); }
+    L.cost = L.order = nullptr;
+    L.capacity = 0;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&L.cost), sizeof(unsigned int) * (size_t)tiles)) != hipSuccess) return e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&L.order), sizeof(unsigned int) * (size_t)tiles)) != hipSuccess) return e;
+    L.capacity = (int)tiles;
+    L.have_cost = false;
+  }
+  if (std::memcmp(key, L.key, sizeof key) != 0) {
+    std::memcpy(L.key, key, sizeof key);
+    L.have_cost = false;
+  }
+  KParams Q = P;
+  Q.block_cost = L.cost;
+  if (L.have_cost) {
+    if ((e = rm::launch_order(L.cost, L.order, (int)tiles, stream)) != hipSuccess) return e;
+    Q.block_order = L.order;
+  } else {
+    if ((e = hipMemsetAsync(L.cost, 0, sizeof(unsigned int) * (size_t)tiles, stream)) != hipSuccess) return e;
+  }
+  L.have_cost = true;
+  return fast ? rm::launch_pixels_fast(Q, stream) : rm::launch_pixels_strict(Q, stream);
 }
 
 static hipError_t launch(rm_ctx* ctx, const KParams& P, int flags) {
@@ -692,7 +752,7 @@ static hipError_t launch(rm_ctx* ctx, const KParams& P, int flags) {
   // full mode with at least one bounce: the kernel's only use of the planes is the final blend, which can be split off
   if (ctx->samples_in_flight > 1 && !(flags & RM_RENDER_NO_OVERLAP) && P.u.renderMode == 0 && P.u.reflections > 0.0f)
     return launch_pixels_in_flight(ctx, P, flags);
-  return (flags & RM_RENDER_FAST) ? rm::launch_pixels_fast(P, ctx->stream) : rm::launch_pixels_strict(P, ctx->stream);
+  return launch_pixels_ordered(ctx, P, flags, ctx->stream, RM_SP_MAX);
 }
 
 int rm_render_sample(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* uniforms, const RmRect* tile, int flags) {

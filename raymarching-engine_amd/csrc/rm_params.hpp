@@ -34,6 +34,10 @@ struct KParams {
   // rm_combine_kernel applies the blend afterwards, in sample order.  nullptr = blend in the kernel.
   float4* stage;
   long long stage_stride;  // elements between the three staged planes
+  // Cost-ordered dispatch (pixel kernel): workgroup b of the launch renders tile block_order[b], and every workgroup
+  // leaves its duration in block_cost[tile] for the next sample's order (rm_order_kernel).  nullptr = in launch order.
+  const unsigned int* block_order;
+  unsigned int* block_cost;
 };
 
 // image row of a local (plane) row
@@ -95,6 +99,8 @@ struct WfParams {
 hipError_t wf_launch_march_strict(const WfParams& W, bool preview, int pass, int blocks, hipStream_t stream);
 hipError_t wf_launch_march_fast(const WfParams& W, bool preview, int pass, int blocks, hipStream_t stream);
 hipError_t launch_combine(const KParams& P, hipStream_t stream);
+hipError_t launch_order(unsigned int* cost, unsigned int* order, int n, hipStream_t stream);
+void pixel_grid(const KParams& P, int* gx, int* gy);  // workgroup grid the pixel kernel uses for this job
 hipError_t wf_launch_shade_strict(const WfParams& W, hipStream_t stream);
 hipError_t wf_launch_shade_fast(const WfParams& W, hipStream_t stream);
 bool wf_kind_has_cost_classes(int kind);
