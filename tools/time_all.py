@@ -16,7 +16,7 @@ print(f"{'workload':58s} {'fast wf':>10s} {'fast mk':>10s} {'strict wf':>10s} {'
 for name, sc, kw in W:
     schema = J.make_schema(sc, **kw); h = ctx.create_scene(sc); fb = ctx.create_framebuffer(kw["width"], kw["height"])
     u = J.uniforms_from_schema(schema, (0.5, 1 / 3)); row = []
-    for flags in (1 | 16, 1 | 4, 0 | 16, 0 | 4):  # fast/strict x forced wavefront/megakernel
+    for flags in (1 | 16 | 32, 1 | 4 | 32, 0 | 16 | 32, 0 | 4 | 32):  # fast/strict x forced wavefront/pixel kernel, one sample at a time
         heavy = "csg64" in name and not (flags & 1)
         ctx.render_timed(h, fb, u, 1, None, flags)
         row.append(min(ctx.render_timed(h, fb, u, 1 if heavy else 3, None, flags) for _ in range(1 if heavy else 2)))
