@@ -206,6 +206,11 @@ int rm_ctx_set_stream(rm_ctx* ctx, void* hip_stream);
  * there afterwards sees the sample blended.  The planes receive the same bits as without overlap.  Costs 3 planes
  * of staging per sample in flight. */
 int rm_ctx_set_samples_in_flight(rm_ctx* ctx, int n);
+/* Cost-ordered dispatch (default on; environment RM_COST_ORDER=0 turns it off).  From the second sample of a job on
+ * (same framebuffer window, tile and scene kind, >= 512 workgroups), the pixel kernel starts its tiles in the order of
+ * their cost in the previous sample, most expensive first, so that a launch does not end on a few late, long
+ * workgroups.  Scheduling only: the planes receive the same bits. */
+int rm_ctx_set_cost_order(rm_ctx* ctx, int on);
 /* RM_RENDER_FAST only, opt-in: a marching lane counts as settled once its step
  * |d| <= eps * max(1, |p|_inf).  The default is 0: only the exact test
  * (position bitwise unchanged), which is what RM_RENDER_STRICT always uses.

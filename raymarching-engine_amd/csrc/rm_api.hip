@@ -203,6 +203,13 @@ int rm_ctx_set_samples_in_flight(rm_ctx* ctx, int n) {
   return RM_OK;
 }
 
+int rm_ctx_set_cost_order(rm_ctx* ctx, int on) {
+  if (!ctx) return RM_ERR_INVALID;
+  ctx->lpt_enabled = on != 0;
+  for (auto& l : ctx->lpt) l.have_cost = false;
+  return RM_OK;
+}
+
 int rm_ctx_set_retire_eps(rm_ctx* ctx, float eps) {
   if (!ctx) return RM_ERR_INVALID;
   if (!(eps >= 0.0f && eps <= 1e-3f)) return fail(ctx, RM_ERR_INVALID, "rm_ctx_set_retire_eps: eps must be in [0, 1e-3]");

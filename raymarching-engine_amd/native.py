@@ -22,7 +22,7 @@ LIB_PATH = Path(os.environ.get("RM_LIB") or Path(__file__).resolve().parent / "l
 # every symbol include/hip_raymarch.h declares
 EXPORTS = [
     "rm_abi_version", "rm_material_default", "rm_ctx_create", "rm_ctx_destroy", "rm_last_error", "rm_ctx_set_stream",
-    "rm_ctx_set_retire_eps", "rm_ctx_set_samples_in_flight", "rm_debug_counters", "rm_sync", "rm_scene_create", "rm_scene_destroy", "rm_fb_create", "rm_fb_create_striped", "rm_fb_rows", "rm_fb_wrap", "rm_fb_clear", "rm_fb_destroy",
+    "rm_ctx_set_retire_eps", "rm_ctx_set_samples_in_flight", "rm_ctx_set_cost_order", "rm_debug_counters", "rm_sync", "rm_scene_create", "rm_scene_destroy", "rm_fb_create", "rm_fb_create_striped", "rm_fb_rows", "rm_fb_wrap", "rm_fb_clear", "rm_fb_destroy",
     "rm_fb_download", "rm_fb_upload", "rm_fb_device_ptr", "rm_render_sample", "rm_render_samples", "rm_render_timed",
     "rm_probe", "rm_probe_camera", "rm_probe_rng", "rm_present", "rm_present_planes",
 ]
@@ -56,6 +56,7 @@ def load_library():
         "rm_ctx_set_stream": (ip, [vp, vp]),
         "rm_ctx_set_retire_eps": (ip, [vp, C.c_float]),
         "rm_ctx_set_samples_in_flight": (ip, [vp, C.c_int]),
+        "rm_ctx_set_cost_order": (ip, [vp, C.c_int]),
         "rm_debug_counters": (ip, [vp, C.POINTER(C.c_ulonglong), ip]),
         "rm_sync": (ip, [vp]),
         "rm_scene_create": (ip, [vp, C.POINTER(abi.RmSceneDesc), C.POINTER(vp)]),
@@ -123,6 +124,10 @@ class Context:
     def set_samples_in_flight(self, n: int):
         """Consecutive full-mode samples that may overlap on the GPU (1 = none); the planes get the same bits."""
         self._check(self.lib.rm_ctx_set_samples_in_flight(self.h, int(n)))
+
+    def set_cost_order(self, on: bool):
+        """Start the tiles of a job most-expensive-first by their cost in the previous sample (scheduling only)."""
+        self._check(self.lib.rm_ctx_set_cost_order(self.h, 1 if on else 0))
 
     def set_retire_eps(self, eps: float):
         self._check(self.lib.rm_ctx_set_retire_eps(self.h, float(eps)))

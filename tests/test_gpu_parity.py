@@ -516,3 +516,37 @@ def test_fast_build_keeps_the_brightness_of_lit_pixels(ctx):
         assert mean_ratio() > 1.03
     finally:
         ctx.set_retire_eps(0.0)
+
+
+@pytest.mark.parametrize("scene", ["bulb", "csg64"])
+def test_cost_ordered_dispatch_leaves_the_same_bits(ctx, scene):
+    """From the second sample of a job on, the pixel kernel starts its tiles
+    most-expensive-first (rm_ctx_set_cost_order; >= 512 workgroups).  That only
+    reorders workgroups: all planes equal the launch-order render bit for bit, one
+    sample at a time and with samples in flight, in both builds."""
+    if scene == "bulb":
+        sc = S.Mandelbulb()
+        schema = J.make_schema(sc, 1024, 640, counts=(48,), render_mode="full", position=(0, 0, -2.5), lights=GC.LIGHT)
+    else:
+        sc = S.csg64()
+        schema = J.make_schema(sc, 768, 512, counts=(32, 16), render_mode="full", position=(0, 0, -5.0), lights=GC.SOFT_LIGHT)
+    noises = GC.halton_pairs(5)
+    NO = abi.RM_RENDER_NO_OVERLAP
+    for build in (STRICT, FAST):
+        ctx.set_cost_order(False)
+        try:
+            plain = render_gpu(ctx, sc, schema, noises, build | MK | NO)
+        finally:
+            ctx.set_cost_order(True)
+        for flags in (build | MK | NO, build | MK):
+            got = render_gpu(ctx, sc, schema, noises, flags)
+            for k in range(3):
+                assert same_bits(got[k], plain[k]).all(), f"build {build} flags {flags} plane {k}"
+    # preview mode goes through the same dispatch
+    pschema = J.make_schema(sc, 1024, 640, counts=(48,), render_mode="preview", position=(0, 0, -2.5 if scene == "bulb" else -5.0))
+    ctx.set_cost_order(False)
+    try:
+        plain = render_gpu(ctx, sc, pschema, noises[:3], FAST | MK)[0]
+    finally:
+        ctx.set_cost_order(True)
+    assert same_bits(render_gpu(ctx, sc, pschema, noises[:3], FAST | MK)[0], plain).all()
