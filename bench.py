@@ -149,7 +149,7 @@ def main():
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # launches ordered with torch / RCCL work
     in_flight = args.in_flight if args.in_flight > 0 else (1 if world == 1 else 3)
     ctx.set_samples_in_flight(in_flight)
-    gatherer = rmdist.FrameGatherer(H, W, world, rank, dev, force=force_dist)
+    gatherer = rmdist.FrameGatherer(H, W, world, rank, dev, force=force_dist, ctx=ctx)
     row_count = gatherer.rows
     # planes live in torch memory (padded to the largest shard so that the gather is regular)
     planes = [torch.zeros((gatherer.max_rows, W, 4), dtype=torch.float32, device=dev) for _ in range(3)]

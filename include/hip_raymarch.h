@@ -325,6 +325,15 @@ int rm_probe_camera(rm_ctx* ctx, const RmUniforms* uniforms, int width, int heig
  * out = height*width*count floats, HOST pointer. */
 int rm_probe_rng(rm_ctx* ctx, const RmUniforms* uniforms, int width, int height, int count, float* out);
 
+/* ---- assembling a sharded frame ------------------------------------------ */
+
+/* Puts the planes of a frame that was rendered as `parts` striped windows (rm_fb_create_striped: stripes of
+ * `stripe_rows` rows dealt round-robin) back into image order, in one launch on the context's stream.
+ * src: DEVICE pointer to parts x max_rows x width float4 (the gathered planes, part p at p * max_rows * width;
+ * a part's rows beyond its own count are padding), dst: DEVICE pointer to height x width float4.  What a
+ * multi-GPU host runs on the rank that shows the frame, after the gather (raymarching_engine_amd/dist.py). */
+int rm_assemble_striped(rm_ctx* ctx, const void* src, int parts, int max_rows, int width, int height, int stripe_rows, void* dst);
+
 /* ---- present ----------------------------------------------------------- */
 
 /* The present pass of the reference (display.frag:16-64, driven from

@@ -19,13 +19,16 @@ class FrameGatherer:
     """
 
     def __init__(self, height: int, width: int, world: int, rank: int, device, dst: int = 0, channels: int = 4,
-                 stripe_rows: int = shard.STRIPE_ROWS, force: bool = False):
+                 stripe_rows: int = shard.STRIPE_ROWS, force: bool = False, ctx=None):
         import torch
 
         self.torch = torch
         self.height, self.width, self.world, self.rank, self.dst = height, width, world, rank, dst
         self.stripe_rows = stripe_rows
         self.force = force  # run the collective even with one rank (testing aid)
+        # native.Context: assemble with one launch of rm_assemble_striped on ITS stream (which must be the stream the
+        # collective is ordered with, i.e. torch's current stream); None = torch index_copy_ (the CPU/gloo tests)
+        self.ctx = ctx if channels == 4 else None
         self.counts = shard.row_counts(height, world, stripe_rows)
         self.max_rows = max(self.counts)
         self.rows = self.counts[rank]
@@ -33,7 +36,8 @@ class FrameGatherer:
         self.frame = None
         self.index = None
         if rank == dst:
-            self.recv = [torch.empty((self.max_rows, width, channels), dtype=torch.float32, device=device) for _ in range(world)]
+            self.recv_all = torch.empty((world, self.max_rows, width, channels), dtype=torch.float32, device=device)
+            self.recv = [self.recv_all[p] for p in range(world)]  # gather's output list: views of one buffer
             self.frame = torch.empty((height, width, channels), dtype=torch.float32, device=device)
             self.index = [torch.as_tensor(shard.owned_rows(height, world, p, stripe_rows), device=device) for p in range(world)]
 
@@ -54,8 +58,15 @@ class FrameGatherer:
         work.wait()
         if self.rank != self.dst:
             return None
-        for p in range(self.world):
-            self.frame.index_copy_(0, self.index[p], self.recv[p][: self.counts[p]])
+        return self._assemble()
+
+    def _assemble(self):
+        if self.ctx is not None:
+            self.ctx.assemble_striped(self.recv_all.data_ptr(), self.world, self.max_rows, self.width, self.height, self.stripe_rows,
+                                      self.frame.data_ptr())
+        else:
+            for p in range(self.world):
+                self.frame.index_copy_(0, self.index[p], self.recv[p][: self.counts[p]])
         return self.frame
 
     def gather(self, plane, dist):
@@ -66,6 +77,4 @@ class FrameGatherer:
         dist.gather(plane, self.recv if self.rank == self.dst else None, dst=self.dst)
         if self.rank != self.dst:
             return None
-        for p in range(self.world):
-            self.frame.index_copy_(0, self.index[p], self.recv[p][: self.counts[p]])
-        return self.frame
+        return self._assemble()

@@ -24,7 +24,7 @@ EXPORTS = [
     "rm_abi_version", "rm_material_default", "rm_ctx_create", "rm_ctx_destroy", "rm_last_error", "rm_ctx_set_stream",
     "rm_ctx_set_retire_eps", "rm_ctx_set_samples_in_flight", "rm_ctx_set_cost_order", "rm_debug_counters", "rm_sync", "rm_scene_create", "rm_scene_destroy", "rm_fb_create", "rm_fb_create_striped", "rm_fb_rows", "rm_fb_wrap", "rm_fb_clear", "rm_fb_destroy",
     "rm_fb_download", "rm_fb_upload", "rm_fb_device_ptr", "rm_render_sample", "rm_render_samples", "rm_render_timed",
-    "rm_probe", "rm_probe_camera", "rm_probe_rng", "rm_present", "rm_present_planes",
+    "rm_probe", "rm_probe_camera", "rm_probe_rng", "rm_assemble_striped", "rm_present", "rm_present_planes",
 ]
 
 
@@ -76,6 +76,7 @@ def load_library():
         "rm_probe": (ip, [vp, vp, ip, fp, ip, C.c_float, ip, fp]),
         "rm_probe_camera": (ip, [vp, C.POINTER(abi.RmUniforms), ip, ip, fp]),
         "rm_probe_rng": (ip, [vp, C.POINTER(abi.RmUniforms), ip, ip, ip, fp]),
+        "rm_assemble_striped": (ip, [vp, vp, ip, ip, ip, ip, ip, vp]),
         "rm_present": (ip, [vp, vp, ip, C.POINTER(C.c_uint8)]),
         "rm_present_planes": (ip, [vp, vp, vp, ip, ip, ip, C.POINTER(C.c_uint8)]),
     }
@@ -124,6 +125,10 @@ class Context:
     def set_samples_in_flight(self, n: int):
         """Consecutive full-mode samples that may overlap on the GPU (1 = none); the planes get the same bits."""
         self._check(self.lib.rm_ctx_set_samples_in_flight(self.h, int(n)))
+
+    def assemble_striped(self, src_ptr: int, parts: int, max_rows: int, width: int, height: int, stripe_rows: int, dst_ptr: int):
+        """Gathered striped windows (device pointer, parts x max_rows x width float4) -> the frame in image order."""
+        self._check(self.lib.rm_assemble_striped(self.h, C.c_void_p(src_ptr), parts, max_rows, width, height, stripe_rows, C.c_void_p(dst_ptr)))
 
     def set_cost_order(self, on: bool):
         """Start the tiles of a job most-expensive-first by their cost in the previous sample (scheduling only)."""

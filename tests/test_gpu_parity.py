@@ -550,3 +550,28 @@ def test_cost_ordered_dispatch_leaves_the_same_bits(ctx, scene):
     finally:
         ctx.set_cost_order(True)
     assert same_bits(render_gpu(ctx, sc, pschema, noises[:3], FAST | MK)[0], plain).all()
+
+
+@pytest.mark.parametrize("parts,height", [(1, 40), (2, 50), (3, 77), (8, 2160)])
+def test_assemble_striped_kernel(ctx, parts, height):
+    """rm_assemble_striped (what rank 0 runs after the gather) against shard.assemble:
+    padded windows of every part -> the frame in image order, ragged last stripes."""
+    from raymarching_engine_amd import native, shard
+
+    width = 96
+    rng = np.random.default_rng(parts * 1000 + height)
+    counts = shard.row_counts(height, parts)
+    max_rows = max(counts)
+    pieces = [rng.standard_normal((c, width, 4)).astype(np.float32) for c in counts]
+    padded = np.zeros((parts * max_rows, width, 4), np.float32)
+    for p, a in enumerate(pieces):
+        padded[p * max_rows: p * max_rows + counts[p]] = a
+    src = ctx.create_framebuffer(width, parts * max_rows)  # plane 0 of a framebuffer as plain device memory
+    dst = ctx.create_framebuffer(width, height)
+    src.upload(0, padded)
+    ctx.assemble_striped(src.device_ptr(0), parts, max_rows, width, height, shard.STRIPE_ROWS, dst.device_ptr(0))
+    assert same_bits(dst.download(0), shard.assemble(pieces, height)).all()
+    with pytest.raises(native.RmError):
+        ctx.assemble_striped(src.device_ptr(0), parts, max(counts) - 1, width, height, shard.STRIPE_ROWS, dst.device_ptr(0))
+    src.destroy()
+    dst.destroy()
