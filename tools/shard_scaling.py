@@ -10,11 +10,13 @@ sc = S.Mandelbulb(); h = ctx.create_scene(sc)
 W, H = 3840, 2160
 schema = J.make_schema(sc, W, H, counts=(256,), render_mode="full", position=(0, 0, -2.5), lights=GC.LIGHT)
 u = J.uniforms_from_schema(schema, (0.5, 1 / 3))
+SR = int(sys.argv[1]) if len(sys.argv) > 1 else shard.STRIPE_ROWS
+print("stripe rows", SR)
 full = None
-for n in (1, 2, 4, 8):
+for n in (1, 4, 8):
     times = []
     for r in range(n):
-        fb = ctx.create_striped_framebuffer(W, H, shard.STRIPE_ROWS, n, r)
+        fb = ctx.create_striped_framebuffer(W, H, SR, n, r)
         ctx.render_timed(h, fb, u, 1, None, 1)
         times.append(min(ctx.render_timed(h, fb, u, 3, None, 1) for _ in range(2)))
         fb.destroy()
