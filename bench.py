@@ -27,6 +27,12 @@ import os
 import sys
 import time
 
+# The HIP runtime maps a process's streams onto 4 hardware queues by default; this path uses the context's stream, up to
+# three side streams for the samples in flight, torch's default stream and RCCL's -- with 4 queues two of the side streams
+# share one and their kernels serialise (8-GPU share of the headline frame: 0.59 instead of 0.42 ms per sample).
+# Read by the runtime when it starts, so it has to be in the environment before anything touches the GPU.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -331,8 +331,11 @@ int rm_probe_rng(rm_ctx* ctx, const RmUniforms* uniforms, int width, int height,
  * `stripe_rows` rows dealt round-robin) back into image order, in one launch on the context's stream.
  * src: DEVICE pointer to parts x max_rows x width float4 (the gathered planes, part p at p * max_rows * width;
  * a part's rows beyond its own count are padding), dst: DEVICE pointer to height x width float4.  What a
- * multi-GPU host runs on the rank that shows the frame, after the gather (raymarching_engine_amd/dist.py). */
-int rm_assemble_striped(rm_ctx* ctx, const void* src, int parts, int max_rows, int width, int height, int stripe_rows, void* dst);
+ * multi-GPU host runs on the rank that shows the frame, after the gather (raymarching_engine_amd/dist.py).
+ * hip_stream: the hipStream_t to launch on, NULL = the context's stream (a host that keeps rendering while the
+ * frame is put together gives it a stream of its own, ordered after the gather). */
+int rm_assemble_striped(rm_ctx* ctx, const void* src, int parts, int max_rows, int width, int height, int stripe_rows, void* dst,
+                        void* hip_stream);
 
 /* ---- present ----------------------------------------------------------- */
 

@@ -808,13 +808,15 @@ int rm_render_timed(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* u
 
 // ---- assembling a sharded frame -------------------------------------------------------
 
-int rm_assemble_striped(rm_ctx* ctx, const void* src, int parts, int max_rows, int width, int height, int stripe_rows, void* dst) {
+int rm_assemble_striped(rm_ctx* ctx, const void* src, int parts, int max_rows, int width, int height, int stripe_rows, void* dst,
+                        void* hip_stream) {
   if (!ctx || !src || !dst) return fail(ctx, RM_ERR_INVALID, "rm_assemble_striped: NULL argument");
   if (parts < 1 || width < 1 || height < 1 || stripe_rows < 1) return fail(ctx, RM_ERR_INVALID, "rm_assemble_striped: parts, width, height and stripe_rows must be >= 1");
   if (max_rows < striped_rows_below(height, stripe_rows, parts, 0))  // part 0 holds the most rows
     return fail(ctx, RM_ERR_INVALID, "rm_assemble_striped: max_rows is smaller than the largest part's window");
   RM_HIP(ctx, hipSetDevice(ctx->device));
-  RM_HIP(ctx, rm::launch_assemble(static_cast<const float4*>(src), parts, max_rows, width, height, stripe_rows, static_cast<float4*>(dst), ctx->stream));
+  RM_HIP(ctx, rm::launch_assemble(static_cast<const float4*>(src), parts, max_rows, width, height, stripe_rows, static_cast<float4*>(dst),
+                                  hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream));
   return RM_OK;
 }
 

@@ -29,6 +29,7 @@ class FrameGatherer:
         # native.Context: assemble with one launch of rm_assemble_striped on ITS stream (which must be the stream the
         # collective is ordered with, i.e. torch's current stream); None = torch index_copy_ (the CPU/gloo tests)
         self.ctx = ctx if channels == 4 else None
+        self.aux = None  # GPU runs: the stream the frame is put together on, so that the render stream never waits for it
         self.counts = shard.row_counts(height, world, stripe_rows)
         self.max_rows = max(self.counts)
         self.rows = self.counts[rank]
@@ -47,6 +48,9 @@ class FrameGatherer:
         if self.world == 1 and not self.force:
             return plane[: self.rows]
         snap = plane.clone()
+        if self.rank == self.dst and self.aux is not None:
+            # the receive buffers are reused: the last frame's assembly (on aux) has to be done before they are overwritten
+            self.torch.cuda.current_stream().wait_stream(self.aux)
         work = dist.gather(snap, self.recv if self.rank == self.dst else None, dst=self.dst, async_op=True)
         return (work, snap)
 
@@ -55,15 +59,24 @@ class FrameGatherer:
         if self.world == 1 and not self.force:
             return handle
         work, _snap = handle
-        work.wait()
         if self.rank != self.dst:
+            work.wait()
             return None
+        if self.ctx is not None and self.recv_all.is_cuda:
+            if self.aux is None:
+                self.aux = self.torch.cuda.Stream(priority=0)
+            with self.torch.cuda.stream(self.aux):
+                work.wait()  # aux waits for the collective; the render stream does not
+                _snap.record_stream(self.aux)
+                self._assemble(self.aux.cuda_stream)
+            return self.frame  # ordered on self.aux: consumers wait_stream(gatherer.aux) (see drain in bench.py)
+        work.wait()
         return self._assemble()
 
-    def _assemble(self):
+    def _assemble(self, stream=None):
         if self.ctx is not None:
             self.ctx.assemble_striped(self.recv_all.data_ptr(), self.world, self.max_rows, self.width, self.height, self.stripe_rows,
-                                      self.frame.data_ptr())
+                                      self.frame.data_ptr(), stream)
         else:
             for p in range(self.world):
                 self.frame.index_copy_(0, self.index[p], self.recv[p][: self.counts[p]])

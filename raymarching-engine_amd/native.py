@@ -16,6 +16,10 @@ from .scene import Scene
 
 import os
 
+# more hardware queues than the HIP runtime's default 4, so that the side streams of the samples in flight do not share one
+# (bench.py has the measurement); only effective if set before the runtime starts in this process
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 # RM_LIB selects an experiment build of the SAME library (tools/); default = the in-tree product
 LIB_PATH = Path(os.environ.get("RM_LIB") or Path(__file__).resolve().parent / "libhip_raymarch.so")
 
@@ -76,7 +80,7 @@ def load_library():
         "rm_probe": (ip, [vp, vp, ip, fp, ip, C.c_float, ip, fp]),
         "rm_probe_camera": (ip, [vp, C.POINTER(abi.RmUniforms), ip, ip, fp]),
         "rm_probe_rng": (ip, [vp, C.POINTER(abi.RmUniforms), ip, ip, ip, fp]),
-        "rm_assemble_striped": (ip, [vp, vp, ip, ip, ip, ip, ip, vp]),
+        "rm_assemble_striped": (ip, [vp, vp, ip, ip, ip, ip, ip, vp, vp]),
         "rm_present": (ip, [vp, vp, ip, C.POINTER(C.c_uint8)]),
         "rm_present_planes": (ip, [vp, vp, vp, ip, ip, ip, C.POINTER(C.c_uint8)]),
     }
@@ -126,9 +130,12 @@ class Context:
         """Consecutive full-mode samples that may overlap on the GPU (1 = none); the planes get the same bits."""
         self._check(self.lib.rm_ctx_set_samples_in_flight(self.h, int(n)))
 
-    def assemble_striped(self, src_ptr: int, parts: int, max_rows: int, width: int, height: int, stripe_rows: int, dst_ptr: int):
-        """Gathered striped windows (device pointer, parts x max_rows x width float4) -> the frame in image order."""
-        self._check(self.lib.rm_assemble_striped(self.h, C.c_void_p(src_ptr), parts, max_rows, width, height, stripe_rows, C.c_void_p(dst_ptr)))
+    def assemble_striped(self, src_ptr: int, parts: int, max_rows: int, width: int, height: int, stripe_rows: int, dst_ptr: int,
+                         stream: Optional[int] = None):
+        """Gathered striped windows (device pointer, parts x max_rows x width float4) -> the frame in image order,
+        on `stream` (a hipStream_t as an integer) or the context's stream."""
+        self._check(self.lib.rm_assemble_striped(self.h, C.c_void_p(src_ptr), parts, max_rows, width, height, stripe_rows, C.c_void_p(dst_ptr),
+                                                 C.c_void_p(stream) if stream else None))
 
     def set_cost_order(self, on: bool):
         """Start the tiles of a job most-expensive-first by their cost in the previous sample (scheduling only)."""
