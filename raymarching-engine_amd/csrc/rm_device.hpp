@@ -234,15 +234,15 @@ struct Sdf<RM_SCENE_TABLE> {
     const float4* src = reinterpret_cast<const float4*>(sc.prims);
     for (int i = threadIdx.x; i < sc.nprims * 2; i += blockDim.x) {
       float4 v = src[i];
-      if ((sc.table_flags & RM_TABLE_SPHERES_SMOOTH) && (i & 1)) {  // second half-row of a sphere: size[1] := 1/k
+      if ((sc.table_flags & RM_TABLE_SPHERES_SMOOTH) && (i & 1)) {  // second half-row of a sphere: size[1] := 0.5/k
         const float k = reinterpret_cast<const float*>(sc.prims)[(i >> 1) * 8 + 1];
-        v.z = 1.0f / k;
+        v.z = 0.5f * (1.0f / k);  // the halving is exact: the bits of 0.5f * inv_k computed per evaluation
       }
       lds.rows[i] = v;
     }
   }
   // Fast-policy path for the common table "spheres folded with smooth unions" (BASELINE configs[3]/[4]):
-  // no per-row dispatch, 1/k read from the row (a sphere does not use size[1]; stage() puts 1/k there),
+  // no per-row dispatch, 0.5/k read from the row (a sphere does not use size[1]; stage() puts it there),
   // two rows per trip so that the LDS reads of the next rows are in flight during the arithmetic.
   static RM_DEV float sphere_row(const float4 a, const float4 b, v3 p) {
     const v3 q = p - V(a.z, a.w, b.x);
@@ -251,9 +251,10 @@ struct Sdf<RM_SCENE_TABLE> {
   // (Tried: a per-wave branch around the fold for spheres further than k behind the running distance -- h = 1 there
   // and the fold is the single subtraction di - (di - d), same bits.  The branch per row breaks the two-row software
   // pipeline: CSG-64 4096^2 went from 56 to 65 ms.  Not kept.)
-  static RM_DEV float smooth_row(float d, float di, float k, float inv_k) {
-    const float h = gclamp(FM::fma(0.5f * inv_k, di - d, 0.5f), 0.0f, 1.0f);
-    return FM::fma(h, d - di, di) - k * h * (1.0f - h);
+  static RM_DEV float smooth_row(float d, float di, float k, float half_inv_k) {
+    const float t = di - d;  // d - di is -t exactly (up to the sign of a zero): one subtraction instead of two
+    const float h = gclamp(FM::fma(half_inv_k, t, 0.5f), 0.0f, 1.0f);
+    return FM::fma(h, -t, di) - k * h * (1.0f - h);
   }
   static RM_DEV float eval_spheres_smooth(const DevScene& sc, const SceneLds& lds, v3 p) {
     const int n = sc.nprims;
