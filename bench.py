@@ -2,28 +2,38 @@
 """Headline benchmark: Mpixels/s of the sphere-tracing path on the Mandelbulb
 scene at 3840x2160 (BASELINE.json), one process per GPU.
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 without a launcher (no WORLD_SIZE in the environment): this process starts
+N fresh ranks itself (python -m torch.distributed.run, 127.0.0.1) BEFORE it
+touches a GPU, relays rank 0's JSON line and exits with the children's status;
+it fails loudly when fewer than N GPUs are visible.  Under a launcher
+(WORLD_SIZE set, as the driver does) it is one of the ranks; WORLD_SIZE must
+equal --gpus.
 
 A step = one sample of every pixel of the frame (one run of the reference's
-main() per pixel: RenderJobExecutor.tsx:299) + the frame assembly on rank 0.
-With N GPUs the frame's rows are sharded in 8-row stripes dealt round-robin
-(no exchange between samples; each pixel depends only on itself, SURVEY.md
-8(e)) and the colour plane is gathered to rank 0 over RCCL once per step and
-put back in image order, as the reference presents once per sample in its live
-loop (index.tsx:158-169).  Total work is fixed => strong scaling.
+main() per pixel: RenderJobExecutor.tsx:299) + presenting it: with N GPUs the
+frame's rows are sharded in 8-row stripes dealt round-robin (no exchange between
+samples; each pixel depends only on itself); every rank
+tone-maps its stripes (display.frag with depth of field off, rm_present_rows)
+and the RGBA8 rows are gathered to rank 0 over RCCL once per step and put back
+in image order, as the reference presents once per sample in its live loop
+(index.tsx:158-169).  Total work is fixed => strong scaling.
 
 Rank 0 prints ONE JSON line.  `roofline` is the fp32-VALU roofline of the
 pixel kernel (the path has no contraction, so no MFMA; HBM traffic is ~100 B
 per ~2e4 flops): achieved = algorithmic flops per launch / HIP-event kernel
-time.  `cpu_baseline` is the oracle (the CPU restatement, kind "port") on the
-host cores over a bounded sample of the same frame.
+time, the flops instrumented over EVERY row of the frame by the counting oracle
+(profiles/flops_per_pixel.json, tools/count_flops.py).  `cpu_baseline` is the
+oracle (the CPU restatement, kind "port") on the host cores over an unbiased row
+sample of the same frame.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -32,6 +42,7 @@ import time
 # share one and their kernels serialise (8-GPU share of the headline frame: 0.59 instead of 0.42 ms per sample).
 # Read by the runtime when it starts, so it has to be in the environment before anything touches the GPU.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -53,6 +64,7 @@ WORKLOADS = {
     "c5": dict(name="C5 csg64 8192x8192 full [128,64,64] soft light", scene="csg64", width=8192, height=8192, counts=(128, 64, 64),
                mode="full", position=(0.0, 0.0, -5.0), light="soft"),
 }
+NOMINAL_FLOPS_PX = {"c3b": 145.5e3, "c3a": 71.7e3, "c2": 2.2e3, "c4": 403e3, "c5": 817e3}  # SURVEY.md 8(d), fixed-E estimate
 
 
 def make_workload(key):
@@ -67,8 +79,23 @@ def make_workload(key):
     return w, sc, schema
 
 
+def instrumented_flops(key, rows_held):
+    """Algorithmic flops of ONE launch over the image rows `rows_held` (an array of row indices), and per pixel of
+    the whole frame, from the committed count of the reference algorithm (profiles/flops_per_pixel.json)."""
+    path = os.path.join(ROOT, "profiles", "flops_per_pixel.json")
+    try:
+        e = json.load(open(path))[key]
+    except Exception:
+        return None, None, None
+    W = e["width"]
+    if e["row_stride"] == 1:  # every row counted: price exactly the rows this launch renders
+        per_row = e["flops_per_row"]
+        return float(sum(per_row[int(r)] for r in rows_held)), e["flops_per_pixel_sample"], e
+    return e["flops_per_pixel_sample"] * len(rows_held) * W, e["flops_per_pixel_sample"], e
+
+
 def cpu_baseline(sc, schema, target_seconds=12.0):
-    """The oracle on the host cores over evenly spaced rows of the same frame."""
+    """The oracle on the host cores over rows spaced evenly over the WHOLE frame (every k-th row: an unbiased sample)."""
     from oracle import oracle as O
     from raymarching_engine_amd import job as J
 
@@ -78,40 +105,67 @@ def cpu_baseline(sc, schema, target_seconds=12.0):
     u = J.uniforms_from_schema(schema, (0.5, 1.0 / 3.0))
     cores = O.host_cores()
 
-    # one row per thread-chunk is too fine for OpenMP-over-rows: render bands of `cores` rows
-    def run_bands(starts, band, count=False):
-        t0 = time.perf_counter()
-        flops = 0
-        for y in starts:
-            fr = O.Frame(W, H, y, band)
-            flops += O.render(sc, u, fr, threads=cores, count_flops=count)
-        return time.perf_counter() - t0, flops
+    def rows_for(n):
+        k = max(1, H // n)
+        return list(range(k // 2, H, k))
 
-    band = max(1, cores)
-    probe_starts = [int((H - band) * f) for f in (0.1, 0.5, 0.9)]
-    t_probe, _ = run_bands(probe_starts, band)
-    per_band = max(t_probe / len(probe_starts), 1e-4)
-    n = int(max(4, min((H // band), target_seconds / per_band)))
-    starts = [int((H - band) * (i + 0.5) / n) for i in range(n)]
-    t, _ = run_bands(starts, band)
-    px = n * band * W
-    # instrumented algorithmic flops per pixel-sample on a thinner sample of the same rows
-    _, flops = run_bands(starts[:: max(1, n // 12)], band, count=True)
-    flops_px = flops / (len(starts[:: max(1, n // 12)]) * band * W)
+    # probe: about one row per core, spread over the frame, to size the timed sample
+    probe = rows_for(max(8, min(H, cores)))
+    t0 = time.perf_counter()
+    O.render_rows(sc, u, W, H, probe, threads=cores)
+    per_row = max((time.perf_counter() - t0) / len(probe), 1e-6)
+    n = int(max(len(probe), min(H, target_seconds / per_row)))
+    rows = rows_for(n)
+    t0 = time.perf_counter()
+    O.render_rows(sc, u, W, H, rows, threads=cores)
+    t = time.perf_counter() - t0
+    px = len(rows) * W
     return {"value": px / t / 1e6, "unit": "Mpixels/s", "cores": cores, "kind": "port",
-            "sample": f"{n} bands of {band} rows evenly spaced over the {W}x{H} frame ({px} pixel-samples, {t:.1f} s), oracle/rm_oracle.c with OpenMP"}, flops_px
+            "sample": f"every {max(1, H // n)}th row of the {W}x{H} frame ({len(rows)} rows, {px} pixel-samples, {t:.1f} s), "
+                      "oracle/rm_oracle.c with OpenMP over the rows"}
+
+
+def self_launch(args):
+    """--gpus N > 1 with no launcher: start N fresh ranks before this process touches a GPU."""
+    import socket
+
+    import torch  # importing torch and counting devices does not initialise the GPU
+
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.exit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0:
+        sys.exit(f"bench.py --gpus {args.gpus}: the ranks exited with status {proc.returncode}")
+    if line is None or json.loads(line).get("n_gpus") != args.gpus:
+        sys.exit(f"bench.py --gpus {args.gpus}: rank 0 did not report n_gpus = {args.gpus}")
+    print(line, flush=True)
+    sys.exit(0)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c3b", choices=list(WORKLOADS))
+    ap.add_argument("--rows", default="", help="render only image rows A:B of the frame (e.g. one shard of C4/C5 on one GPU)")
     ap.add_argument("--strict", action="store_true", help="parity build instead of the fast build")
     ap.add_argument("--megakernel", action="store_true", help="force the one-thread-one-pixel kernel (default: the library picks per job)")
     ap.add_argument("--wavefront", action="store_true", help="force the wavefront pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--payload", default="rgba8", choices=["rgba8", "f32"], help="what a sharded run gathers: the tone-mapped rows or the fp32 colour plane")
     ap.add_argument("--overlap-leg", action="store_true",
                     help="also time the same K steps with 3 samples in flight on this one GPU (reported as `overlap`, never as `value`)")
     ap.add_argument("--in-flight", type=int, default=0,
@@ -120,16 +174,25 @@ def main():
                          "(a shard's launch is too small to fill the chip: a ray is a ~1 ms serial chain)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE); they must agree")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
     import numpy as np
     import torch
 
     from raymarching_engine_amd import abi, dist as rmdist, job as J, native, shard
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the product has no CPU path")
+    if torch.cuda.device_count() <= local_rank:
+        sys.exit(f"bench.py: rank {rank} wants GPU {local_rank} but only {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -142,6 +205,7 @@ def main():
             for key, val in (("MASTER_PORT", "29511"), ("RANK", "0"), ("WORLD_SIZE", "1")):
                 os.environ.setdefault(key, val)
         dist.init_process_group("nccl", device_id=dev)
+    sharded = world > 1 or force_dist
 
     wl, sc, schema = make_workload(args.workload)
     W, H = wl["width"], wl["height"]
@@ -152,10 +216,25 @@ def main():
         flags |= abi.RM_RENDER_WAVEFRONT
 
     ctx = native.Context(local_rank)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # launches ordered with torch / RCCL work
+    # One stream for the renders, the torch ops on the planes and the point RCCL orders its collectives after.  Not torch's
+    # default stream: its handle is NULL, which rm_ctx_set_stream reads as "the context's own stream" -- and that one is
+    # non-blocking, i.e. NOT ordered with the NULL stream.
+    render_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(render_stream)
+    ctx.set_stream(render_stream.cuda_stream)
     in_flight = args.in_flight if args.in_flight > 0 else (1 if world == 1 else 3)
     ctx.set_samples_in_flight(in_flight)
-    gatherer = rmdist.FrameGatherer(H, W, world, rank, dev, force=force_dist, ctx=ctx)
+    tile = None
+    rows_window = None
+    if args.rows:
+        if sharded:
+            sys.exit("bench.py: --rows is a one-GPU option")
+        a, b = (int(v) for v in args.rows.split(":"))
+        rows_window = (a, b)
+        tile = abi.RmRect(0, a, W, b - a)
+    # the tone-mapped rows can only be gathered when depth of field is off (the blur of display.frag reads neighbour rows)
+    payload = args.payload if schema["dof"]["amount"] == 0.0 else "f32"
+    gatherer = rmdist.FrameGatherer(H, W, world, rank, dev, force=force_dist, ctx=ctx, payload=payload)
     row_count = gatherer.rows
     # planes live in torch memory (padded to the largest shard so that the gather is regular)
     planes = [torch.zeros((gatherer.max_rows, W, 4), dtype=torch.float32, device=dev) for _ in range(3)]
@@ -164,24 +243,25 @@ def main():
     scene = ctx.create_scene(sc)
 
     h2, h3 = J.halton(2), J.halton(3)
-
-    pending = [None]
     u_step = J.uniforms_from_schema(schema, (0.5, 1.0 / 3.0))  # only randNoise changes from sample to sample
+    samples = [0]
 
     def step():
-        # render sample n, then start the gather of its (snapshotted) colour plane; the gather runs over
-        # RCCL while sample n+1 renders, and frame n is assembled on rank 0 at the start of step n+1
+        # render sample n, then start the gather of its presented rows (a snapshot); the gather runs over RCCL
+        # while sample n+1 renders, and frame n is assembled on rank 0 at the start of step n+1
         u_step.randNoise[0], u_step.randNoise[1] = next(h2), next(h3)
-        ctx.render_sample(scene, fb, u_step, None, flags)
-        if world > 1 or force_dist:
-            if pending[0] is not None:
-                gatherer.finish(pending[0])
-            pending[0] = gatherer.start(planes[0], dist)
+        ctx.render_sample(scene, fb, u_step, tile, flags)
+        samples[0] += 1
+        if sharded:
+            if gatherer.pending is not None:
+                gatherer.finish()
+            gatherer.start(planes[0], dist, fb=fb, samples=samples[0])
 
     def drain():
-        if (world > 1 or force_dist) and pending[0] is not None:
-            gatherer.finish(pending[0])
-            pending[0] = None
+        if sharded and gatherer.pending is not None:
+            gatherer.finish()
+        if sharded and gatherer.aux is not None:
+            torch.cuda.current_stream().wait_stream(gatherer.aux)  # the last frame is assembled before the clock stops
 
     for _ in range(args.warmup):
         step()
@@ -202,8 +282,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    px_frame = W * H if rows_window is None else W * (rows_window[1] - rows_window[0])
     ms_per_step = elapsed / args.steps * 1e3
-    value = W * H * args.steps / elapsed / 1e6
+    value = px_frame * args.steps / elapsed / 1e6
 
     overlap = None
     if world == 1 and not force_dist and in_flight == 1 and args.overlap_leg:
@@ -218,53 +299,74 @@ def main():
         torch.cuda.synchronize()
         e1 = time.perf_counter() - t1
         ctx.set_samples_in_flight(in_flight)
-        overlap = {"samples_in_flight": 3, "value": W * H * args.steps / e1 / 1e6, "ms_per_step": e1 / args.steps * 1e3}
+        overlap = {"samples_in_flight": 3, "value": px_frame * args.steps / e1 / 1e6, "ms_per_step": e1 / args.steps * 1e3}
 
     out = None
     if rank == 0:
         # kernel time of this rank's launch, HIP events on the launch stream
         u = J.uniforms_from_schema(schema, (0.5, 1.0 / 3.0))
-        kernel_ms = ctx.render_timed(scene, fb, u, max(3, min(args.steps, 10)), None, flags | abi.RM_RENDER_NO_OVERLAP)
-        cpu, flops_px = (None, None)
+        n_timed = max(3, min(args.steps, 20))
+        ctx.render_timed(scene, fb, u, 2, tile, flags | abi.RM_RENDER_NO_OVERLAP)  # let the cost order of this job settle
+        kernel_ms = ctx.render_timed(scene, fb, u, n_timed, tile, flags | abi.RM_RENDER_NO_OVERLAP)
+        rows_held = shard.owned_rows(H, world, rank) if rows_window is None else np.arange(rows_window[0], rows_window[1])
+        px_launch = len(rows_held) * W
+        flops_launch, flops_px, fixture = instrumented_flops(args.workload, rows_held)
+        cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu, flops_px = cpu_baseline(sc, schema)
-        nominal_px = {"c3b": 145.5e3, "c3a": 71.7e3, "c2": 2.2e3, "c4": 403e3, "c5": 817e3}[args.workload]
-        px_launch = row_count * W
+            cpu = cpu_baseline(sc, schema)
+        nominal_px = NOMINAL_FLOPS_PX[args.workload]
         roof = None
-        traffic = None
-        try:  # measured in a separate rocprofv3 --pmc run (profiles/r01_traffic.json says how)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if args.workload == "c3b" and not args.strict:
-                traffic = (tj["hbm_bytes_per_frame"] if args.wavefront else tj["megakernel_hbm_bytes_per_frame"]) * px_launch / (3840 * 2160)
+        # measured in separate rocprofv3 --pmc runs of this command (profiles/*_counters.json says how and from which file)
+        traffic = executed = counters_file = None
+        try:
+            cj = json.load(open(os.path.join(ROOT, "profiles", "r02_counters.json")))
+            ent = cj.get(args.workload + ("_strict" if args.strict else "_fast"))
+            if ent and not args.wavefront and rows_window is None:
+                traffic = ent["hbm_bytes_per_frame"] * px_launch / (W * H)
+                executed = ent["executed_lane_flops_per_frame"] * px_launch / (W * H)
+                counters_file = ent["profile"]
         except Exception:
             pass
-        if flops_px is not None:
-            achieved = flops_px * px_launch / (kernel_ms * 1e-3) / 1e12
+        if flops_launch is not None:
+            sec = kernel_ms * 1e-3
+            achieved = flops_launch / sec / 1e12
             roof = {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,
+                    "frac_nominal": nominal_px * px_launch / sec / 1e12 / PEAK_FP32_VALU_TFLOPS,
+                    "frac_executed": executed / sec / 1e12 / PEAK_FP32_VALU_TFLOPS if executed else None,
                     "flops_per_pixel_sample_instrumented": flops_px, "flops_per_pixel_sample_nominal": nominal_px,
-                    "frac_nominal": nominal_px * px_launch / (kernel_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
-                    "kernel_ms": kernel_ms, "pixels_per_launch": px_launch,
-                    "hbm_algorithmic_GBs": 96.0 * px_launch / (kernel_ms * 1e-3) / 1e9, "hbm_peak_GBs": PEAK_HBM_GBS}
+                    "flops_per_launch_instrumented": flops_launch,
+                    "flops_source": f"profiles/flops_per_pixel.json[{args.workload}] (every {fixture['row_stride']} row(s) of the whole frame; tools/count_flops.py)",
+                    "executed_source": counters_file,
+                    "kernel_ms": kernel_ms, "kernel_launches_timed": n_timed, "pixels_per_launch": px_launch,
+                    "hbm_algorithmic_GBs": 96.0 * px_launch / sec / 1e9, "hbm_peak_GBs": PEAK_HBM_GBS}
+        auto = "auto (wavefront)" if (args.workload in ("c4", "c5") and world == 1 and rows_window is None and _prefers_wavefront(args.workload)) else "auto (megakernel)"
         out = {
             "metric": "Mpixels/sec at 3840x2160 Mandelbulb" if args.workload in ("c3b", "c3a") else "Mpixels/sec",
             "value": value, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["name"], "build": "strict" if args.strict else "fast",
-                       "rows_per_gpu": row_count, "pipeline": "megakernel" if args.megakernel else "wavefront" if args.wavefront else "auto (wavefront)" if (args.workload == "c4" and world == 1) else "auto (megakernel)",
-                       "sharding": f"{shard.STRIPE_ROWS}-row stripes round-robin over ranks, colour plane gathered to rank 0 over RCCL every step (overlapped with the next sample's render) and put back in image order" if world > 1 else "none",
+                       "rows_per_gpu": row_count if rows_window is None else rows_window[1] - rows_window[0],
+                       "pipeline": "megakernel" if args.megakernel else "wavefront" if args.wavefront else auto,
+                       "sharding": (f"{shard.STRIPE_ROWS}-row stripes round-robin over ranks; every step each rank tone-maps its rows "
+                                    f"and the {payload} rows are gathered to rank 0 over RCCL (overlapped with the next sample's render) and put back in image order")
+                       if sharded else "none",
                        "planes": "color+normal_dof+albedo_depth fp32, accumulated in place", "samples_in_flight": in_flight},
             "roofline": roof, "cpu_baseline": cpu, "overlap": overlap,
         }
     fb.destroy()
     scene.destroy()
     ctx.close()
-    if world > 1 or force_dist:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:
         print(json.dumps(out), flush=True)
+
+
+def _prefers_wavefront(workload):
+    return False  # the library's default dispatch is the pixel kernel for every workload (rm_api.hip prefer_wavefront)
 
 
 if __name__ == "__main__":

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RM_ABI_VERSION 1
+#define RM_ABI_VERSION 2
 
 #define RM_MAX_BOUNCES 10 /* raymarchingStepCountsArray[10], raymarcher.frag:31 */
 #define RM_MAX_LIGHTS 10  /* lightPositions[10],             raymarcher.frag:37-39 */
@@ -196,7 +196,11 @@ void rm_ctx_destroy(rm_ctx* ctx);
  * errors of rm_ctx_create itself.  Replaces ShaderError.infoLog. */
 const char* rm_last_error(const rm_ctx* ctx);
 /* Use an externally owned hipStream_t (e.g. torch's current stream) for all
- * later launches; NULL restores the context's own stream. */
+ * later launches; NULL restores the context's own stream.  The switch is
+ * ordered on the device (an event, no host wait): work this library queued on
+ * the old stream -- the zeroing of rm_fb_create / rm_fb_clear, uploads,
+ * renders -- completes before anything enqueued on the new stream after the
+ * call.  The old stream must still exist when this is called. */
 int rm_ctx_set_stream(rm_ctx* ctx, void* hip_stream);
 /* Samples in flight (default 3, 1 = off; environment RM_SAMPLES_IN_FLIGHT).  The reference submits its draw calls
  * back to back (RenderJobExecutor.tsx:240-260) and the GPU overlaps them; here a full-mode sample of the pixel
@@ -261,8 +265,10 @@ int rm_fb_create(rm_ctx* ctx, int width, int height, int row_begin, int row_coun
  * library allocate them.  Pixel coordinates stay global as in rm_fb_create. */
 int rm_fb_create_striped(rm_ctx* ctx, int width, int height, int stripe_rows, int parts, int part,
                          void* color, void* normal_dof, void* albedo_depth, rm_fb** out);
-/* Number of image rows a framebuffer holds. */
+/* Number of image rows a framebuffer holds; width / height of the image it is a window of. */
 int rm_fb_rows(const rm_fb* fb);
+int rm_fb_width(const rm_fb* fb);
+int rm_fb_height(const rm_fb* fb);
 /* Same, but over caller-owned device memory (e.g. torch tensors): each plane
  * pointer addresses row_count*width float4; normal_dof/albedo_depth may be
  * NULL (then only RM_RENDER_COLOR_ONLY renders are accepted). */
@@ -336,6 +342,10 @@ int rm_probe_rng(rm_ctx* ctx, const RmUniforms* uniforms, int width, int height,
  * frame is put together gives it a stream of its own, ordered after the gather). */
 int rm_assemble_striped(rm_ctx* ctx, const void* src, int parts, int max_rows, int width, int height, int stripe_rows, void* dst,
                         void* hip_stream);
+/* The same for rows of `row_bytes` opaque bytes (a multiple of 4; buffers 16-byte aligned): RGBA8 rows after the
+ * per-rank present (rm_present_rows, row_bytes = 4 * width), or any other per-pixel payload. */
+int rm_assemble_striped_bytes(rm_ctx* ctx, const void* src, int parts, int max_rows, long long row_bytes, int height, int stripe_rows,
+                              void* dst, void* hip_stream);
 
 /* ---- present ----------------------------------------------------------- */
 
@@ -349,6 +359,17 @@ int rm_assemble_striped(rm_ctx* ctx, const void* src, int parts, int max_rows, i
  * normal_dof may be NULL = no blur). */
 int rm_present(rm_ctx* ctx, rm_fb* fb, int samples, uint8_t* out_rgba8);
 int rm_present_planes(rm_ctx* ctx, const void* color, const void* normal_dof, int width, int height, int samples, uint8_t* out_rgba8);
+/* The same pass left on the device and asynchronous: out_rgba8_device = height*width*4 bytes of DEVICE memory,
+ * launched on hip_stream (NULL = the context's stream); no allocation, no host wait.  For a host that shows the
+ * frame from device memory or reads it back itself (index.tsx:25-59 draws straight to the canvas). */
+int rm_present_device(rm_ctx* ctx, const void* color, const void* normal_dof, int width, int height, int samples,
+                      void* out_rgba8_device, void* hip_stream);
+/* The present pass of the rows ONE framebuffer window holds, for jobs without depth of field (dof.amount = 0: the
+ * blur radius of display.frag:24-27 is 0 and its only tap is the pixel itself, so no neighbour row is needed and
+ * the bytes equal rm_present's).  out_rgba8_device = rm_fb_rows(fb)*width*4 bytes of DEVICE memory, in the
+ * window's own row order.  This is what a sharded run gathers instead of the fp32 colour plane: a quarter of the
+ * bytes (raymarching_engine_amd/dist.py); rm_assemble_striped_bytes puts the stripes in image order. */
+int rm_present_rows(rm_ctx* ctx, rm_fb* fb, int samples, void* out_rgba8_device, void* hip_stream);
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,10 @@ def build(force: bool = False) -> None:
     subprocess.run(["make", "-C", str(_HERE), "-s", "-B"], check=True)
 
 
+# idle OpenMP threads sleep instead of spinning (read by libgomp when it is loaded): the hosts this runs on are shared
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
+
 def _lib(count: bool = False):
     key = bool(count)
     if key not in _libs:
@@ -37,6 +41,8 @@ def _lib(count: bool = False):
         fp = C.POINTER(C.c_float)
         lib.or_render.restype = C.c_uint64
         lib.or_render.argtypes = [C.POINTER(abi.RmSceneDesc), C.POINTER(abi.RmUniforms)] + [C.c_int] * 8 + [fp, fp, fp, C.c_int]
+        lib.or_render_rows.restype = C.c_uint64
+        lib.or_render_rows.argtypes = [C.POINTER(abi.RmSceneDesc), C.POINTER(abi.RmUniforms), C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, fp, C.c_int]
         lib.or_eval_sdf.argtypes = [C.POINTER(abi.RmSceneDesc), fp, C.c_int, fp]
         lib.or_cast_ray.argtypes = [C.POINTER(abi.RmSceneDesc), fp, C.c_int, C.c_float, fp]
         lib.or_normal.argtypes = [C.POINTER(abi.RmSceneDesc), fp, C.c_int, C.c_float, fp]
@@ -89,6 +95,18 @@ def render(scene, uniforms: abi.RmUniforms, frame: Frame, tile=None, threads: in
     x, y, w, h = tile if tile is not None else (0, 0, frame.width, frame.height)
     return lib.or_render(C.byref(desc), C.byref(uniforms), frame.width, frame.height, frame.row_begin, frame.row_count,
                          x, y, w, h, _fp(frame.color), _fp(frame.normal_dof), _fp(frame.albedo_depth), threads)
+
+
+def render_rows(scene, uniforms: abi.RmUniforms, width: int, height: int, rows, threads: int = 1, nan_mode: int = NAN_IEEE,
+                count_flops: bool = False):
+    """One sample of the listed image rows (colour only).  Returns (flops, colour[len(rows), width, 4])."""
+    lib = _lib(count_flops)
+    lib.or_set_nan_mode(nan_mode)
+    desc = scene.desc()
+    r = np.ascontiguousarray(rows, np.int32)
+    out = np.zeros((len(r), width, 4), np.float32)
+    flops = lib.or_render_rows(C.byref(desc), C.byref(uniforms), width, height, r.ctypes.data_as(C.POINTER(C.c_int)), len(r), _fp(out), threads)
+    return int(flops), out
 
 
 def eval_sdf(scene, points: np.ndarray, nan_mode: int = NAN_IEEE) -> np.ndarray:

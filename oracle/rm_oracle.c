@@ -669,6 +669,27 @@ uint64_t or_render(const RmSceneDesc* sc, const RmUniforms* u, int W, int H, int
   return total;
 }
 
+/* One sample of a LIST of image rows (an unbiased row sample of a large frame: bench.py's cpu_baseline and
+ * tools/count_flops.py): row rows[i] of the W x H image goes to row i of the n x W colour plane (zeroed by the
+ * caller).  OpenMP over the list.  Returns the flop count like or_render. */
+uint64_t or_render_rows(const RmSceneDesc* sc, const RmUniforms* u, int W, int H, const int* rows, int n, float* color, int threads) {
+  uint64_t total = 0;
+  (void)threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : 1) reduction(+ : total)
+#endif
+  for (int i = 0; i < n; i++) {
+#ifdef OR_COUNT_FLOPS
+    or_flops = 0;
+#endif
+    for (int x = 0; x < W; x++) pixel_main(sc, u, W, H, x, rows[i], color + ((size_t)i * (size_t)W + (size_t)x) * 4, NULL, NULL);
+#ifdef OR_COUNT_FLOPS
+    total += or_flops;
+#endif
+  }
+  return total;
+}
+
 void or_eval_sdf(const RmSceneDesc* sc, const float* p, int n, float* out) {
   for (int i = 0; i < n; i++) out[i] = scene_sdf(sc, V(p[3 * i], p[3 * i + 1], p[3 * i + 2]));
 }

@@ -67,6 +67,9 @@ struct rm_ctx {
     bool have_cost = false;
   } lpt[RM_SP_MAX + 1];
   bool lpt_enabled = true;
+  hipEvent_t switch_ev = nullptr;  // orders the old stream before the new one in rm_ctx_set_stream
+  uchar4* present_buf = nullptr;   // device staging of rm_present / rm_present_planes, grown on demand
+  size_t present_cap = 0;          // pixels
   std::string error;
 };
 
@@ -134,7 +137,8 @@ int rm_ctx_create(int device, rm_ctx** out) {
   if (!ctx) return fail(nullptr, RM_ERR_DEVICE, "out of host memory");
   ctx->device = device;
   if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess ||
-      (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess) {
+      (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&ctx->switch_ev, hipEventDisableTiming)) != hipSuccess) {
     std::string msg = std::string("rm_ctx_create: ") + hipGetErrorString(e);
     delete ctx;
     return fail(nullptr, RM_ERR_DEVICE, msg);
@@ -179,6 +183,8 @@ void rm_ctx_destroy(rm_ctx* ctx) {
     if (ctx->sp_free[s]) (void)hipEventDestroy(ctx->sp_free[s]);
     if (ctx->sp_stage[s]) (void)hipFree(ctx->sp_stage[s]);
   }
+  if (ctx->present_buf) (void)hipFree(ctx->present_buf);
+  if (ctx->switch_ev) (void)hipEventDestroy(ctx->switch_ev);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -189,9 +195,14 @@ const char* rm_last_error(const rm_ctx* ctx) { return ctx ? ctx->error.c_str() :
 
 int rm_ctx_set_stream(rm_ctx* ctx, void* hip_stream) {
   if (!ctx) return RM_ERR_INVALID;
-  // samples in flight are blended in order on the current stream: let them land before the order moves elsewhere
-  if (ctx->sp_ready) RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  hipStream_t next = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  if (next == ctx->stream) return RM_OK;
+  RM_HIP(ctx, hipSetDevice(ctx->device));
+  // Everything already queued on the old stream (the zeroing of rm_fb_create / rm_fb_clear, uploads, renders, the
+  // blends of samples in flight) is ordered before whatever the caller enqueues on the new one: an event, no host wait.
+  RM_HIP(ctx, hipEventRecord(ctx->switch_ev, ctx->stream));
+  RM_HIP(ctx, hipStreamWaitEvent(next, ctx->switch_ev, 0));
+  ctx->stream = next;
   return RM_OK;
 }
 
@@ -276,6 +287,11 @@ int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out) {
   } else if (desc->kind == RM_SCENE_MANDELBULB) {
     if (!(desc->params[RM_P_BULB_ITERATIONS] >= 0.0f && desc->params[RM_P_BULB_ITERATIONS] <= 64.0f))
       return fail(ctx, RM_ERR_INVALID, "scene: mandelbulb iterations must be in 0..64");
+  } else if (desc->kind == RM_SCENE_SPHERE_GRID || desc->kind == RM_SCENE_MENGER || desc->kind == RM_SCENE_KIFS_TREE ||
+             desc->kind == RM_SCENE_KIFS_BOX) {
+    // one evaluation loops `iterations` times, a sample evaluates ~10^3 times per pixel: an unbounded count is an endless kernel
+    const int slot = desc->kind == RM_SCENE_SPHERE_GRID ? RM_P_GRID_ITERATIONS : desc->kind == RM_SCENE_MENGER ? RM_P_MENGER_ITERATIONS : RM_P_KIFS_ITERATIONS;
+    if (!(desc->params[slot] <= 64.0f)) return fail(ctx, RM_ERR_INVALID, "scene: fractal iterations must be <= 64");
   }
   rm_scene* s = new (std::nothrow) rm_scene();
   if (!s) return fail(ctx, RM_ERR_DEVICE, "out of host memory");
@@ -320,6 +336,8 @@ void rm_scene_destroy(rm_scene* scene) {
 
 static int fb_check(rm_ctx* ctx, int width, int height, int row_begin, int row_count) {
   if (width < 1 || height < 1 || width > 65536 || height > 65536) return fail(ctx, RM_ERR_INVALID, "framebuffer: size must be 1..65536");
+  // ray and tile counts are 32-bit in the kernels' index arithmetic (8x8 tiles round a frame up by < 2 %)
+  if ((long long)width * (long long)height > (1ll << 28)) return fail(ctx, RM_ERR_INVALID, "framebuffer: width x height must be <= 2^28 pixels");
   if (row_begin < 0 || row_count < 1 || row_begin + row_count > height) return fail(ctx, RM_ERR_INVALID, "framebuffer: row window outside the image");
   return RM_OK;
 }
@@ -399,6 +417,8 @@ int rm_fb_create_striped(rm_ctx* ctx, int width, int height, int stripe_rows, in
 }
 
 int rm_fb_rows(const rm_fb* fb) { return fb ? fb->row_count : 0; }
+int rm_fb_width(const rm_fb* fb) { return fb ? fb->width : 0; }
+int rm_fb_height(const rm_fb* fb) { return fb ? fb->height : 0; }
 
 int rm_fb_wrap(rm_ctx* ctx, int width, int height, int row_begin, int row_count, void* color, void* normal_dof,
                void* albedo_depth, rm_fb** out) {
@@ -630,7 +650,13 @@ static hipError_t launch_wavefront(rm_ctx* ctx, const KParams& P, int flags) {
       ctx->ws_list2 = nullptr;
       ctx->ws_rays = 0;
     }
-    if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->ws), sizeof(float4) * (size_t)rm::WF_ARRAYS * total_rays)) != hipSuccess) return e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->ws), sizeof(float4) * (size_t)rm::WF_ARRAYS * total_rays)) != hipSuccess) {
+      char msg[160];
+      std::snprintf(msg, sizeof msg, "wavefront pipeline: cannot allocate its %.1f GB ray workspace (%zu rays x %d B); render in tiles or use RM_RENDER_MEGAKERNEL",
+                    (double)(sizeof(float4) * (size_t)rm::WF_ARRAYS * total_rays) / 1e9, total_rays, (int)(sizeof(float4) * rm::WF_ARRAYS));
+      ctx->error = msg;
+      return e;
+    }
     if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->ws_list), sizeof(unsigned int) * total_rays)) != hipSuccess) return e;
     if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->ws_list2), sizeof(unsigned int) * total_rays)) != hipSuccess) return e;
     ctx->ws_rays = total_rays;
@@ -808,40 +834,72 @@ int rm_render_timed(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* u
 
 // ---- assembling a sharded frame -------------------------------------------------------
 
-int rm_assemble_striped(rm_ctx* ctx, const void* src, int parts, int max_rows, int width, int height, int stripe_rows, void* dst,
-                        void* hip_stream) {
+int rm_assemble_striped_bytes(rm_ctx* ctx, const void* src, int parts, int max_rows, long long row_bytes, int height, int stripe_rows,
+                              void* dst, void* hip_stream) {
   if (!ctx || !src || !dst) return fail(ctx, RM_ERR_INVALID, "rm_assemble_striped: NULL argument");
-  if (parts < 1 || width < 1 || height < 1 || stripe_rows < 1) return fail(ctx, RM_ERR_INVALID, "rm_assemble_striped: parts, width, height and stripe_rows must be >= 1");
+  if (parts < 1 || row_bytes < 4 || (row_bytes & 3) || row_bytes > (1ll << 24) || height < 1 || stripe_rows < 1)
+    return fail(ctx, RM_ERR_INVALID, "rm_assemble_striped: parts, height and stripe_rows must be >= 1, row_bytes a multiple of 4");
   if (max_rows < striped_rows_below(height, stripe_rows, parts, 0))  // part 0 holds the most rows
     return fail(ctx, RM_ERR_INVALID, "rm_assemble_striped: max_rows is smaller than the largest part's window");
+  if ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) return fail(ctx, RM_ERR_INVALID, "rm_assemble_striped: buffers must be 16-byte aligned");
   RM_HIP(ctx, hipSetDevice(ctx->device));
-  RM_HIP(ctx, rm::launch_assemble(static_cast<const float4*>(src), parts, max_rows, width, height, stripe_rows, static_cast<float4*>(dst),
-                                  hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream));
+  RM_HIP(ctx, rm::launch_assemble(src, parts, max_rows, row_bytes, height, stripe_rows, dst, hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream));
   return RM_OK;
 }
 
+int rm_assemble_striped(rm_ctx* ctx, const void* src, int parts, int max_rows, int width, int height, int stripe_rows, void* dst,
+                        void* hip_stream) {
+  if (width < 1) return fail(ctx, RM_ERR_INVALID, "rm_assemble_striped: width must be >= 1");
+  return rm_assemble_striped_bytes(ctx, src, parts, max_rows, (long long)width * 16, height, stripe_rows, dst, hip_stream);
+}
+
 // ---- present ---------------------------------------------------------------------
+
+int rm_present_device(rm_ctx* ctx, const void* color, const void* normal_dof, int width, int height, int samples, void* out_rgba8_device,
+                      void* hip_stream) {
+  if (!ctx || !color || !out_rgba8_device) return fail(ctx, RM_ERR_INVALID, "rm_present_device: NULL argument");
+  if (width < 1 || height < 1 || samples < 1) return fail(ctx, RM_ERR_INVALID, "rm_present_device: width, height and samples must be >= 1");
+  RM_HIP(ctx, hipSetDevice(ctx->device));
+  RM_HIP(ctx, rm::launch_present(static_cast<const float4*>(color), static_cast<const float4*>(normal_dof), width, height, 1.0f / (float)samples,
+                                 static_cast<uchar4*>(out_rgba8_device), hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream));
+  return RM_OK;
+}
+
+int rm_present_rows(rm_ctx* ctx, rm_fb* fb, int samples, void* out_rgba8_device, void* hip_stream) {
+  if (!ctx || !fb || !out_rgba8_device) return fail(ctx, RM_ERR_INVALID, "rm_present_rows: NULL argument");
+  if (fb->ctx != ctx) return fail(ctx, RM_ERR_INVALID, "rm_present_rows: framebuffer belongs to another context");
+  if (samples < 1) return fail(ctx, RM_ERR_INVALID, "rm_present_rows: samples must be >= 1");
+  RM_HIP(ctx, hipSetDevice(ctx->device));
+  RM_HIP(ctx, rm::launch_present_rows(fb->plane[0], (long long)fb->width * (long long)fb->row_count, 1.0f / (float)samples,
+                                      static_cast<uchar4*>(out_rgba8_device), hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream));
+  return RM_OK;
+}
 
 int rm_present_planes(rm_ctx* ctx, const void* color, const void* normal_dof, int width, int height, int samples, uint8_t* out_rgba8) {
   if (!ctx || !color || !out_rgba8) return fail(ctx, RM_ERR_INVALID, "rm_present_planes: NULL argument");
   if (width < 1 || height < 1 || samples < 1) return fail(ctx, RM_ERR_INVALID, "rm_present_planes: width, height and samples must be >= 1");
   RM_HIP(ctx, hipSetDevice(ctx->device));
-  uchar4* d_out = nullptr;
-  const size_t bytes = (size_t)width * (size_t)height * 4;
-  RM_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&d_out), bytes));
-  hipError_t e = rm::launch_present(static_cast<const float4*>(color), static_cast<const float4*>(normal_dof), width, height,
-                                    1.0f / (float)samples, d_out, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(out_rgba8, d_out, bytes, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d_out);
-  if (e != hipSuccess) return fail(ctx, RM_ERR_DEVICE, std::string("rm_present_planes: ") + hipGetErrorString(e));
+  const size_t pixels = (size_t)width * (size_t)height;
+  if (ctx->present_cap < pixels) {  // the staging buffer lives with the context: a live loop presents every sample
+    if (ctx->present_buf) {
+      RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      (void)hipFree(ctx->present_buf);
+      ctx->present_buf = nullptr;
+      ctx->present_cap = 0;
+    }
+    RM_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->present_buf), pixels * 4));
+    ctx->present_cap = pixels;
+  }
+  if (int rc = rm_present_device(ctx, color, normal_dof, width, height, samples, ctx->present_buf, nullptr)) return rc;
+  RM_HIP(ctx, hipMemcpyAsync(out_rgba8, ctx->present_buf, pixels * 4, hipMemcpyDeviceToHost, ctx->stream));
+  RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return RM_OK;
 }
 
 int rm_present(rm_ctx* ctx, rm_fb* fb, int samples, uint8_t* out_rgba8) {
   if (!ctx || !fb) return fail(ctx, RM_ERR_INVALID, "rm_present: NULL argument");
   if (fb->stripe_rows > 0 || fb->row_begin != 0 || fb->row_count != fb->height)
-    return fail(ctx, RM_ERR_INVALID, "rm_present: the blur reads neighbouring rows, so it needs the whole frame: gather the planes and use rm_present_planes");
+    return fail(ctx, RM_ERR_INVALID, "rm_present: the blur reads neighbouring rows, so it needs the whole frame: gather the planes and use rm_present_planes (or rm_present_rows when depth of field is off)");
   return rm_present_planes(ctx, fb->plane[0], fb->plane[1], fb->width, fb->height, samples, out_rgba8);
 }
 

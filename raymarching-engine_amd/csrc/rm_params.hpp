@@ -104,7 +104,8 @@ void pixel_grid(const KParams& P, int* gx, int* gy);  // workgroup grid the pixe
 hipError_t wf_launch_shade_strict(const WfParams& W, hipStream_t stream);
 hipError_t wf_launch_shade_fast(const WfParams& W, hipStream_t stream);
 bool wf_kind_has_cost_classes(int kind);
-hipError_t launch_assemble(const float4* src, int parts, int max_rows, int W, int H, int stripe_rows, float4* dst, hipStream_t stream);
+hipError_t launch_assemble(const void* src, int parts, int max_rows, long long row_bytes, int H, int stripe_rows, void* dst, hipStream_t stream);
+hipError_t launch_present_rows(const float4* color, long long pixels, float brightness, uchar4* out, hipStream_t stream);
 hipError_t launch_present(const float4* color, const float4* normal_dof, int W, int H, float brightness, uchar4* out, hipStream_t stream);
 hipError_t wf_launch_stage(const WfParams& W, int stage, hipStream_t stream);
 hipError_t launch_pixels_strict(const KParams& P, hipStream_t stream);

@@ -38,6 +38,12 @@ const rm = require("./index.js");
   fs.writeFileSync(out + ".png", rm.encodePng(fb.present(3), 64, 32));  // what canvas.toDataURL would hold
   const bad = await rm.doRenderJob(Object.assign({}, schema, { sdfScene: new rm.CsgScene().smoothUnion(-1).sphere([0, 0, 0], 1).sphere([1, 0, 0], 1) }), ctx);
   const badRes = bad(() => {}).next().value;
-  process.stdout.write(JSON.stringify({ res, seen, badRes }));
+  // the addon's own argument checks: a short output buffer and a handle of the wrong kind are JS errors, not memory errors
+  const addon = require("./rm_napi.node");
+  const guards = {};
+  try { addon.fbDownload(ctx.ctx, fb.fb, 0, new Float32Array(16)); guards.shortDownload = "no error"; } catch (e) { guards.shortDownload = e.name; }
+  try { addon.present(ctx.ctx, fb.fb, 3, new Uint8Array(16)); guards.shortPresent = "no error"; } catch (e) { guards.shortPresent = e.name; }
+  try { addon.fbDownload(ctx.ctx, ctx.ctx, 0, new Float32Array(64 * 32 * 4)); guards.wrongKind = "no error"; } catch (e) { guards.wrongKind = e.name; }
+  process.stdout.write(JSON.stringify({ res, seen, badRes, guards }));
   ctx.close();
 })().catch((e) => { console.error(e); process.exit(1); });

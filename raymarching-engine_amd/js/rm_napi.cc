@@ -28,11 +28,44 @@ static napi_value throw_rm(napi_env env, rm_ctx* ctx, const char* what) {
   return nullptr;
 }
 
+// Handles travel as externals that carry their kind, so a scene passed where a framebuffer is expected (or a
+// destroyed handle used again) is a TypeError in JS, not a wild pointer in the library.
+enum HandleKind : uint32_t { KIND_CTX = 0x726d6301u, KIND_SCENE = 0x726d7302u, KIND_FB = 0x726d6603u };
+struct Handle {
+  uint32_t kind;
+  void* ptr;
+};
+template <class T> struct KindOf;
+template <> struct KindOf<rm_ctx> { static constexpr uint32_t value = KIND_CTX; };
+template <> struct KindOf<rm_scene> { static constexpr uint32_t value = KIND_SCENE; };
+template <> struct KindOf<rm_fb> { static constexpr uint32_t value = KIND_FB; };
+
+static void finalize_handle(napi_env, void* data, void*) { delete static_cast<Handle*>(data); }
+
 template <class T>
-static T* get_external(napi_env env, napi_value v) {
+static napi_value make_external(napi_env env, T* p) {
+  Handle* h = new Handle{KindOf<T>::value, p};
+  napi_value out;
+  if (napi_create_external(env, h, finalize_handle, nullptr, &out) != napi_ok) {
+    delete h;
+    napi_throw_error(env, nullptr, "N-API call failed: napi_create_external");
+    return nullptr;
+  }
+  return out;
+}
+
+// the handle of kind T, or nullptr (wrong kind, not an external, or already destroyed); take = the caller destroys it
+template <class T>
+static T* get_external(napi_env env, napi_value v, bool take = false) {
   void* p = nullptr;
-  if (napi_get_value_external(env, v, &p) != napi_ok) return nullptr;
-  return static_cast<T*>(p);
+  napi_valuetype t;
+  if (napi_typeof(env, v, &t) != napi_ok || t != napi_external) return nullptr;
+  if (napi_get_value_external(env, v, &p) != napi_ok || !p) return nullptr;
+  Handle* h = static_cast<Handle*>(p);
+  if (h->kind != KindOf<T>::value) return nullptr;
+  T* out = static_cast<T*>(h->ptr);
+  if (take) h->ptr = nullptr;
+  return out;
 }
 
 static bool get_buffer(napi_env env, napi_value v, void** data, size_t* len) {
@@ -59,16 +92,14 @@ static napi_value CtxCreate(napi_env env, napi_callback_info info) {
   if (argc > 0) napi_get_value_int32(env, argv[0], &device);
   rm_ctx* ctx = nullptr;
   if (rm_ctx_create(device, &ctx) != RM_OK) return throw_rm(env, nullptr, "rm_ctx_create");
-  napi_value out;
-  NAPI_OK(napi_create_external(env, ctx, nullptr, nullptr, &out));
-  return out;
+  return make_external(env, ctx);
 }
 
 static napi_value CtxDestroy(napi_env env, napi_callback_info info) {
   size_t argc = 1;
   napi_value argv[1];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
-  rm_ctx_destroy(get_external<rm_ctx>(env, argv[0]));
+  rm_ctx_destroy(get_external<rm_ctx>(env, argv[0], true));
   return nullptr;
 }
 
@@ -107,16 +138,14 @@ static napi_value SceneCreate(napi_env env, napi_callback_info info) {
   }
   rm_scene* scene = nullptr;
   if (rm_scene_create(ctx, &desc, &scene) != RM_OK) return throw_rm(env, ctx, "rm_scene_create");
-  napi_value out;
-  NAPI_OK(napi_create_external(env, scene, nullptr, nullptr, &out));
-  return out;
+  return make_external(env, scene);
 }
 
 static napi_value SceneDestroy(napi_env env, napi_callback_info info) {
   size_t argc = 1;
   napi_value argv[1];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
-  rm_scene_destroy(get_external<rm_scene>(env, argv[0]));
+  rm_scene_destroy(get_external<rm_scene>(env, argv[0], true));
   return nullptr;
 }
 
@@ -130,16 +159,22 @@ static napi_value FbCreate(napi_env env, napi_callback_info info) {
   for (int i = 0; i < 4; i++) napi_get_value_int32(env, argv[1 + i], &v[i]);
   rm_fb* fb = nullptr;
   if (rm_fb_create(ctx, v[0], v[1], v[2], v[3], &fb) != RM_OK) return throw_rm(env, ctx, "rm_fb_create");
-  napi_value out;
-  NAPI_OK(napi_create_external(env, fb, nullptr, nullptr, &out));
-  return out;
+  return make_external(env, fb);
 }
 
 static napi_value FbClear(napi_env env, napi_callback_info info) {
   size_t argc = 1;
   napi_value argv[1];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
-  rm_fb_clear(get_external<rm_fb>(env, argv[0]));
+  rm_fb* fb = get_external<rm_fb>(env, argv[0]);
+  if (!fb) {
+    napi_throw_type_error(env, nullptr, "fbClear(fb): not a framebuffer handle");
+    return nullptr;
+  }
+  if (rm_fb_clear(fb) != RM_OK) {
+    napi_throw_error(env, "RM_ERROR", "rm_fb_clear failed");
+    return nullptr;
+  }
   return nullptr;
 }
 
@@ -147,7 +182,7 @@ static napi_value FbDestroy(napi_env env, napi_callback_info info) {
   size_t argc = 1;
   napi_value argv[1];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
-  rm_fb_destroy(get_external<rm_fb>(env, argv[0]));
+  rm_fb_destroy(get_external<rm_fb>(env, argv[0], true));
   return nullptr;
 }
 
@@ -164,6 +199,11 @@ static napi_value FbDownload(napi_env env, napi_callback_info info) {
   size_t n = 0;
   if (!fb || !get_buffer(env, argv[3], &d, &n)) {
     napi_throw_type_error(env, nullptr, "fbDownload(ctx, fb, plane, out: Float32Array)");
+    return nullptr;
+  }
+  const size_t need = (size_t)rm_fb_rows(fb) * (size_t)rm_fb_width(fb) * 16;
+  if (n < need) {
+    napi_throw_range_error(env, nullptr, "fbDownload: out is smaller than rows * width * 4 floats");
     return nullptr;
   }
   if (rm_fb_download(fb, plane, static_cast<float*>(d)) != RM_OK) return throw_rm(env, ctx, "rm_fb_download");
@@ -185,6 +225,10 @@ static napi_value Present(napi_env env, napi_callback_info info) {
     napi_throw_type_error(env, nullptr, "present(ctx, fb, samples, out: Uint8Array)");
     return nullptr;
   }
+  if (n < (size_t)rm_fb_width(fb) * (size_t)rm_fb_height(fb) * 4) {
+    napi_throw_range_error(env, nullptr, "present: out is smaller than width * height * 4 bytes");
+    return nullptr;
+  }
   if (rm_present(ctx, fb, samples, static_cast<uint8_t*>(d)) != RM_OK) return throw_rm(env, ctx, "rm_present");
   return nullptr;
 }
@@ -199,6 +243,10 @@ static napi_value RenderSample(napi_env env, napi_callback_info info) {
   rm_fb* fb = get_external<rm_fb>(env, argv[2]);
   void* u = nullptr;
   size_t un = 0;
+  if (!ctx || !scene || !fb) {
+    napi_throw_type_error(env, nullptr, "renderSample(ctx, scene, fb, ...): wrong or destroyed handle");
+    return nullptr;
+  }
   if (!get_buffer(env, argv[3], &u, &un) || un != sizeof(RmUniforms)) {
     napi_throw_type_error(env, nullptr, "renderSample: uniforms must be an ArrayBuffer of sizeof(RmUniforms) bytes");
     return nullptr;

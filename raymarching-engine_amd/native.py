@@ -26,9 +26,9 @@ LIB_PATH = Path(os.environ.get("RM_LIB") or Path(__file__).resolve().parent / "l
 # every symbol include/hip_raymarch.h declares
 EXPORTS = [
     "rm_abi_version", "rm_material_default", "rm_ctx_create", "rm_ctx_destroy", "rm_last_error", "rm_ctx_set_stream",
-    "rm_ctx_set_retire_eps", "rm_ctx_set_samples_in_flight", "rm_ctx_set_cost_order", "rm_debug_counters", "rm_sync", "rm_scene_create", "rm_scene_destroy", "rm_fb_create", "rm_fb_create_striped", "rm_fb_rows", "rm_fb_wrap", "rm_fb_clear", "rm_fb_destroy",
+    "rm_ctx_set_retire_eps", "rm_ctx_set_samples_in_flight", "rm_ctx_set_cost_order", "rm_debug_counters", "rm_sync", "rm_scene_create", "rm_scene_destroy", "rm_fb_create", "rm_fb_create_striped", "rm_fb_rows", "rm_fb_width", "rm_fb_height", "rm_fb_wrap", "rm_fb_clear", "rm_fb_destroy",
     "rm_fb_download", "rm_fb_upload", "rm_fb_device_ptr", "rm_render_sample", "rm_render_samples", "rm_render_timed",
-    "rm_probe", "rm_probe_camera", "rm_probe_rng", "rm_assemble_striped", "rm_present", "rm_present_planes",
+    "rm_probe", "rm_probe_camera", "rm_probe_rng", "rm_assemble_striped", "rm_assemble_striped_bytes", "rm_present", "rm_present_planes", "rm_present_device", "rm_present_rows",
 ]
 
 
@@ -41,6 +41,33 @@ class RmError(RuntimeError):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP/HSA runtime per process.  PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64 (same sonames as
+    /opt/rocm's); if this library pulls in /opt/rocm's copies first and torch initialises its own afterwards, the
+    second HSA runtime finds no GPU ("No HIP GPUs are available").  When torch is installed, load ITS runtime first:
+    libhip_raymarch.so then binds to it by soname, whichever of the two is imported first.  Hosts without torch (the
+    Node addon) use /opt/rocm's."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return  # torch's runtime is already in the process
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = Path(list(spec.submodule_search_locations)[0]) / "lib"
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        p = libdir / name
+        if p.exists():
+            try:
+                C.CDLL(str(p), mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def load_library():
     """dlopen the HIP library (loading needs no GPU; creating a context does)."""
     global _lib
@@ -49,6 +76,7 @@ def load_library():
     if not LIB_PATH.exists():
         raise RmError(abi.RM_ERR_DEVICE, f"{LIB_PATH} is missing: build it with `python raymarching-engine_amd/build.py` "
                                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    _share_torch_hip_runtime()
     lib = C.CDLL(str(LIB_PATH))
     vp, fp, ip = C.c_void_p, C.POINTER(C.c_float), C.c_int
     sig = {
@@ -69,6 +97,8 @@ def load_library():
         "rm_fb_wrap": (ip, [vp, ip, ip, ip, ip, vp, vp, vp, C.POINTER(vp)]),
         "rm_fb_create_striped": (ip, [vp, ip, ip, ip, ip, ip, vp, vp, vp, C.POINTER(vp)]),
         "rm_fb_rows": (ip, [vp]),
+        "rm_fb_width": (ip, [vp]),
+        "rm_fb_height": (ip, [vp]),
         "rm_fb_clear": (ip, [vp]),
         "rm_fb_destroy": (None, [vp]),
         "rm_fb_download": (ip, [vp, ip, fp]),
@@ -81,6 +111,9 @@ def load_library():
         "rm_probe_camera": (ip, [vp, C.POINTER(abi.RmUniforms), ip, ip, fp]),
         "rm_probe_rng": (ip, [vp, C.POINTER(abi.RmUniforms), ip, ip, ip, fp]),
         "rm_assemble_striped": (ip, [vp, vp, ip, ip, ip, ip, ip, vp, vp]),
+        "rm_assemble_striped_bytes": (ip, [vp, vp, ip, ip, C.c_longlong, ip, ip, vp, vp]),
+        "rm_present_device": (ip, [vp, vp, vp, ip, ip, ip, vp, vp]),
+        "rm_present_rows": (ip, [vp, vp, ip, vp, vp]),
         "rm_present": (ip, [vp, vp, ip, C.POINTER(C.c_uint8)]),
         "rm_present_planes": (ip, [vp, vp, vp, ip, ip, ip, C.POINTER(C.c_uint8)]),
     }
@@ -124,6 +157,13 @@ class Context:
             self.h = None
 
     def set_stream(self, hip_stream: Optional[int]):
+        """A hipStream_t (as an integer) for all later launches; None = the context's own stream.  torch's DEFAULT
+        stream has the handle 0 (the NULL stream), which cannot be told from None here and with which the context's
+        own non-blocking stream is not ordered: give torch work that shares buffers with the renders a stream of its own
+        (torch.cuda.Stream) and pass that one."""
+        if hip_stream is not None and int(hip_stream) == 0:
+            raise RmError(abi.RM_ERR_INVALID, "set_stream(0): the NULL stream is not supported; use a torch.cuda.Stream() "
+                                              "(or None for the context's own stream)")
         self._check(self.lib.rm_ctx_set_stream(self.h, C.c_void_p(hip_stream or 0)))
 
     def set_samples_in_flight(self, n: int):
@@ -136,6 +176,22 @@ class Context:
         on `stream` (a hipStream_t as an integer) or the context's stream."""
         self._check(self.lib.rm_assemble_striped(self.h, C.c_void_p(src_ptr), parts, max_rows, width, height, stripe_rows, C.c_void_p(dst_ptr),
                                                  C.c_void_p(stream) if stream else None))
+
+    def assemble_striped_bytes(self, src_ptr: int, parts: int, max_rows: int, row_bytes: int, height: int, stripe_rows: int, dst_ptr: int,
+                               stream: Optional[int] = None):
+        """assemble_striped for rows of opaque bytes (RGBA8 after present_rows: row_bytes = 4 * width)."""
+        self._check(self.lib.rm_assemble_striped_bytes(self.h, C.c_void_p(src_ptr), parts, max_rows, int(row_bytes), height, stripe_rows,
+                                                       C.c_void_p(dst_ptr), C.c_void_p(stream) if stream else None))
+
+    def present_device(self, color_ptr: int, normal_dof_ptr: Optional[int], width: int, height: int, samples: int, out_ptr: int,
+                       stream: Optional[int] = None):
+        """display.frag into DEVICE memory (height*width*4 bytes), asynchronous."""
+        self._check(self.lib.rm_present_device(self.h, C.c_void_p(color_ptr), C.c_void_p(normal_dof_ptr or 0), width, height, int(samples),
+                                               C.c_void_p(out_ptr), C.c_void_p(stream) if stream else None))
+
+    def present_rows(self, fb: "Framebuffer", samples: int, out_ptr: int, stream: Optional[int] = None):
+        """Tone-map the rows `fb` holds (no depth of field) into DEVICE memory (rows*width*4 bytes), asynchronous."""
+        self._check(self.lib.rm_present_rows(self.h, fb.h, int(samples), C.c_void_p(out_ptr), C.c_void_p(stream) if stream else None))
 
     def set_cost_order(self, on: bool):
         """Start the tiles of a job most-expensive-first by their cost in the previous sample (scheduling only)."""

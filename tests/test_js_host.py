@@ -72,6 +72,7 @@ def test_js_do_render_job_matches_oracle(tmp_path):
     info = json.loads(r.stdout)
     assert info["res"] == {"success": True} and info["seen"] == [0, 2, 4, 6, 8, 10, 12]  # 4 tiles x 3 samples, yield every 2
     assert info["badRes"]["success"] is False and info["badRes"]["why"]["type"] == "fragment" and "smooth union" in info["badRes"]["why"]["infoLog"]
+    assert info["guards"] == {"shortDownload": "RangeError", "shortPresent": "RangeError", "wrongKind": "TypeError"}
     got = np.fromfile(out, np.float32).reshape(32, 64, 4)
     sc = _scene()
     schema = _schema(sc)
