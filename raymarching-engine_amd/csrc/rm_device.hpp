@@ -104,6 +104,8 @@ RM_DEV bool is_inf(float x) { return fabsf(x) == __builtin_inff(); }
 RM_DEV bool is_nan(float x) { return x != x; }
 RM_DEV bool finite(float x) { return fabsf(x) < __builtin_inff(); }
 RM_DEV bool any_nonfinite(v3 a) { return !finite(a.x) || !finite(a.y) || !finite(a.z); }
+// the wave's mask of a condition, straight from the compare (HIP's __ballot goes through an integer 0/1 and a second compare)
+RM_DEV unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 RM_DEV bool same_bits(v3 a, v3 b) {
   return __float_as_uint(a.x) == __float_as_uint(b.x) && __float_as_uint(a.y) == __float_as_uint(b.y) &&
          __float_as_uint(a.z) == __float_as_uint(b.z);
@@ -131,7 +133,10 @@ RM_DEV float rm_tan(float x) {
   c = c * r2 + 4.166664568298827e-2f;
   c = c * r2 * r2 + (1.0f - 0.5f * r2);
   float odd = k - 2.0f * floorf(k * 0.5f);
-  return (odd > 0.5f) ? (-c / s) : (s / c);
+  // (odd > 0.5f) ? (-c / s) : (s / c) with ONE division: picking the operands first gives the same bits
+  // (an IEEE division is ~12 instructions, and every random number is one tangent)
+  const bool flip = odd > 0.5f;
+  return (flip ? -c : s) / (flip ? s : c);
 }
 
 // ---- RNG: :44-49, :78-105.  distance(xy*PHI, xy) depends on the pixel only,
@@ -192,6 +197,39 @@ RM_DEV v3 sphere_sample(Rng& r) {
   box_muller(r, bx, by);
   return normalize<PM>(V(ax, ay, bx));
 }
+
+// What the stream looks like after uniformSample() / sphereSample() without their values (a value that no
+// live computation reads need not be computed; the seed has to advance by exactly the same additions).
+RM_DEV void rng_skip_uniform(Rng& r) { r.seed += 0.131223f; }
+RM_DEV void rng_skip_sphere(Rng& r) {
+  r.seed += 0.123123213f; r.seed += 0.123123213f; r.seed += 0.123123213f; r.seed += 0.123123213f;
+}
+
+// sphereSample() * scale, exactly, for a `scale` that is usually 0 (dof.amount = 0: :186-193; a point light's size:
+// :359).  With scale == 0 the product is a vector of zeros unless the sample is non-finite, and then it is NaN, which
+// reaches the image (the pixel's ray origin is NaN).  The sample is non-finite exactly when the first uniform of one
+// of its two Box-Muller pairs is 0 (log 0 = -Inf; a gold_noise value is 0 whenever |tan| x 1000 x texcoord.x >= 2^23,
+// about 1e-5 of the draws), so two of the four random numbers decide, and the logarithms, square roots, sines,
+// cosines and the normalisation are only computed for the lanes that need them.  The signs of the zeros are not
+// reproduced (+0 is returned): the callers add the product to, or subtract it from, a value, where the sign of a zero
+// addend shows only if that value is itself -0 -- `zero_sign_matters` says so, and then the full sample is taken.
+RM_DEV v3 sphere_sample_times(Rng& r, float scale, bool zero_sign_matters) {
+  if (scale != 0.0f || scale != scale) return sphere_sample(r) * scale;
+  const float seed0 = r.seed;
+  const float s1 = seed0 + 0.123123213f;   // first pair: log argument
+  const float s2 = s1 + 0.123123213f;      //             angle (value not needed)
+  const float s3 = s2 + 0.123123213f;      // second pair: log argument
+  const float s4 = s3 + 0.123123213f;
+  const float a = r.n0 + s1, b = r.n0 + s3;
+  const float u1a = gold_noise(r, a - floorf(a)), u1b = gold_noise(r, b - floorf(b));
+  r.seed = s4;
+  // (a value of exactly 1 -- fract() of a tiny negative number -- makes a radius 0, two of them a 0/0: also the slow way)
+  const bool ordinary = u1a > 0.0f && u1a < 1.0f && u1b > 0.0f && u1b < 1.0f;
+  if (ordinary && !zero_sign_matters) return V(0.0f, 0.0f, 0.0f);
+  r.seed = seed0;  // rare: a logarithm is -Inf or 0 (or the caller needs the zeros' signs)
+  return sphere_sample(r) * scale;
+}
+RM_DEV bool is_neg_zero(float x) { return __float_as_uint(x) == 0x80000000u; }
 
 // ---- scene in LDS ---------------------------------------------------------------
 
@@ -356,13 +394,19 @@ struct Sdf<RM_SCENE_MANDELBULB> {
     const float s8 = on_axis ? 0.0f : B * q8;  // r^8 sin(8 theta) / rho^8
     z = V(FM::fma(s8, C, pos.x), FM::fma(s8, D, pos.y), A + pos.z);
   }
-  static RM_DEV float eval_pow8(const DevScene& sc, v3 pos) {
-    const int iterations = (int)sc.p[RM_P_BULB_ITERATIONS];
+  // 0.5 log(r) r / dr with r = sqrt(r2): log2(r2) and sqrt(r2) both start from r2 (no chain through r), and the
+  // constants fold: 0.5 * ln 2 * 0.5 = 0.17328680
+  static RM_DEV float pow8_distance(float r2, float dr) {
+    return __builtin_amdgcn_logf(r2) * 0.17328680f * FM::sqrt(r2) * FM::rcp(dr);
+  }
+  // ITERS = 8: the usual round count, unrolled -- no loop bookkeeping between the exec-mask regions (11 % on the
+  // headline frame); ITERS = 0: the count is a scene parameter
+  template <int ITERS>
+  static RM_DEV float eval_pow8_n(const DevScene& sc, v3 pos) {
     const float bail2 = sc.p[RM_P_BULB_BAILOUT] * sc.p[RM_P_BULB_BAILOUT];
     v3 z = pos;
     float dr = 1.0f, r2 = 0.0f;
-    if (iterations == 8) {
-      // the usual round count, unrolled: no loop bookkeeping between the exec-mask regions (11 % on the headline frame)
+    if (ITERS == 8) {
 #ifdef RM_LANE_STATS
       int rounds = 0;
 #endif
@@ -378,10 +422,10 @@ struct Sdf<RM_SCENE_MANDELBULB> {
       }
 #ifdef RM_LANE_STATS
       {  // diagnostic build (tools/lane_stats.py): lanes x rounds used against lanes x rounds issued
-        const unsigned long long act = __ballot(1);
+        const unsigned long long act = ballot(true);
         unsigned long long lane_rounds = 0, wave_rounds = 0;
         for (int r = 1; r <= 8; r++) {
-          const unsigned long long m = __ballot(rounds >= r);
+          const unsigned long long m = ballot(rounds >= r);
           lane_rounds += __popcll(m);
           wave_rounds += m != 0ull ? 1 : 0;
         }
@@ -394,6 +438,7 @@ struct Sdf<RM_SCENE_MANDELBULB> {
       }
 #endif
     } else {
+      const int iterations = (int)sc.p[RM_P_BULB_ITERATIONS];
       for (int i = 0; i < iterations; i++) {
         const float rho2 = FM::fma(z.y, z.y, z.x * z.x);
         r2 = FM::fma(z.z, z.z, rho2);
@@ -401,8 +446,10 @@ struct Sdf<RM_SCENE_MANDELBULB> {
         pow8_round(z, dr, pos, rho2, r2);
       }
     }
-    const float r = FM::sqrt(r2);
-    return 0.5f * FM::log(r) * r * FM::rcp(dr);
+    return pow8_distance(r2, dr);
+  }
+  static RM_DEV float eval_pow8(const DevScene& sc, v3 pos) {
+    return (int)sc.p[RM_P_BULB_ITERATIONS] == 8 ? eval_pow8_n<8>(sc, pos) : eval_pow8_n<0>(sc, pos);
   }
   template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds&, v3 p) {
@@ -436,8 +483,7 @@ struct Sdf<RM_SCENE_MANDELBULB> {
         pow8_round(z, dr, p, rho2, r2);
       }
       if (!bailed) return false;
-      const float r = FM::sqrt(r2);
-      d = 0.5f * FM::log(r) * r * FM::rcp(dr);
+      d = pow8_distance(r2, dr);
       return true;
     }
     const float power = sc.p[RM_P_BULB_POWER], bailout = sc.p[RM_P_BULB_BAILOUT];
@@ -453,6 +499,16 @@ struct Sdf<RM_SCENE_MANDELBULB> {
     d = M::div(0.5f * M::log(r) * r, dr);
     return true;
   }
+};
+
+// The Mandelbulb as the headline configuration has it (fast build, power 8, 8 rounds): a kernel of its own
+// (rm_kernels.inc launch_pixels), so that the march loop carries neither the generic-power path (acos, atan, pow)
+// nor the runtime round count.  Internal to the pixel kernel's dispatch; not a scene kind of the ABI.
+#define RM_KIND_BULB8 RM_SCENE_KIND_COUNT
+template <>
+struct Sdf<RM_KIND_BULB8> : Sdf<RM_SCENE_MANDELBULB> {
+  template <class M>
+  static RM_DEV float eval(const DevScene& sc, const SceneLds&, v3 p) { return eval_pow8_n<8>(sc, p); }
 };
 
 // per-level scale factors pow(base, i), i = first .. first + RM_TAB_POW - 1,
@@ -607,8 +663,12 @@ RM_DEV v3 scene_emission(const DevScene& sc, v3 p) {
   return length<PM>(p) > m.sky_radius ? bright * m.sky_scale : V(0.0f, 0.0f, 0.0f);
 }
 
-// :148-150
-RM_DEV float inv_exp_dist(float x, float lambda) { return -logf(1.0f - x) / lambda; }
+// :148-150.  Without fog (lambda = +0, the default) -log(1 - x) / 0 is +Inf, or NaN when 1 - x rounds to 1
+// (-0 / 0): the same values without the logarithm and the division.
+RM_DEV float inv_exp_dist(float x, float lambda) {
+  if (__float_as_uint(lambda) == 0u) return (1.0f - x == 1.0f) ? __builtin_nanf("") : __builtin_inff();
+  return -logf(1.0f - x) / lambda;
+}
 
 // :172-175
 RM_DEV float schlick(float cos_theta, float n1, float n2) {
