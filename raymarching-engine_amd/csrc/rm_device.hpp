@@ -368,31 +368,33 @@ struct Sdf<RM_SCENE_MANDELBULB> {
     }
     return M::div(0.5f * M::log(r) * r, dr);
   }
-  // Power 8 without trigonometry: with rho = |z.xy|, (z.z + i rho)^8 =
-  // r^8 (cos 8theta + i sin 8theta) and (z.x + i z.y)^8 = rho^8 (cos 8phi + i sin 8phi),
-  // each by three complex squarings.  The same function as eval_generic up to
-  // rounding; 2 sqrt + 1 rcp per iteration instead of 12 transcendentals.
+  // Power 8 without trigonometry: with rho = |z.xy|, the angles' 8-fold multiples come from 8th powers of complex
+  // numbers, each by three complex squarings.  The same function as eval_generic up to
+  // rounding; 1 sqrt + 1 rsq per iteration instead of 12 transcendentals.
   static RM_DEV void pow8_round(v3& z, float& dr, v3 pos, float rho2, float r2) {
-    // 2 transcendentals per round: r = sqrt(r2) and q = 1/rho = rsq(rho2); rho = rho2*q, 1/rho^8 = q^8
+    // 2 transcendentals per round: r = sqrt(r2) and q = 1/rho = rsq(rho2); rho = rho2 * q.
+    // (z.z + i rho)^8 = r^8 (cos 8theta + i sin 8theta) =: A + iB is taken as it stands; the azimuth comes from the
+    // UNIT vector (z.x + i z.y) / rho, whose 8th power is cos 8phi + i sin 8phi =: C + iD with no rho^8 to divide
+    // out again (two multiplications by q instead of q^2, q^4, q^8 and the product).  On the axis rho2 = 0 and
+    // q = rsq(0) = Inf would turn 0 * q into NaN: the rsq sees rho2 + 1e-30 (the same float as rho2 unless rho2 <
+    // 1e-23), so there q is finite, C + iD = 0 and B = 0 anyway (sin 8theta = 0), and the new z is
+    // (pos.x, pos.y, A + pos.z) as it should be.
     const float r = FM::sqrt(r2);
-    const float q = __builtin_amdgcn_rsqf(rho2);
+    const float q = __builtin_amdgcn_rsqf(rho2 + 1e-30f);
     const float rho = rho2 * q;
     const float r4 = r2 * r2;
     dr = FM::fma((r4 * r2 * r) * 8.0f, dr, 1.0f);
-    // (A + iB) = (z.z + i rho)^8, (C + iD) = (z.x + i z.y)^8: three complex squarings each,
-    // re' = re^2 - im^2 (one mul + one fma), im' = 2 re im
-    float A = z.z, B = rho, C = z.x, D = z.y, t;
+    // three complex squarings each: re' = re^2 - im^2 (one mul + one fma), im' = 2 re im
+    float A = z.z, B = rho, C = z.x * q, D = z.y * q, t;
 #pragma unroll
     for (int s = 0; s < 3; s++) {
       t = FM::fma(A, A, -(B * B)); B = (A + A) * B; A = t;
       t = FM::fma(C, C, -(D * D)); D = (C + C) * D; C = t;
     }
-    const float q2 = q * q, q4 = q2 * q2, q8 = q4 * q4;
-    // on the axis (rho2 = 0: q = rsq(0) = Inf; also a rho so small that q^8 overflows, or NaN) phi = atan(0, 0) = 0:
-    // cos 8phi = 1, sin 8theta = 0.  One test covers them all.
-    const bool on_axis = !(q8 < __builtin_inff());
-    const float s8 = on_axis ? 0.0f : B * q8;  // r^8 sin(8 theta) / rho^8
-    z = V(FM::fma(s8, C, pos.x), FM::fma(s8, D, pos.y), A + pos.z);
+    // (Packed fp32 -- v_pk_mul / v_pk_fma / v_pk_add_f32 on the pairs (A, C) and (B, D), 12 instructions instead of
+    // 24, same IEEE results per half -- was measured on the headline frame: 2.80 ms against 2.69.  A packed
+    // instruction takes two issue slots of a busy SIMD, and the SIMDs are busy.)
+    z = V(FM::fma(B, C, pos.x), FM::fma(B, D, pos.y), A + pos.z);
   }
   // 0.5 log(r) r / dr with r = sqrt(r2): log2(r2) and sqrt(r2) both start from r2 (no chain through r), and the
   // constants fold: 0.5 * ln 2 * 0.5 = 0.17328680
