@@ -63,10 +63,10 @@ def gen_texcoord():
         save(f"texcoord_{w}x{h}", out=g)
 
 
-def gen_sdf():
+def gen_sdf(only=None):
     pts = GC.sdf_points()
     w, h = 64, 64
-    for name in GC.SCENES:
+    for name in (only or GC.SCENES):
         sc, text, uni = scene_text(name)
         frag = glref.splice(text, "void main(void){ " + FETCH + " fragColor = vec4(sdf(t.xyz), 0.0, 0.0, 0.0); }")
         g = glref.run_gl(frag, w, h, uni, init_prev0=pack(pts, w, h))["planes"][0]
@@ -146,10 +146,11 @@ def gen_rng():
     save("portable_tan", x=g[..., 0].reshape(-1), tan=g[..., 1].reshape(-1))
 
 
-def gen_image():
+def gen_image(only=None):
     """Unmodified main() of the reference (tan routed to the portable tangent):
-    three planes after `samples` draws with the Halton(2,3) randNoise sequence."""
-    for case in GC.IMAGES:
+    three planes after `samples` draws with the Halton(2,3) randNoise sequence.
+    `only`: a list of case names (python oracle/gl/gen_golden.py image:case1,case2)."""
+    for case in (only or GC.IMAGES):
         scene_name, samples, _ = GC.IMAGES[case]
         sc, _, schema = GC.image_schema(case)
         _, text, uni = scene_text(scene_name)
@@ -181,6 +182,15 @@ def gen_stat():
     draws = [{"randNoise": glref.u_float(*x)} for x in noise]
     r = glref.run_gl(glref.splice(sc.glsl()), w, h, base, draws=draws, read=(0,))
     save("stat_sphere_full_native_tan", color_sum=r["planes"][0], samples=np.int32(n))
+    # the same pin on the headline scene: Mandelbulb, 1 bounce + the point light, 64x32, 256 samples
+    w, h, n = 64, 32, 256
+    sc = GC.build_scene("mandelbulb")
+    schema = J.make_schema(sc, w, h, render_mode="full", counts=(64,), position=(0, 0, -2.5), lights=GC.LIGHT, exposure=1.0)
+    noise = GC.halton_pairs(n)
+    base = glref.uniforms_from_schema(schema, noise[0])
+    draws = [{"randNoise": glref.u_float(*x)} for x in noise]
+    r = glref.run_gl(glref.splice(sc.glsl()), w, h, base, draws=draws, read=(0,))
+    save("stat_mandelbulb_full_native_tan", color_sum=r["planes"][0], samples=np.int32(n))
 
 
 def gen_display():
@@ -204,4 +214,8 @@ if __name__ == "__main__":
         sys.exit("needs /root/reference and the kaleido wheel (build container only)")
     for g in (sys.argv[1:] or list(GROUPS)):
         print(g)
-        GROUPS[g]()
+        if ":" in g:
+            name, only = g.split(":", 1)
+            GROUPS[name](only.split(","))
+        else:
+            GROUPS[g]()

@@ -125,6 +125,12 @@ def point_light(position, color=(1.0, 1.0, 1.0), strength: float = 3.0, size: fl
     return {"type": "point", "position": list(position), "color": [c * 255.0 * strength / 256.0 for c in color], "size": size}
 
 
+def sun_light(direction, color=(1.0, 1.0, 1.0), strength: float = 3.0) -> dict:
+    """A sun: the reference passes its `direction` where a point light has its position, with size 0
+    (RenderJobExecutor.tsx:276-291) -- so it is lit like a point at that place."""
+    return {"type": "sun", "direction": list(direction), "color": [c * 255.0 * strength / 256.0 for c in color]}
+
+
 _REQUIRED = ("reflectionIterationCounts", "fogDensity", "dof", "camera", "render", "lights")
 
 

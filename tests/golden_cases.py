@@ -12,6 +12,10 @@ from raymarching_engine_amd import scene as S
 LIGHT = [J.point_light((2.0, 3.0, -4.0))]
 SOFT_LIGHT = [J.point_light((2.0, 3.0, -4.0), size=0.3)]
 
+# two point lights (the second soft) and a sun (RenderJobExecutor.tsx:276-291): light indices 1 and 2 of raymarcher.frag:354-373
+THREE_LIGHTS = [J.point_light((2.0, 3.0, -4.0)), J.point_light((-3.0, 1.0, -2.0), color=(1.0, 0.5, 0.25), strength=2.0, size=0.4),
+                J.sun_light((0.5, 4.0, 1.0), color=(0.3, 0.6, 1.0), strength=1.5)]
+
 # rotation about y by 0.4 rad then x by -0.25 rad, column-major like gl-matrix
 def _rot():
     cy, sy = np.cos(0.4), np.sin(0.4)
@@ -27,6 +31,8 @@ ROT = _rot()
 # name -> (scene factory, reference example file or None)
 SCENES = {
     "sphere": (lambda: S.single_sphere(), None),
+    # subsurface scattering on: mean free path 1/5, tinted (raymarcher.frag:266-271, :284-288)
+    "sphere_sss": (lambda: S.single_sphere(material=S.Material(subsurface=5.0, subsurface_color=(0.9, 0.5, 0.3))), None),
     "csg64": (lambda: S.csg64(), None),
     "csg_mixed": (
         lambda: S.CsgScene().box((0, 0, 0), (1.0, 0.6, 0.8)).subtract().sphere((0.4, 0.3, -0.6), 0.7)
@@ -72,6 +78,14 @@ IMAGES = {
     "mandelbulb_full_light": ("mandelbulb", 1, dict(render_mode="full", position=(0, 0, -2.5), counts=(64,), lights=LIGHT)),
     "menger_preview": ("menger", 1, dict(render_mode="preview", position=(0.5, 0.5, -2.0), counts=(48,))),
     "tree_preview": ("tree", 1, dict(render_mode="preview", position=(0, 0, -6.0), counts=(48,))),
+    # round 2: the branches no case reached before
+    "sphere_sss_full_3b": ("sphere_sss", 2, dict(render_mode="full", counts=(64, 32, 32), lights=LIGHT)),  # subsurface branch :284-288
+    "sphere_full_3lights": ("sphere", 1, dict(render_mode="full", counts=(64, 32), lights=THREE_LIGHTS)),  # lightCount 3, a sun, a soft light
+    "fractal1_live_default": ("fractal1", 1, dict(render_mode="full", position=(0, 0, 0), counts=(128, 128, 64, 32, 32))),  # index.tsx:321
+    "menger_full_2b": ("menger", 1, dict(render_mode="full", position=(0.5, 0.5, -2.0), counts=(48, 24), lights=LIGHT)),
+    "tree_full_2b": ("tree", 1, dict(render_mode="full", position=(0, 0, -6.0), counts=(48, 24), lights=LIGHT)),
+    "smooth_tree_full_2b": ("smooth_tree", 1, dict(render_mode="full", position=(0, 0, -6.0), counts=(48, 24), lights=LIGHT)),
+    "rotation_fractal_full_2b": ("rotation_fractal", 1, dict(render_mode="full", position=(0, 0, -4.0), counts=(48, 24), lights=LIGHT)),
 }
 
 # cast-ray goldens: scene -> (camera position, steps)
