@@ -21,6 +21,51 @@ float sdf(vec3 p) { return length(p) - shellRadius; }
 """
 
 
+def _norm(entry):
+    import math
+
+    return {k: ("NaN" if isinstance(v, float) and math.isnan(v) else v) for k, v in entry.items()}
+
+
+def _fixture():
+    import json
+    from pathlib import Path
+
+    return json.loads((Path(__file__).parent / "golden" / "params_reference.json").read_text())
+
+
+def test_scanner_equals_the_reference_on_synthetic_texts():
+    """get_custom_shader_params against the outputs of the reference's own getCustomShaderParams
+    (CustomShaderParamParser.tsx:8-209, run under node by oracle/ts/gen_params_golden.py): block comments, quoted
+    values, every error entry with its span, non-float types, annotations before the first uniform, `uniform` that is
+    not a declaration, two uniforms on a line, the empty text."""
+    fx = _fixture()
+    assert len(fx["synthetic_texts"]) >= 9
+    for name, text in fx["synthetic_texts"].items():
+        got = [_norm(e) for e in P.get_custom_shader_params(text)]
+        assert got == fx["results"][name]["params"], name
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/client/public/examples"), reason="the reference's example texts are only in the build container (they are not copied into the repo)")
+def test_scanner_equals_the_reference_on_its_example_scenes():
+    from pathlib import Path
+
+    fx = _fixture()
+    seen = 0
+    for key, res in fx["results"].items():
+        if not key.startswith("example:"):
+            continue
+        for sub in ("public/examples", "dist/examples"):
+            f = Path("/root/reference/client") / sub / key.split(":", 1)[1]
+            if f.exists():
+                text = f.read_text()
+                assert len(text) == res["length"], key
+                assert [_norm(e) for e in P.get_custom_shader_params(text)] == res["params"], key
+                seen += 1
+                break
+    assert seen >= 6
+
+
 def test_annotation_scanner():
     ps = P.get_custom_shader_params(SNIPPET)
     assert [p["internalName"] for p in ps] == ["shellRadius", "tint", "mode", "bare"]
@@ -30,17 +75,20 @@ def test_annotation_scanner():
     assert a["tooltip"] == "Radius of the shell."
     assert b["quantity"] == 3 and b["defaultValue"] == [0.25, 0.5, 0.75] and b["formats"] == ["color", "numerical"]
     assert c["type"] == "i" and c["defaultValue"] == [1.0] and c["formats"] == ["checkbox"]
-    assert d["name"] == "bare" and "defaultValue" not in d and d["formats"] == ["numerical"]
+    # no @default: the reference's table carries four zeros whatever the quantity (CustomShaderParamParser.tsx:32)
+    assert d["name"] == "bare" and d["defaultValue"] == [0, 0, 0, 0] and d["formats"] == ["numerical"]
     vals = P.default_custom_shader_parameters(SNIPPET)
     assert vals["tint"] == {"type": "f", "count": 3, "data": [0.25, 0.5, 0.75]}
     assert vals["mode"] == {"type": "i", "count": 1, "data": [1]} and vals["bare"]["data"] == [0.0]
 
 
 def test_annotation_errors_are_values():
+    # unknown keys are ignored by the reference (its switch has no default); the two malformed values are reported,
+    # BEFORE the parameter they belong to (a parameter is emitted when the next `uniform` or the end is reached)
     ps = P.get_custom_shader_params("uniform vec2 a;\n//@default=1 @bogus=3 @min=abc\n")
-    bad = [p for p in ps if not p["success"]]
-    assert len(bad) == 3 and all("start" in b and "end" in b and b["reason"] for b in bad)
-    assert [p for p in ps if p["success"]][0]["internalName"] == "a"
+    assert [p["success"] for p in ps] == [False, False, True]
+    assert all("start" in b and "end" in b and b["reason"] for b in ps[:2])
+    assert ps[2]["internalName"] == "a" and ps[2]["defaultValue"] == [1]
 
 
 def test_scene_from_example_text():
