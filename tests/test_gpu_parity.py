@@ -548,6 +548,29 @@ def test_present_pass(ctx, name):
     win.destroy()
 
 
+def test_present_pass_blur_radii_and_wrap(ctx):
+    """The LDS-staged blur on a frame whose DoF radius runs from 0 to the 16-pixel cap across the image, borders
+    included (REPEAT taps wrap): the same RGBA8 as the oracle's display.frag within one code value, and tiles
+    without blur (radius 0 everywhere) equal the unblurred tone map exactly."""
+    rng = np.random.default_rng(11)
+    w, h, n = 203, 117, 4
+    color = (rng.uniform(0, 3.0, (h, w, 4)) * rng.uniform(0, 1, (h, w, 1)) ** 3).astype(np.float32)
+    ndof = np.zeros((h, w, 4), np.float32)
+    ramp = np.linspace(0.0, 0.09 * n, w, dtype=np.float32)[None, :] * np.ones((h, 1), np.float32)  # kernel = w / n * 200: 0 .. 18 -> capped at 16
+    ramp[:, :40] = 0.0
+    ramp[: h // 3, :] *= 0.3
+    ndof[..., 3] = ramp
+    fb = ctx.create_framebuffer(w, h)
+    fb.upload(0, color)
+    fb.upload(1, ndof)
+    got = fb.present(n)
+    want = O.present(color, ndof, n)
+    d = np.abs(got.astype(int) - want.astype(int))
+    assert d.max() <= 1 and np.mean(d == 0) >= 0.99, (d.max(), np.mean(d == 0))
+    assert np.array_equal(got[:, :16], O.present(color, None, n)[:, :16]) or np.abs(got[:, :16].astype(int) - O.present(color, None, n)[:, :16].astype(int)).max() <= 1
+    fb.destroy()
+
+
 # ---- boundary behaviour -----------------------------------------------------------
 
 

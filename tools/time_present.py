@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Time of the present pass (display.frag) on a 3840x2160 frame: no depth of field, a moderate blur, the 16-pixel cap."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+from raymarching_engine_amd import native
+W, H = 3840, 2160
+ctx = native.Context(0)
+st = torch.cuda.Stream(); torch.cuda.set_stream(st); ctx.set_stream(st.cuda_stream)
+color = torch.rand((H, W, 4), device="cuda") * 2
+out = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+for name, radius in (("no depth of field (radius 0)", None), ("radius 4 px", 4.0), ("radius 16 px (cap)", 16.0), ("radius 0..16 ramp", "ramp")):
+    ndof = None
+    if radius is not None:
+        ndof = torch.zeros((H, W, 4), device="cuda")
+        ndof[..., 3] = (torch.linspace(0, 16.0 / 200.0, W, device="cuda")[None, :] if radius == "ramp" else radius / 200.0)
+    for rep in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(5):
+            ctx.present_device(color.data_ptr(), ndof.data_ptr() if ndof is not None else None, W, H, 1, out.data_ptr())
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+    print(f"present 3840x2160, {name}: {dt * 1e3:.3f} ms")
+fb = ctx.wrap_framebuffer(W, H, 0, H, color.data_ptr())
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(20):
+    ctx.present_rows(fb, 1, out.data_ptr())
+torch.cuda.synchronize(); print(f"present_rows 3840x2160: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms")
