@@ -173,17 +173,22 @@ def uniforms_from_schema(schema: dict, rand_noise: Tuple[float, float]) -> abi.R
     return u
 
 
-def tile_rect(schema: dict, x_part: int, y_part: int) -> abi.RmRect:
+def tile_rect(schema: dict, x_part: int, y_part: int, reference_scissor: bool = False) -> abi.RmRect:
     """Screen tile of the `subdivisions` loop (RenderJobExecutor.tsx:167-180).
-    The reference hands (x1, y1, x2, y2) to gl.scissor where GL expects
-    (x, y, width, height) (:182), which is harmless only for subdivisions == 1;
-    the intent -- the tile rectangle -- is what is honoured here."""
+    The reference hands (x1, y1, x2, y2) to gl.scissor, where GL expects (x, y, width, height) (:182): GL then
+    takes x2, y2 as the SIZE of the rectangle at (x1, y1).  Clipped to the image that is exactly the intended
+    tile for subdivisions 1 and 2; from 3 on the rectangles reach to the right and top edges of the image and
+    overlap, so with the reference an additive render is brighter where they do.  The default here is the
+    intent -- the tile rectangle; `reference_scissor=True` (job option `render.referenceScissor`) gives the
+    reference's rectangle, for a host that has to reproduce upstream images of subdivided renders."""
     r = schema["render"]
     n = r["subdivisions"]
     x1 = math.floor(r["width"] / n * x_part)
     y1 = math.floor(r["height"] / n * y_part)
     x2 = math.ceil(r["width"] / n * (x_part + 1))
     y2 = math.ceil(r["height"] / n * (y_part + 1))
+    if reference_scissor or r.get("referenceScissor"):
+        return abi.RmRect(x1, y1, min(x2, r["width"] - x1), min(y2, r["height"] - y1))
     return abi.RmRect(x1, y1, x2 - x1, y2 - y1)
 
 

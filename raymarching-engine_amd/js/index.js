@@ -131,10 +131,13 @@ function uniformsFromSchema(schema, randNoise) {  // RenderJobExecutor.tsx:212-2
   });
 }
 
-function tileRect(schema, xp, yp) {  // :167-180 (the intent of the scissor call, see DESIGN.md)
+// :167-180.  The reference passes (x1, y1, x2, y2) to gl.scissor(x, y, width, height): identical to the intended tile
+// for subdivisions <= 2, over-covering from 3 on.  Default: the intent; render.referenceScissor = true: the reference's rectangle.
+function tileRect(schema, xp, yp) {
   const r = schema.render, n = r.subdivisions;
   const x1 = Math.floor((r.width / n) * xp), y1 = Math.floor((r.height / n) * yp);
   const x2 = Math.ceil((r.width / n) * (xp + 1)), y2 = Math.ceil((r.height / n) * (yp + 1));
+  if (r.referenceScissor) return new Int32Array([x1, y1, Math.min(x2, r.width - x1), Math.min(y2, r.height - y1)]);
   return new Int32Array([x1, y1, x2 - x1, y2 - y1]);
 }
 

@@ -196,3 +196,19 @@ def test_png_capture_round_trip_and_container():
     bad[20] ^= 1
     with pytest.raises(ValueError):
         capture.decode_png(bytes(bad))
+
+
+def test_reference_scissor_option():
+    """gl.scissor(x1, y1, x2, y2) read as (x, y, width, height) (RenderJobExecutor.tsx:182): the intended tile for
+    1 and 2 subdivisions, rectangles that reach the far edges from 3 on."""
+    for n in (1, 2):
+        schema = J.make_schema(None, 100, 60, subdivisions=n)
+        for y in range(n):
+            for x in range(n):
+                a, b = J.tile_rect(schema, x, y), J.tile_rect(schema, x, y, reference_scissor=True)
+                assert (a.x, a.y, a.w, a.h) == (b.x, b.y, b.w, b.h)
+    schema = J.make_schema(None, 90, 60, subdivisions=3)
+    t = J.tile_rect(schema, 1, 1, reference_scissor=True)
+    assert (t.x, t.y, t.w, t.h) == (30, 20, 60, 40)  # scissor(30, 20, 60, 40): to the right and top edges
+    t = J.tile_rect(schema, 1, 1)
+    assert (t.x, t.y, t.w, t.h) == (30, 20, 30, 20)
