@@ -43,6 +43,9 @@ import time
 # Read by the runtime when it starts, so it has to be in the environment before anything touches the GPU.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+# one node by contract (N GPUs over xGMI): no InfiniBand to probe, rendezvous over loopback
+os.environ.setdefault("NCCL_IB_DISABLE", "1")
+os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

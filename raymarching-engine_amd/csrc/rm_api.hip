@@ -65,7 +65,16 @@ struct rm_ctx {
     int capacity = 0;   // tiles the buffers hold
     long long key[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // the job the costs belong to
     bool have_cost = false;
+    // Off the critical path (the context's own slot): two cost / order buffers used in turn.  The costs of launch n
+    // are sorted on a side stream WHILE launch n + 1 runs, and launch n + 2 starts in that order -- tile costs hardly
+    // change from one sample to the next, so an order that is one sample old is as good, and the 15 us of the sort
+    // (one workgroup) no longer stand between two launches.
+    unsigned int* cost2 = nullptr;
+    unsigned int* order2 = nullptr;
+    hipEvent_t rendered[2] = {nullptr, nullptr}, sorted[2] = {nullptr, nullptr};
+    unsigned long long launches = 0;  // of this job
   } lpt[RM_SP_MAX + 1];
+  hipStream_t lpt_stream = nullptr;
   bool lpt_enabled = true;
   hipEvent_t switch_ev = nullptr;  // orders the old stream before the new one in rm_ctx_set_stream
   uchar4* present_buf = nullptr;   // device staging of rm_present / rm_present_planes, grown on demand
@@ -173,9 +182,16 @@ void rm_ctx_destroy(rm_ctx* ctx) {
     if (ctx->wf_join[s]) (void)hipEventDestroy(ctx->wf_join[s]);
   }
   if (ctx->wf_fork) (void)hipEventDestroy(ctx->wf_fork);
+  if (ctx->lpt_stream) { (void)hipStreamSynchronize(ctx->lpt_stream); (void)hipStreamDestroy(ctx->lpt_stream); }
   for (auto& l : ctx->lpt) {
     if (l.cost) (void)hipFree(l.cost);
     if (l.order) (void)hipFree(l.order);
+    if (l.cost2) (void)hipFree(l.cost2);
+    if (l.order2) (void)hipFree(l.order2);
+    for (int k = 0; k < 2; k++) {
+      if (l.rendered[k]) (void)hipEventDestroy(l.rendered[k]);
+      if (l.sorted[k]) (void)hipEventDestroy(l.sorted[k]);
+    }
   }
   for (int s = 0; s < RM_SP_MAX; s++) {
     if (ctx->sp_stream[s]) { (void)hipStreamSynchronize(ctx->sp_stream[s]); (void)hipStreamDestroy(ctx->sp_stream[s]); }
@@ -754,12 +770,22 @@ static hipError_t launch_pixels_ordered(rm_ctx* ctx, const KParams& P, int flags
   const long long key[8] = {P.W, P.H, ((long long)P.tx << 32) | (unsigned int)P.ty, ((long long)P.tw << 32) | (unsigned int)P.th,
                             ((long long)P.stripe_rows << 40) | ((long long)P.parts << 20) | P.part, P.row_begin,
                             ((long long)P.scene.kind << 8) | P.u.renderMode, tiles};
+  const bool async_sort = slot == RM_SP_MAX;  // the context's own stream: sort on a side stream, one sample behind
   if (L.capacity < tiles) {
-    if (L.cost) { (void)hipStreamSynchronize(stream); (void)hipFree(L.cost); (void)hipFree(L.order); }
-    L.cost = L.order = nullptr;
+    if (L.cost) {
+      (void)hipStreamSynchronize(stream);
+      if (ctx->lpt_stream) (void)hipStreamSynchronize(ctx->lpt_stream);
+      (void)hipFree(L.cost); (void)hipFree(L.order);
+      if (L.cost2) { (void)hipFree(L.cost2); (void)hipFree(L.order2); }
+    }
+    L.cost = L.order = L.cost2 = L.order2 = nullptr;
     L.capacity = 0;
     if ((e = hipMalloc(reinterpret_cast<void**>(&L.cost), sizeof(unsigned int) * (size_t)tiles)) != hipSuccess) return e;
     if ((e = hipMalloc(reinterpret_cast<void**>(&L.order), sizeof(unsigned int) * (size_t)tiles)) != hipSuccess) return e;
+    if (async_sort) {
+      if ((e = hipMalloc(reinterpret_cast<void**>(&L.cost2), sizeof(unsigned int) * (size_t)tiles)) != hipSuccess) return e;
+      if ((e = hipMalloc(reinterpret_cast<void**>(&L.order2), sizeof(unsigned int) * (size_t)tiles)) != hipSuccess) return e;
+    }
     L.capacity = (int)tiles;
     L.have_cost = false;
   }
@@ -768,15 +794,49 @@ static hipError_t launch_pixels_ordered(rm_ctx* ctx, const KParams& P, int flags
     L.have_cost = false;
   }
   KParams Q = P;
-  Q.block_cost = L.cost;
-  if (L.have_cost) {
-    if ((e = rm::launch_order(L.cost, L.order, (int)tiles, stream)) != hipSuccess) return e;
-    Q.block_order = L.order;
-  } else {
-    if ((e = hipMemsetAsync(L.cost, 0, sizeof(unsigned int) * (size_t)tiles, stream)) != hipSuccess) return e;
+  if (!async_sort) {
+    Q.block_cost = L.cost;
+    if (L.have_cost) {
+      if ((e = rm::launch_order(L.cost, L.order, (int)tiles, stream)) != hipSuccess) return e;
+      Q.block_order = L.order;
+    } else {
+      if ((e = hipMemsetAsync(L.cost, 0, sizeof(unsigned int) * (size_t)tiles, stream)) != hipSuccess) return e;
+    }
+    L.have_cost = true;
+    return fast ? rm::launch_pixels_fast(Q, stream) : rm::launch_pixels_strict(Q, stream);
   }
-  L.have_cost = true;
-  return fast ? rm::launch_pixels_fast(Q, stream) : rm::launch_pixels_strict(Q, stream);
+  if (!ctx->lpt_stream) {
+    if ((e = hipStreamCreateWithFlags(&ctx->lpt_stream, hipStreamNonBlocking)) != hipSuccess) return e;
+  }
+  for (int k = 0; k < 2; k++) {
+    if (!L.rendered[k] && (e = hipEventCreateWithFlags(&L.rendered[k], hipEventDisableTiming)) != hipSuccess) return e;
+    if (!L.sorted[k] && (e = hipEventCreateWithFlags(&L.sorted[k], hipEventDisableTiming)) != hipSuccess) return e;
+  }
+  if (!L.have_cost) {  // a new job: both cost buffers start from zero, no order yet
+    if ((e = hipStreamSynchronize(ctx->lpt_stream)) != hipSuccess) return e;  // sorts of the previous job still use the buffers
+    if ((e = hipMemsetAsync(L.cost, 0, sizeof(unsigned int) * (size_t)tiles, stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(L.cost2, 0, sizeof(unsigned int) * (size_t)tiles, stream)) != hipSuccess) return e;
+    L.launches = 0;
+    L.have_cost = true;
+  }
+  const int cur = (int)(L.launches & 1ull), prev = cur ^ 1;
+  unsigned int* cost_cur = cur ? L.cost2 : L.cost;
+  unsigned int* order_cur = cur ? L.order2 : L.order;
+  // launch n writes its costs into buffer n % 2 (zeroed by the sort of launch n - 2, which launch n therefore waits
+  // for -- it ran during launch n - 1) and starts in the order that sort left in the same buffer's order array
+  if (L.launches >= 2) {
+    if ((e = hipStreamWaitEvent(stream, L.sorted[cur], 0)) != hipSuccess) return e;
+    Q.block_order = order_cur;
+  }
+  Q.block_cost = cost_cur;
+  (void)prev;
+  if ((e = fast ? rm::launch_pixels_fast(Q, stream) : rm::launch_pixels_strict(Q, stream)) != hipSuccess) return e;
+  if ((e = hipEventRecord(L.rendered[cur], stream)) != hipSuccess) return e;
+  if ((e = hipStreamWaitEvent(ctx->lpt_stream, L.rendered[cur], 0)) != hipSuccess) return e;
+  if ((e = rm::launch_order(cost_cur, order_cur, (int)tiles, ctx->lpt_stream)) != hipSuccess) return e;  // sorts and zeroes the costs
+  if ((e = hipEventRecord(L.sorted[cur], ctx->lpt_stream)) != hipSuccess) return e;
+  L.launches++;
+  return hipSuccess;
 }
 
 static hipError_t launch(rm_ctx* ctx, const KParams& P, int flags) {

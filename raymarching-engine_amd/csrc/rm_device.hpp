@@ -54,7 +54,10 @@ struct PM {
   static RM_DEV float rcp(float x) { return 1.0f / x; }
   static RM_DEV float div(float a, float b) { return a / b; }
   static RM_DEV float sqrt(float x) { return sqrtf(x); }
-  static RM_DEV float pow(float x, float y) { return powf(fabsf(x), y); }  // |x|: oracle/rm_oracle.c gl_pow
+  // |x|: oracle/rm_oracle.c gl_pow.  A square is a square: pow(x, 2.) = x * x, correctly rounded (every use of the
+  // path with that exponent has it as a literal -- the GGX term :371, schlick's r0 :173 -- so the test folds away
+  // and ~80 instructions of the library pow with it)
+  static RM_DEV float pow(float x, float y) { return y == 2.0f ? x * x : powf(fabsf(x), y); }
   static RM_DEV float log(float x) { return logf(x); }
   static RM_DEV float sin(float x) { return sinf(x); }
   static RM_DEV float cos(float x) { return cosf(x); }
