@@ -173,7 +173,7 @@ def main():
                     help="also time the same K steps with 3 samples in flight on this one GPU (reported as `overlap`, never as `value`)")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="consecutive samples that may overlap on one GPU (rm_ctx_set_samples_in_flight); default: 1 on one GPU, "
-                         "so that a kernel's duration in a rocprofv3 trace is the time of a step, 3 when the frame is sharded "
+                         "so that a kernel's duration in a rocprofv3 trace is the time of a step, 4 when the frame is sharded "
                          "(a shard's launch is too small to fill the chip: a ray is a ~1 ms serial chain)")
     args = ap.parse_args()
 
@@ -225,7 +225,9 @@ def main():
     render_stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(render_stream)
     ctx.set_stream(render_stream.cuda_stream)
-    in_flight = args.in_flight if args.in_flight > 0 else (1 if world == 1 else 3)
+    # measured on one GPU standing in for a rank (tools/dbg/depth_sweep.py, ms per sample of a rank's stripes, depth 1/2/3/4/6):
+    # whole frame 2.48/2.57/2.55/2.51/2.51, 1/2 of it 1.45/1.32/1.31/1.29/1.28, 1/4 0.88/0.70/0.70/0.68/0.66, 1/8 0.58/0.41/0.46/0.37/0.36
+    in_flight = args.in_flight if args.in_flight > 0 else (1 if world == 1 else 4)
     ctx.set_samples_in_flight(in_flight)
     tile = None
     rows_window = None

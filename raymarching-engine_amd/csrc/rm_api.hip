@@ -719,14 +719,15 @@ static hipError_t launch_pixels_ordered(rm_ctx* ctx, const KParams& P, int flags
 static hipError_t launch_pixels_in_flight(rm_ctx* ctx, const KParams& P, int flags) {
   hipError_t e;
   const int depth = ctx->samples_in_flight;
-  if (!ctx->sp_ready) {
-    for (int s = 0; s < RM_SP_MAX; s++) {
-      if ((e = hipStreamCreateWithFlags(&ctx->sp_stream[s], hipStreamNonBlocking)) != hipSuccess) return e;
-      if ((e = hipEventCreateWithFlags(&ctx->sp_done[s], hipEventDisableTiming)) != hipSuccess) return e;
-      if ((e = hipEventCreateWithFlags(&ctx->sp_free[s], hipEventDisableTiming)) != hipSuccess) return e;
-    }
-    ctx->sp_ready = true;
+  // side streams are made as the depth asks for them, not all RM_SP_MAX at once: the HIP runtime deals a process's streams
+  // over a few hardware queues, and streams that share a queue serialise (measured: see bench.py, GPU_MAX_HW_QUEUES)
+  for (int s = 0; s < depth; s++) {
+    if (ctx->sp_stream[s]) continue;
+    if ((e = hipStreamCreateWithFlags(&ctx->sp_stream[s], hipStreamNonBlocking)) != hipSuccess) return e;
+    if ((e = hipEventCreateWithFlags(&ctx->sp_done[s], hipEventDisableTiming)) != hipSuccess) return e;
+    if ((e = hipEventCreateWithFlags(&ctx->sp_free[s], hipEventDisableTiming)) != hipSuccess) return e;
   }
+  ctx->sp_ready = true;
   const size_t need = (size_t)(P.ty + P.th) * (size_t)P.W;  // staged values sit at the plane index of their pixel
   if (ctx->sp_capacity < need) {
     if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
