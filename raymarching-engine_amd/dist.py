@@ -31,11 +31,13 @@ class FrameGatherer:
     stripe).  Receive buffers, the assembled frame and two snapshot buffers are
     allocated once.  At most ONE gather is outstanding: start() -> finish().
 
-    Streams on a GPU (none of them ever blocks the render stream):
+    Streams on a GPU (the render stream is never made to wait):
       render stream  snapshot (clone / present_rows) of the window
-      issue stream   waits for the snapshot and for the previous assembly, then the collective is enqueued from it
-                     (RCCL's own stream waits for the stream it is called on)
-      aux stream     waits for the collective, runs rm_assemble_striped(_bytes)
+      aux stream     waits for the snapshot; the collective is enqueued from it (RCCL's own stream waits for the stream
+                     it is called on, so also for the previous frame's assembly, which is earlier on aux); then waits
+                     for the collective and runs rm_assemble_striped(_bytes)
+    One extra stream, not two: the HIP runtime deals a process's streams over a few hardware queues, and streams
+    that share one serialise (that cost rank 0 a third of its step before the side streams were trimmed).
     """
 
     def __init__(self, height: int, width: int, world: int, rank: int, device, dst: int = 0, channels: int = 4,
@@ -59,7 +61,7 @@ class FrameGatherer:
         self.frame = None
         self.index = None
         self.pending = None
-        self.aux = self.issue = None
+        self.aux = None
         self.snaps = None  # two snapshot buffers, used alternately (GPU)
         self.snap_free = None
         self.turn = 0
@@ -71,7 +73,6 @@ class FrameGatherer:
             self.index = [torch.as_tensor(shard.owned_rows(height, world, p, stripe_rows), device=device) for p in range(world)]
         if torch.device(device).type == "cuda":
             self.aux = torch.cuda.Stream(device=device)
-            self.issue = torch.cuda.Stream(device=device)
             self.snaps = [torch.zeros(shape, dtype=self.dtype, device=device) for _ in range(2)]
             self.snap_free = [None, None]  # events: the collective that sent snaps[k] is done
 
@@ -101,9 +102,8 @@ class FrameGatherer:
                 self.ctx.present_rows(fb, samples, snap.data_ptr(), cur.cuda_stream)
             else:
                 snap.copy_(plane)
-            self.issue.wait_stream(cur)       # the snapshot is complete
-            self.issue.wait_stream(self.aux)  # the receive buffers are free: the previous frame has been assembled
-            with torch.cuda.stream(self.issue):
+            self.aux.wait_stream(cur)  # the snapshot is complete; the previous frame's assembly is earlier on aux
+            with torch.cuda.stream(self.aux):
                 work = dist.gather(snap, self.recv if self.rank == self.dst else None, dst=self.dst, async_op=True)
             self.pending = (work, k)
         else:  # CPU (gloo)

@@ -886,7 +886,7 @@ print(f"RCCL_ONE_RANK_OK {payload} {time.time() - t_start:.1f} s", flush=True)
 @pytest.mark.parametrize("payload", ["rgba8", "f32"])
 def test_frame_gatherer_over_rccl_one_rank(payload, tmp_path):
     """dist.FrameGatherer on the GPU over backend nccl (= RCCL) with the collective forced at world size 1: snapshot
-    -> issue stream -> gather -> aux stream -> rm_assemble_striped(_bytes), overlapped with the next sample's render
+    -> aux stream: gather, rm_assemble_striped(_bytes) -- overlapped with the next sample's render
     exactly as bench.py drives it, and the assembled frame is bit-identical to the planes / to rm_present.
     Runs in a process of its own (a process group per pytest process is one too many, and a collective library that
     stalls is stopped by the timeout instead of stopping the suite)."""
