@@ -266,7 +266,7 @@ def main():
         if sharded and gatherer.pending is not None:
             gatherer.finish()
         if sharded and gatherer.aux is not None:
-            torch.cuda.current_stream().wait_stream(gatherer.aux)  # the last frame is assembled before the clock stops
+            torch.cuda.current_stream().wait_stream(gatherer.aux)  # the last frame is assembled before the clock stops (side-stream mode)
 
     for _ in range(args.warmup):
         step()
@@ -345,7 +345,8 @@ def main():
                     "executed_source": counters_file,
                     "kernel_ms": kernel_ms, "kernel_launches_timed": n_timed, "pixels_per_launch": px_launch,
                     "hbm_algorithmic_GBs": 96.0 * px_launch / sec / 1e9, "hbm_peak_GBs": PEAK_HBM_GBS}
-        auto = "auto (wavefront)" if (args.workload in ("c4", "c5") and world == 1 and rows_window is None and _prefers_wavefront(args.workload)) else "auto (megakernel)"
+        # rm_api.hip prefer_wavefront: full-mode tiles of >= 2^23 pixels over a primitive table of >= 16 rows
+        auto = "auto (wavefront)" if (args.workload in ("c4", "c5") and wl["mode"] == "full" and px_launch >= (1 << 23)) else "auto (megakernel)"
         out = {
             "metric": "Mpixels/sec at 3840x2160 Mandelbulb" if args.workload in ("c3b", "c3a") else "Mpixels/sec",
             "value": value, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -368,10 +369,6 @@ def main():
         dist.destroy_process_group()
     if out is not None:
         print(json.dumps(out), flush=True)
-
-
-def _prefers_wavefront(workload):
-    return False  # the library's default dispatch is the pixel kernel for every workload (rm_api.hip prefer_wavefront)
 
 
 if __name__ == "__main__":

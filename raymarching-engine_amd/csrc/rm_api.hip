@@ -702,14 +702,16 @@ static hipError_t launch_wavefront(rm_ctx* ctx, const KParams& P, int flags) {
 }
 
 // Which implementation of the per-pixel program runs a job (same results either way).
-// Measured on MI355X at the end of round 1 (tools/time_all.py): the one-kernel form wins everywhere
-// (Mandelbulb 4K lit 3.11 vs 4.52 ms fast, 26.1 vs 28.3 strict; sphere 1080p preview 0.12 vs 1.4) except on the
-// largest full-mode frames of long primitive tables (CSG-64 4096^2: 50.0 vs 54.1 ms fast, 131 vs 146 strict), where the
-// pipeline's global ray compaction still pays for its per-ray state traffic and launch chain.
+// Measured on MI355X in round 2 (bench.py --workload ..., fast build, ms per sample, pixel kernel / wavefront pipeline):
+//   Mandelbulb 3840x2160 full      2.49 / 4.5         sphere 1080p preview 0.11 / 1.4
+//   CSG-64 4096x512  (2 Mpx)       7.76 / 8.94        CSG-64 4096x4096 (16.8 Mpx)  53.4 / 48.5
+//   CSG-64 8192x1024 (8.4 Mpx)     68.8 / 65.4        CSG-64 8192x8192 (67 Mpx)    531  / 496
+// The one-kernel form wins everywhere except on large full-mode frames of long primitive tables, where the pipeline's
+// global ray compaction over very many long, uniform evaluations outweighs its per-ray state traffic (5-9 %).
 static bool prefer_wavefront(const KParams& P, int flags) {
   (void)flags;
   if (P.u.renderMode == 1) return false;
-  if ((long long)P.tw * (long long)P.th < (1ll << 24)) return false;
+  if ((long long)P.tw * (long long)P.th < (1ll << 23)) return false;
   return P.scene.kind == RM_SCENE_TABLE && P.scene.nprims >= 16;
 }
 
@@ -750,8 +752,12 @@ static hipError_t launch_pixels_in_flight(rm_ctx* ctx, const KParams& P, int fla
   hipStream_t side = ctx->sp_stream[slot];
   // the render reads no plane: it only has to wait until the blend that last used this staging buffer is done
   if ((e = hipStreamWaitEvent(side, ctx->sp_free[slot], 0)) != hipSuccess) return e;
+  ctx->lpt[slot].launches = 0;
   if ((e = launch_pixels_ordered(ctx, Q, flags, side, slot)) != hipSuccess) return e;
   if ((e = hipEventRecord(ctx->sp_done[slot], side)) != hipSuccess) return e;
+  if (ctx->lpt[slot].launches > 0) {  // the launch recorded tile costs: sort them now, behind the completion event
+    if ((e = rm::launch_order(ctx->lpt[slot].cost, ctx->lpt[slot].order, (int)ctx->lpt[slot].launches, side)) != hipSuccess) return e;
+  }
   if ((e = hipStreamWaitEvent(ctx->stream, ctx->sp_done[slot], 0)) != hipSuccess) return e;
   if ((e = rm::launch_combine(Q, ctx->stream)) != hipSuccess) return e;
   return hipEventRecord(ctx->sp_free[slot], ctx->stream);
@@ -796,14 +802,14 @@ static hipError_t launch_pixels_ordered(rm_ctx* ctx, const KParams& P, int flags
   }
   KParams Q = P;
   if (!async_sort) {
+    // a sample-in-flight slot: the costs are sorted on the slot's own stream right AFTER the render (sort_slot_costs,
+    // called once the render's completion event is recorded), so the 15 us of the one-workgroup sort sit in the
+    // shadow of the other slots' renders instead of in front of this slot's next one
     Q.block_cost = L.cost;
-    if (L.have_cost) {
-      if ((e = rm::launch_order(L.cost, L.order, (int)tiles, stream)) != hipSuccess) return e;
-      Q.block_order = L.order;
-    } else {
-      if ((e = hipMemsetAsync(L.cost, 0, sizeof(unsigned int) * (size_t)tiles, stream)) != hipSuccess) return e;
-    }
+    if (L.have_cost) Q.block_order = L.order;
+    else if ((e = hipMemsetAsync(L.cost, 0, sizeof(unsigned int) * (size_t)tiles, stream)) != hipSuccess) return e;
     L.have_cost = true;
+    L.launches = (unsigned long long)tiles;  // what sort_slot_costs has to sort
     return fast ? rm::launch_pixels_fast(Q, stream) : rm::launch_pixels_strict(Q, stream);
   }
   if (!ctx->lpt_stream) {

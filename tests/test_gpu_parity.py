@@ -843,7 +843,7 @@ schema = J.make_schema(sc, W, H, counts=(48,), render_mode="full", position=(0, 
 noises = GC.halton_pairs(3)
 render_stream = torch.cuda.Stream(device=dev)  # not the default stream: its NULL handle means "own stream" to the library
 torch.cuda.set_stream(render_stream)
-g = rmdist.FrameGatherer(H, W, 1, 0, dev, force=True, ctx=ctx, payload=payload)
+g = rmdist.FrameGatherer(H, W, 1, 0, dev, force=True, ctx=ctx, payload=payload, side_stream=(sys.argv[3] == "side"))
 planes = [torch.zeros((g.max_rows, W, 4), dtype=torch.float32, device=dev) for _ in range(3)]
 ctx.set_stream(render_stream.cuda_stream)
 fb = ctx.create_striped_framebuffer(W, H, shard.STRIPE_ROWS, 1, 0, *(p.data_ptr() for p in planes))
@@ -853,7 +853,7 @@ for i, n in enumerate(noises):
     ctx.render_sample(h, fb, J.uniforms_from_schema(schema, n), None, abi.RM_RENDER_FAST)
     if g.pending is not None:
         f = g.finish()
-        torch.cuda.current_stream().wait_stream(g.aux)
+        torch.cuda.current_stream().wait_stream(g.stream())
         frames.append(f.clone())
     snaps.append(planes[0].clone())
     g.start(planes[0], dist, fb=fb, samples=i + 1)
@@ -863,7 +863,7 @@ for i, n in enumerate(noises):
     except AssertionError:
         pass
 f = g.finish()
-torch.cuda.current_stream().wait_stream(g.aux)
+torch.cuda.current_stream().wait_stream(g.stream())
 frames.append(f.clone())
 torch.cuda.synchronize()
 for i in range(3):
@@ -883,8 +883,8 @@ print(f"RCCL_ONE_RANK_OK {payload} {time.time() - t_start:.1f} s", flush=True)
 '''
 
 
-@pytest.mark.parametrize("payload", ["rgba8", "f32"])
-def test_frame_gatherer_over_rccl_one_rank(payload, tmp_path):
+@pytest.mark.parametrize("payload,streams", [("rgba8", "current"), ("f32", "current"), ("rgba8", "side")])
+def test_frame_gatherer_over_rccl_one_rank(payload, streams, tmp_path):
     """dist.FrameGatherer on the GPU over backend nccl (= RCCL) with the collective forced at world size 1: snapshot
     -> aux stream: gather, rm_assemble_striped(_bytes) -- overlapped with the next sample's render
     exactly as bench.py drives it, and the assembled frame is bit-identical to the planes / to rm_present.
@@ -900,7 +900,7 @@ def test_frame_gatherer_over_rccl_one_rank(payload, tmp_path):
     last = None
     for attempt in range(2):  # the library's start-up has been seen to stall once in a while on a shared box
         try:
-            last = subprocess.run([sys.executable, str(script), root, payload], capture_output=True, text=True, timeout=240, env=env)
+            last = subprocess.run([sys.executable, str(script), root, payload, streams], capture_output=True, text=True, timeout=240, env=env)
         except subprocess.TimeoutExpired as e:
             last = e
             continue

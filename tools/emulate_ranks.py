@@ -24,7 +24,7 @@ issue = torch.cuda.Stream()  # the stream the collective is enqueued from (dist.
 full = None
 for N in (1, 2, 4, 8):
     counts = shard.row_counts(H, N); max_rows = max(counts)
-    depth = 1 if N == 1 else 3
+    depth = 1 if N == 1 else int(os.environ.get("EMU_DEPTH", "4"))
     ctx.set_samples_in_flight(depth)
     recv = torch.zeros((N, max_rows, W, 4), dtype=torch.uint8, device=dev)
     frame = torch.empty((H, W, 4), dtype=torch.uint8, device=dev)
