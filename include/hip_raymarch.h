@@ -100,16 +100,25 @@ enum {
   RM_SCENE_KIND_COUNT = 7
 };
 
-enum { RM_PRIM_SPHERE = 0, RM_PRIM_BOX = 1 };
+/* Shapes, and the domain operators of the composition API: a domain row produces no distance, it
+ * transforms the point at which the FOLLOWING rows are evaluated (and the factor their distances are scaled by):
+ *   RM_PRIM_REPEAT  q = mod(q + 0.5 * period, period) - 0.5 * period         period = size[0..2] (> 0); the `repeat`
+ *                   of the reference's sphere-grid example (dist/examples/sphere-grid.glsl:42-49)
+ *   RM_PRIM_FOLD    q = abs(q / scale) - offset;  q = the three plane rotations by angles;  factor *= scale
+ *                   scale = k (> 0), offset = center[0..2], angles = size[0..2] (radians): one level of the
+ *                   reference's kaleidoscopic folds (examples/tree.glsl:24-32, rotation-fractal.glsl:21-29)
+ * A shape row contributes  shape(q) * factor. */
+enum { RM_PRIM_SPHERE = 0, RM_PRIM_BOX = 1, RM_PRIM_REPEAT = 2, RM_PRIM_FOLD = 3 };
 enum { RM_OP_UNION = 0, RM_OP_SMOOTH_UNION = 1, RM_OP_SUBTRACT = 2, RM_OP_INTERSECT = 3 };
 
 /* One row of the primitive table, 32 bytes.  The scene distance is the left
- * fold  d = prim[0];  d = op_i(d, prim[i])  for i = 1..n-1. */
+ * fold  d = shape[0];  d = op_i(d, shape[i])  over the shape rows, in table order
+ * (the operator of the first shape row is ignored); at least one row must be a shape. */
 typedef struct RmPrim {
   int32_t type; /* RM_PRIM_* in bits 0..7, RM_OP_* in bits 8..15 */
   float k;      /* smooth-union radius */
   float center[3];
-  float size[3]; /* sphere: size[0] = radius; box: half extents */
+  float size[3]; /* sphere: size[0] = radius; box: half extents; repeat: period; fold: angles */
 } RmPrim;
 
 /* parameter slots of RmSceneDesc.params per kind */

@@ -73,9 +73,11 @@ def gen_sdf(only=None):
         save(f"sdf_{name}", points=pts, sdf=g[..., 0].reshape(-1))
 
 
-def gen_cast():
+def gen_cast(only=None):
     w, h = GC.IMG_W, GC.IMG_H
     for name, (pos, steps) in GC.CAST.items():
+        if only and name not in only:
+            continue
         sc, text, uni = scene_text(name)
         rays = GC.camera_rays(pos, w, h)
         uni = dict(uni)

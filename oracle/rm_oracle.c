@@ -203,16 +203,37 @@ static float op_smooth_union(float d1, float d2, float k) {
   return gl_mix(d2, d1, h) - k * h * (1.0f - h);
 }
 
-/* RM_SCENE_TABLE: the GLSL the composer emits is the same left fold */
+/* RM_SCENE_TABLE: the GLSL the composer emits is the same left fold over the shape rows; domain rows
+ * (RM_PRIM_REPEAT, RM_PRIM_FOLD: include/hip_raymarch.h) transform the point the following rows see */
+static v3 kifs_rotate(v3 t, const float* ang);
 static float sdf_table(const RmSceneDesc* sc, v3 p) {
-  float d = 0.0f;
+  float d = 0.0f, factor = 1.0f;
+  int first = 1, domain = 0;
+  v3 q = p;
+  for (int i = 0; i < sc->nprims; i++) domain |= (sc->prims[i].type & 0xff) >= RM_PRIM_REPEAT;
   for (int i = 0; i < sc->nprims; i++) {
     const RmPrim* pr = &sc->prims[i];
     v3 c = V(pr->center[0], pr->center[1], pr->center[2]);
+    const int prim = pr->type & 0xff;
+    if (prim == RM_PRIM_REPEAT) {  /* dist/examples/sphere-grid.glsl:42-49 */
+      FL(3 * 6);
+      q = V(gl_mod(q.x + 0.5f * pr->size[0], pr->size[0]) - 0.5f * pr->size[0], gl_mod(q.y + 0.5f * pr->size[1], pr->size[1]) - 0.5f * pr->size[1],
+            gl_mod(q.z + 0.5f * pr->size[2], pr->size[2]) - 0.5f * pr->size[2]);
+      continue;
+    }
+    if (prim == RM_PRIM_FOLD) {  /* examples/tree.glsl:24-32 */
+      FL(3 + 3 + 1);
+      q = V(q.x / pr->k, q.y / pr->k, q.z / pr->k);
+      q = vsub(vabs(q), c);
+      q = kifs_rotate(q, pr->size);
+      factor = factor * pr->k;
+      continue;
+    }
     float di;
-    if ((pr->type & 0xff) == RM_PRIM_SPHERE) di = sdf_sphere(p, c, pr->size[0]);
-    else di = sd_box(vsub(p, c), V(pr->size[0], pr->size[1], pr->size[2]));
-    if (i == 0) { d = di; continue; }
+    if (prim == RM_PRIM_SPHERE) di = sdf_sphere(q, c, pr->size[0]);
+    else di = sd_box(vsub(q, c), V(pr->size[0], pr->size[1], pr->size[2]));
+    if (domain) { FL(1); di = di * factor; }
+    if (first) { d = di; first = 0; continue; }
     switch ((pr->type >> 8) & 0xff) {
       case RM_OP_UNION: d = gl_min(d, di); break;
       case RM_OP_SMOOTH_UNION: d = op_smooth_union(d, di, pr->k); break;

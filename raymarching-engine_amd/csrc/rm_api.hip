@@ -284,10 +284,11 @@ int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out) {
       std::snprintf(buf, sizeof buf, "scene: primitive table needs 1..%d rows (got %d)", RM_MAX_PRIMS, desc->nprims);
       return fail(ctx, RM_ERR_INVALID, buf);
     }
+    int shapes = 0;
     for (int i = 0; i < desc->nprims; i++) {
       const RmPrim& p = desc->prims[i];
       const int type = p.type & 0xff, op = (p.type >> 8) & 0xff;
-      if ((type != RM_PRIM_SPHERE && type != RM_PRIM_BOX) || op > RM_OP_INTERSECT || (p.type >> 16) != 0) {
+      if (type > RM_PRIM_FOLD || op > RM_OP_INTERSECT || (p.type >> 16) != 0) {
         std::snprintf(buf, sizeof buf, "scene: row %d: unknown primitive/operator 0x%x", i, p.type);
         return fail(ctx, RM_ERR_INVALID, buf);
       }
@@ -295,11 +296,22 @@ int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out) {
         std::snprintf(buf, sizeof buf, "scene: row %d: non-finite value", i);
         return fail(ctx, RM_ERR_INVALID, buf);
       }
-      if (op == RM_OP_SMOOTH_UNION && !(p.k > 0.0f) && i > 0) {
+      if (type == RM_PRIM_REPEAT && !(p.size[0] > 0.0f && p.size[1] > 0.0f && p.size[2] > 0.0f)) {
+        std::snprintf(buf, sizeof buf, "scene: row %d: repeat needs a period > 0 on every axis", i);
+        return fail(ctx, RM_ERR_INVALID, buf);
+      }
+      if (type == RM_PRIM_FOLD && !(p.k > 0.0f)) {
+        std::snprintf(buf, sizeof buf, "scene: row %d: fold needs scale > 0", i);
+        return fail(ctx, RM_ERR_INVALID, buf);
+      }
+      const bool shape = type == RM_PRIM_SPHERE || type == RM_PRIM_BOX;
+      if (shape && op == RM_OP_SMOOTH_UNION && !(p.k > 0.0f) && shapes > 0) {
         std::snprintf(buf, sizeof buf, "scene: row %d: smooth union needs k > 0", i);
         return fail(ctx, RM_ERR_INVALID, buf);
       }
+      shapes += shape ? 1 : 0;
     }
+    if (shapes == 0) return fail(ctx, RM_ERR_INVALID, "scene: the table has no shape row (sphere / box), only domain operators");
   } else if (desc->kind == RM_SCENE_MANDELBULB) {
     if (!(desc->params[RM_P_BULB_ITERATIONS] >= 0.0f && desc->params[RM_P_BULB_ITERATIONS] <= 64.0f))
       return fail(ctx, RM_ERR_INVALID, "scene: mandelbulb iterations must be in 0..64");
@@ -315,12 +327,13 @@ int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out) {
   s->dev.kind = desc->kind;
   s->dev.nprims = desc->kind == RM_SCENE_TABLE ? desc->nprims : 0;
   if (desc->kind == RM_SCENE_TABLE) {
-    bool spheres_smooth = true;
+    bool spheres_smooth = true, domain = false;
     for (int i = 0; i < desc->nprims; i++) {
       const int type = desc->prims[i].type & 0xff, op = (desc->prims[i].type >> 8) & 0xff;
       if (type != RM_PRIM_SPHERE || (i > 0 && op != RM_OP_SMOOTH_UNION)) spheres_smooth = false;
+      if (type == RM_PRIM_REPEAT || type == RM_PRIM_FOLD) domain = true;
     }
-    s->dev.table_flags = spheres_smooth ? RM_TABLE_SPHERES_SMOOTH : 0;
+    s->dev.table_flags = (spheres_smooth ? RM_TABLE_SPHERES_SMOOTH : 0) | (domain ? RM_TABLE_HAS_DOMAIN : 0);
   }
   std::memcpy(s->dev.p, desc->params, sizeof s->dev.p);
   s->dev.mat = desc->material;

@@ -313,20 +313,48 @@ struct Sdf<RM_SCENE_TABLE> {
     }
     return d;
   }
+  // one level of a kaleidoscopic fold (RM_PRIM_FOLD): the operations of tree.glsl:24-32 on the running point
+  template <class M>
+  static RM_DEV v3 fold_row(v3 q, float scale, v3 off, v3 ang) {
+    q = V(M::div(q.x, scale), M::div(q.y, scale), M::div(q.z, scale));
+    q = vabs(q) - off;
+    float c, s, nx, ny;
+    c = cosf(ang.x); s = sinf(ang.x);
+    nx = M::fma(q.y, -s, q.x * c); ny = M::fma(q.y, c, q.x * s); q.x = nx; q.y = ny;
+    c = cosf(ang.y); s = sinf(ang.y);
+    nx = M::fma(q.z, -s, q.y * c); ny = M::fma(q.z, c, q.y * s); q.y = nx; q.z = ny;
+    c = cosf(ang.z); s = sinf(ang.z);
+    nx = M::fma(q.z, -s, q.x * c); ny = M::fma(q.z, c, q.x * s); q.x = nx; q.z = ny;
+    return q;
+  }
   template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds& lds, v3 p) {
     if (M::fast && (sc.table_flags & RM_TABLE_SPHERES_SMOOTH)) return eval_spheres_smooth(sc, lds, p);
-    float d = 0.0f;
+    const bool domain = (sc.table_flags & RM_TABLE_HAS_DOMAIN) != 0;  // kernel-uniform
+    float d = 0.0f, factor = 1.0f;
+    bool first = true;
+    v3 q = p;
     const int n = sc.nprims;
     for (int i = 0; i < n; i++) {
       const float4 a = lds.rows[2 * i];      // type, k, cx, cy
       const float4 b = lds.rows[2 * i + 1];  // cz, sx, sy, sz
       const int type = __builtin_amdgcn_readfirstlane(__float_as_int(a.x));
       const v3 c = V(a.z, a.w, b.x);
+      const int prim = type & 0xff;
+      if (domain && prim == RM_PRIM_REPEAT) {  // q = mod(q + 0.5 * period, period) - 0.5 * period
+        q = V(gmod<M>(q.x + 0.5f * b.y, b.y) - 0.5f * b.y, gmod<M>(q.y + 0.5f * b.z, b.z) - 0.5f * b.z, gmod<M>(q.z + 0.5f * b.w, b.w) - 0.5f * b.w);
+        continue;
+      }
+      if (domain && prim == RM_PRIM_FOLD) {
+        q = fold_row<M>(q, a.y, c, V(b.y, b.z, b.w));
+        factor = factor * a.y;
+        continue;
+      }
       float di;
-      if ((type & 0xff) == RM_PRIM_SPHERE) di = sdf_sphere<M>(p, c, b.y);
-      else di = sd_box<M>(p - c, V(b.y, b.z, b.w));
-      if (i == 0) { d = di; continue; }
+      if (prim == RM_PRIM_SPHERE) di = sdf_sphere<M>(q, c, b.y);
+      else di = sd_box<M>(q - c, V(b.y, b.z, b.w));
+      if (domain) di = di * factor;
+      if (first) { d = di; first = false; continue; }
       const int op = (type >> 8) & 0xff;
       if (op == RM_OP_UNION) d = gmin(d, di);
       else if (op == RM_OP_SMOOTH_UNION) d = op_smooth_union<M>(d, di, a.y);

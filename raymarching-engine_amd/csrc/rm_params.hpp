@@ -7,6 +7,7 @@
 
 // table_flags of DevScene (set by rm_scene_create)
 #define RM_TABLE_SPHERES_SMOOTH 1  /* every row is a sphere and every fold after the first a smooth union */
+#define RM_TABLE_HAS_DOMAIN 2      /* the table has domain rows (RM_PRIM_REPEAT / RM_PRIM_FOLD) */
 
 struct DevScene {
   int kind;

@@ -14,6 +14,8 @@ export class CsgScene extends Scene {
   constructor(material?: Partial<Material>);
   union(): this; smoothUnion(k: number): this; subtract(): this; intersect(): this;
   sphere(center: Vec3, radius: number): this; box(center: Vec3, halfExtents: Vec3): this;
+  /** domain operators: transform the point the FOLLOWING primitives are evaluated at (sphere-grid.glsl's repeat; one level of tree.glsl's fold) */
+  repeat(period: Vec3): this; fold(scale: number, offset: Vec3, angles?: Vec3): this;
   glsl(): string;
 }
 export class Mandelbulb extends Scene { constructor(power?: number, iterations?: number, bailout?: number, material?: Partial<Material>); }

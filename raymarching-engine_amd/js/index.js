@@ -16,7 +16,7 @@ const addon = require("./rm_napi.node");
 const RM = {
   MAX_BOUNCES: 10, MAX_LIGHTS: 10,
   SCENE_TABLE: 0, SCENE_MANDELBULB: 1, SCENE_SPHERE_GRID: 2, SCENE_SPHERE_LATTICE: 3, SCENE_MENGER: 4, SCENE_KIFS_TREE: 5, SCENE_KIFS_BOX: 6,
-  PRIM_SPHERE: 0, PRIM_BOX: 1, OP_UNION: 0, OP_SMOOTH_UNION: 1, OP_SUBTRACT: 2, OP_INTERSECT: 3,
+  PRIM_SPHERE: 0, PRIM_BOX: 1, PRIM_REPEAT: 2, PRIM_FOLD: 3, OP_UNION: 0, OP_SMOOTH_UNION: 1, OP_SUBTRACT: 2, OP_INTERSECT: 3,
   RENDER_STRICT: 0, RENDER_FAST: 1, RENDER_COLOR_ONLY: 2, RENDER_MEGAKERNEL: 4,
 };
 
@@ -84,14 +84,30 @@ class CsgScene extends Scene {
   intersect() { this._op = RM.OP_INTERSECT; this._k = 0; return this; }
   sphere(center, radius) { this.prims.push({ prim: RM.PRIM_SPHERE, op: this._op, k: this._k, center, size: [radius, 0, 0] }); return this; }
   box(center, half) { this.prims.push({ prim: RM.PRIM_BOX, op: this._op, k: this._k, center, size: half }); return this; }
+  // domain operators (include/hip_raymarch.h): they transform the point the FOLLOWING primitives are evaluated at
+  repeat(period) { this.prims.push({ prim: RM.PRIM_REPEAT, op: 0, k: 0, center: [0, 0, 0], size: period }); return this; }
+  fold(scale, offset, angles = [0, 0, 0]) { this.prims.push({ prim: RM.PRIM_FOLD, op: 0, k: scale, center: offset, size: angles }); return this; }
   glsl() {  // the reference's scene contract: float sdf(vec3); helpers sdfSphere/sdBox come from raymarcher.frag:74,108
     const lines = [];
-    if (this.prims.slice(1).some((p) => p.op === RM.OP_SMOOTH_UNION))
+    const isShape = (n) => n.prim === RM.PRIM_SPHERE || n.prim === RM.PRIM_BOX;
+    const shapes = this.prims.filter(isShape), domain = shapes.length !== this.prims.length;
+    if (shapes.slice(1).some((p) => p.op === RM.OP_SMOOTH_UNION))
       lines.push("float rmSmoothUnion(float d1, float d2, float k) { float h = clamp(0.5 + 0.5 * (d2 - d1) / k, 0.0, 1.0); return mix(d2, d1, h) - k * h * (1.0 - h); }");
+    if (this.prims.some((n) => n.prim === RM.PRIM_FOLD))
+      lines.push("vec3 rmFold(vec3 q, float scale, vec3 off, vec3 ang) { q = q / scale; q = abs(q) - off; float c; float s; float nx; float ny;" +
+        " c = cos(ang.x); s = sin(ang.x); nx = q.x * c + q.y * -s; ny = q.x * s + q.y * c; q.x = nx; q.y = ny;" +
+        " c = cos(ang.y); s = sin(ang.y); nx = q.y * c + q.z * -s; ny = q.y * s + q.z * c; q.y = nx; q.z = ny;" +
+        " c = cos(ang.z); s = sin(ang.z); nx = q.x * c + q.z * -s; ny = q.x * s + q.z * c; q.x = nx; q.z = ny; return q; }");
     lines.push("float sdf(vec3 p) {");
-    this.prims.forEach((n, i) => {
-      const e = n.prim === RM.PRIM_SPHERE ? `sdfSphere(p, ${glv(n.center)}, ${glf(n.size[0])})` : `sdBox(p - ${glv(n.center)}, ${glv(n.size)})`;
-      if (i === 0) lines.push(`  float d = ${e};`);
+    const q = domain ? "q" : "p";
+    if (domain) lines.push("  vec3 q = p; float factor = 1.0; float d;");
+    let first = true;
+    this.prims.forEach((n) => {
+      if (n.prim === RM.PRIM_REPEAT) { lines.push(`  q = mod(q + 0.5 * ${glv(n.size)}, ${glv(n.size)}) - 0.5 * ${glv(n.size)};`); return; }
+      if (n.prim === RM.PRIM_FOLD) { lines.push(`  q = rmFold(q, ${glf(n.k)}, ${glv(n.center)}, ${glv(n.size)}); factor = factor * ${glf(n.k)};`); return; }
+      let e = n.prim === RM.PRIM_SPHERE ? `sdfSphere(${q}, ${glv(n.center)}, ${glf(n.size[0])})` : `sdBox(${q} - ${glv(n.center)}, ${glv(n.size)})`;
+      if (domain) e = `(${e} * factor)`;
+      if (first) { lines.push(domain ? `  d = ${e};` : `  float d = ${e};`); first = false; }
       else if (n.op === RM.OP_UNION) lines.push(`  d = min(d, ${e});`);
       else if (n.op === RM.OP_SMOOTH_UNION) lines.push(`  d = rmSmoothUnion(d, ${e}, ${glf(n.k)});`);
       else if (n.op === RM.OP_SUBTRACT) lines.push(`  d = max(d, -${e});`);

@@ -20,6 +20,12 @@ const rm = require("./index.js");
     fs.writeFileSync(out, rm.encodePng(px, w, h));
     return;
   }
+  if (mode === "domain") {  // no GPU needed: a scene with the domain operators, as the table and as GLSL
+    const sc = new rm.CsgScene().repeat([3, 3, 3]).fold(0.8, [0.5, 0.2, 0.3], [0.3, -0.2, 0.1]).box([0, 0, 0], [0.4, 0.3, 0.2]).smoothUnion(0.15).sphere([0.3, 0.1, 0], 0.25);
+    const d = sc.desc();
+    process.stdout.write(JSON.stringify({ prims: Buffer.from(d.prims).toString("hex"), glsl: sc.glsl() }));
+    return;
+  }
   if (mode === "layout") {  // no GPU needed: the uniform block bytes and the scene description
     const u = rm.uniformsFromSchema(schema, [0.5, 1 / 3]);
     const d = schema.sdfScene.desc();

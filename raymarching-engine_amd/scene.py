@@ -163,6 +163,15 @@ class CsgScene(Scene):
     ``intersect()``, ``union()`` select the operator for the primitives that
     follow.  The smooth union is the polynomial smooth-min of
     examples/smooth-tree.glsl:20-22.
+
+    Domain operators transform the point at which the primitives
+    that FOLLOW them are evaluated: ``repeat(period)`` tiles space like the
+    ``repeat`` of the reference's sphere-grid example
+    (dist/examples/sphere-grid.glsl:42-49), ``fold(scale, offset, angles)`` is one
+    level of its kaleidoscopic folds (examples/tree.glsl:24-32: divide by the
+    scale, mirror, shift, three plane rotations; the distances of the following
+    primitives are multiplied back by the scale).  They compose: several folds
+    in a row give the levels of a KIFS fractal over any primitives.
     """
 
     kind = abi.RM_SCENE_TABLE
@@ -197,6 +206,16 @@ class CsgScene(Scene):
         self._nodes.append(_Node(abi.RM_PRIM_BOX, self._op, self._k, tuple(center), tuple(half_extents)))
         return self
 
+    def repeat(self, period: Sequence[float]):
+        """q = mod(q + period / 2, period) - period / 2 for the primitives that follow; every period > 0."""
+        self._nodes.append(_Node(abi.RM_PRIM_REPEAT, 0, 0.0, (0.0, 0.0, 0.0), tuple(float(v) for v in period)))
+        return self
+
+    def fold(self, scale: float, offset: Sequence[float], angles: Sequence[float] = (0.0, 0.0, 0.0)):
+        """q = abs(q / scale) - offset, then the rotations in the xy, yz and xz planes by `angles` (radians)."""
+        self._nodes.append(_Node(abi.RM_PRIM_FOLD, 0, float(scale), tuple(float(v) for v in offset), tuple(float(v) for v in angles)))
+        return self
+
     def prims(self) -> List[abi.RmPrim]:
         out = []
         for n in self._nodes:
@@ -209,23 +228,48 @@ class CsgScene(Scene):
         return out
 
     def sdf_glsl(self) -> str:
-        if not self._nodes:
-            raise ValueError("empty CSG scene")
+        shapes = [n for n in self._nodes if n.prim in (abi.RM_PRIM_SPHERE, abi.RM_PRIM_BOX)]
+        if not shapes:
+            raise ValueError("a CSG scene needs at least one sphere or box")
+        domain = len(shapes) != len(self._nodes)
         lines = []
-        if any(n.op == abi.RM_OP_SMOOTH_UNION for n in self._nodes[1:]):
+        if any(n.op == abi.RM_OP_SMOOTH_UNION for n in shapes[1:]):
             lines.append(
                 "float rmSmoothUnion(float d1, float d2, float k) {"
                 " float h = clamp(0.5 + 0.5 * (d2 - d1) / k, 0.0, 1.0);"
                 " return mix(d2, d1, h) - k * h * (1.0 - h); }"
             )
+        if any(n.prim == abi.RM_PRIM_FOLD for n in self._nodes):
+            lines.append(  # scalar by scalar, in the order of the oracle / the kernel (tree.glsl:24-32 writes it with mat2)
+                "vec3 rmFold(vec3 q, float scale, vec3 off, vec3 ang) {"
+                " q = q / scale; q = abs(q) - off; float c; float s; float nx; float ny;"
+                " c = cos(ang.x); s = sin(ang.x); nx = q.x * c + q.y * -s; ny = q.x * s + q.y * c; q.x = nx; q.y = ny;"
+                " c = cos(ang.y); s = sin(ang.y); nx = q.y * c + q.z * -s; ny = q.y * s + q.z * c; q.y = nx; q.z = ny;"
+                " c = cos(ang.z); s = sin(ang.z); nx = q.x * c + q.z * -s; ny = q.x * s + q.z * c; q.x = nx; q.z = ny;"
+                " return q; }"
+            )
         lines.append("float sdf(vec3 p) {")
-        for i, n in enumerate(self._nodes):
+        q = "p"
+        if domain:
+            lines.append("  vec3 q = p; float factor = 1.0; float d;")
+            q = "q"
+        first = True
+        for n in self._nodes:
+            if n.prim == abi.RM_PRIM_REPEAT:
+                lines.append(f"  q = mod(q + 0.5 * {_v3(n.size)}, {_v3(n.size)}) - 0.5 * {_v3(n.size)};")
+                continue
+            if n.prim == abi.RM_PRIM_FOLD:
+                lines.append(f"  q = rmFold(q, {_f(n.k)}, {_v3(n.center)}, {_v3(n.size)}); factor = factor * {_f(n.k)};")
+                continue
             if n.prim == abi.RM_PRIM_SPHERE:
-                e = f"sdfSphere(p, {_v3(n.center)}, {_f(n.size[0])})"
+                e = f"sdfSphere({q}, {_v3(n.center)}, {_f(n.size[0])})"
             else:
-                e = f"sdBox(p - {_v3(n.center)}, {_v3(n.size)})"
-            if i == 0:
-                lines.append(f"  float d = {e};")
+                e = f"sdBox({q} - {_v3(n.center)}, {_v3(n.size)})"
+            if domain:
+                e = f"({e} * factor)"
+            if first:
+                lines.append(f"  d = {e};" if domain else f"  float d = {e};")
+                first = False
             elif n.op == abi.RM_OP_UNION:
                 lines.append(f"  d = min(d, {e});")
             elif n.op == abi.RM_OP_SMOOTH_UNION:

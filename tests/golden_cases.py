@@ -40,6 +40,20 @@ SCENES = {
         .intersect().sphere((0, 0, 0), 1.6),
         None,
     ),
+    # the composition API's domain operators: space tiled with period 3, one mirror fold (no rotation: + - * / abs floor
+    # only, so bit-exact), a box smooth-joined with a sphere in every cell
+    "csg_repeat_fold": (
+        lambda: S.CsgScene().repeat((3.0, 3.0, 3.0)).fold(0.8, (0.5, 0.2, 0.3)).box((0, 0, 0), (0.4, 0.3, 0.2))
+        .smooth_union(0.15).sphere((0.3, 0.1, 0.0), 0.25),
+        None,
+    ),
+    # folds with and without rotations over a box and a sphere: a small KIFS fractal composed from table rows (the rotated
+    # level goes through sin / cos of the angles)
+    "csg_kifs": (
+        lambda: S.CsgScene().fold(0.7, (1.2, 0.12, 0.12)).fold(0.7, (1.2, 0.12, 0.12), (2.9, -0.8, 0.4))
+        .box((0, 0, 0), (1.0, 0.1, 0.1)).union().sphere((0.0, 0.0, 0.0), 0.3),
+        None,
+    ),
     "mandelbulb": (lambda: S.Mandelbulb(), None),
     "lattice": (lambda: S.sphere_lattice_example(), None),
     "fractal1": (lambda: S.SphereGridFractal(), "fractal1.glsl"),
@@ -52,7 +66,7 @@ SCENES = {
 # scenes whose SDF the oracle reproduces bit for bit (only + - * / sqrt floor
 # abs min max); the others go through sin/cos/acos/atan/pow/log where
 # SwiftShader and libm differ in the last bits (or much more: see test tolerances)
-SDF_BIT_EXACT = ("sphere", "csg64", "csg_mixed", "lattice", "fractal1")
+SDF_BIT_EXACT = ("sphere", "sphere_sss", "csg64", "csg_mixed", "csg_repeat_fold", "lattice", "fractal1")
 
 IMG_W, IMG_H = 64, 32
 
@@ -86,6 +100,8 @@ IMAGES = {
     "tree_full_2b": ("tree", 1, dict(render_mode="full", position=(0, 0, -6.0), counts=(48, 24), lights=LIGHT)),
     "smooth_tree_full_2b": ("smooth_tree", 1, dict(render_mode="full", position=(0, 0, -6.0), counts=(48, 24), lights=LIGHT)),
     "rotation_fractal_full_2b": ("rotation_fractal", 1, dict(render_mode="full", position=(0, 0, -4.0), counts=(48, 24), lights=LIGHT)),
+    "csg_repeat_fold_full_2b": ("csg_repeat_fold", 1, dict(render_mode="full", position=(0.2, 0.1, -1.4), counts=(48, 24), lights=LIGHT)),
+    "csg_kifs_full_2b": ("csg_kifs", 1, dict(render_mode="full", position=(0.3, 0.2, -2.2), counts=(48, 24), lights=LIGHT)),
 }
 
 # cast-ray goldens: scene -> (camera position, steps)
@@ -96,6 +112,7 @@ CAST = {
     "fractal1": ((0, 0, 0), 64.0),
     "mandelbulb": ((0, 0, -2.5), 64.0),
     "menger": ((0.5, 0.5, -2.0), 48.0),
+    "csg_repeat_fold": ((0.2, 0.1, -1.4), 48.0),
 }
 
 

@@ -46,6 +46,20 @@ def test_js_layouts_match_the_c_abi():
     assert out["halton3"] == [next(g), next(g), next(g)]
 
 
+def test_js_domain_operators_match_the_python_composer():
+    """repeat / fold (the composition API's domain operators): the JS composer lays out the same table rows and the
+    same GLSL statements as the Python one."""
+    out = json.loads(subprocess.run(["node", str(JS / "render_cli.js"), "-", "domain"], capture_output=True, text=True, check=True).stdout)
+    sc = S.CsgScene().repeat((3, 3, 3)).fold(0.8, (0.5, 0.2, 0.3), (0.3, -0.2, 0.1)).box((0, 0, 0), (0.4, 0.3, 0.2)).smooth_union(0.15).sphere((0.3, 0.1, 0), 0.25)
+    import ctypes as C
+
+    d = sc.desc()
+    assert out["prims"] == bytes(C.string_at(d.prims, 32 * d.nprims)).hex()
+    norm = lambda t: [ln.split("(")[0].strip() for ln in t.splitlines()]
+    assert norm(out["glsl"]) == norm(sc.glsl())
+    assert "rmFold(q," in out["glsl"] and "mod(q + 0.5 *" in out["glsl"] and "* factor)" in out["glsl"]
+
+
 def test_js_png_writer(tmp_path):
     """encodePng of the JS host writes the same picture as the Python writer reads: same
     container rules (RGBA8, filter 0, rows flipped to top-down)."""
