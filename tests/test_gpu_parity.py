@@ -912,3 +912,29 @@ def test_frame_gatherer_over_rccl_one_rank(payload, streams, tmp_path):
     out = getattr(last, "stdout", "") or ""
     err = getattr(last, "stderr", "") or ""
     pytest.fail(f"RCCL one-rank run failed or timed out:\n{str(out)[-1500:]}\n{str(err)[-1500:]}")
+
+
+def test_bench_under_the_drivers_launcher_with_one_rank(tmp_path):
+    """bench.py started the way the driver starts its N > 1 runs -- python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ... -- with N = 1 and the RCCL path
+    forced (this box has one GPU): rendezvous from the launcher's environment, render, present rows, gather, assemble,
+    one JSON line with n_gpus = N on stdout."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RM_BENCH_FORCE_DIST="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["steps"] == 4 and out["warmup"] == 2 and out["value"] > 100.0
+    assert "gathered to rank 0 over RCCL" in out["config"]["sharding"] and out["roofline"]["frac"] > 0.2
