@@ -334,8 +334,17 @@ int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out) {
       if (type == RM_PRIM_REPEAT || type == RM_PRIM_FOLD) domain = true;
     }
     s->dev.table_flags = (spheres_smooth ? RM_TABLE_SPHERES_SMOOTH : 0) | (domain ? RM_TABLE_HAS_DOMAIN : 0);
+    if (spheres_smooth && desc->nprims >= 2 && desc->nprims * 3 <= RM_MAX_PRIMS * 2) {  // one smooth-union radius for the whole table (the usual case): it travels as a kernel argument, and a compact image of the rows fits behind them in LDS
+      bool one_k = true;
+      for (int i = 2; i < desc->nprims; i++) one_k = one_k && desc->prims[i].k == desc->prims[1].k;
+      if (one_k) s->dev.table_flags |= RM_TABLE_UNIFORM_K;
+    }
   }
   std::memcpy(s->dev.p, desc->params, sizeof s->dev.p);
+  if (s->dev.table_flags & RM_TABLE_UNIFORM_K) {
+    s->dev.p[0] = desc->prims[1].k;
+    s->dev.p[1] = 0.5f * (1.0f / desc->prims[1].k);  // the bits the kernel's staging computes per row otherwise
+  }
   s->dev.mat = desc->material;
   (void)hipSetDevice(ctx->device);
   if (s->dev.nprims > 0) {
@@ -717,10 +726,10 @@ static hipError_t launch_wavefront(rm_ctx* ctx, const KParams& P, int flags) {
 // Which implementation of the per-pixel program runs a job (same results either way).
 // Measured on MI355X in round 2 (bench.py --workload ..., fast build, ms per sample, pixel kernel / wavefront pipeline):
 //   Mandelbulb 3840x2160 full      2.49 / 4.5         sphere 1080p preview 0.11 / 1.4
-//   CSG-64 4096x512  (2 Mpx)       7.76 / 8.94        CSG-64 4096x4096 (16.8 Mpx)  53.4 / 48.5
-//   CSG-64 8192x1024 (8.4 Mpx)     68.8 / 65.4        CSG-64 8192x8192 (67 Mpx)    531  / 496
+//   CSG-64 4096x512  (2 Mpx)       6.79 / 7.67        CSG-64 4096x4096 (16.8 Mpx)  47.0 / 40.6
+//   CSG-64 8192x1024 (8.4 Mpx)     60.5 / 54.6        CSG-64 8192x8192 (67 Mpx)    467  / 415
 // The one-kernel form wins everywhere except on large full-mode frames of long primitive tables, where the pipeline's
-// global ray compaction over very many long, uniform evaluations outweighs its per-ray state traffic (5-9 %).
+// global ray compaction over very many long, uniform evaluations outweighs its per-ray state traffic (10-16 %).
 static bool prefer_wavefront(const KParams& P, int flags) {
   (void)flags;
   if (P.u.renderMode == 1) return false;
