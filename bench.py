@@ -12,13 +12,18 @@ it fails loudly when fewer than N GPUs are visible.  Under a launcher
 equal --gpus.
 
 A step = one sample of every pixel of the frame (one run of the reference's
-main() per pixel: RenderJobExecutor.tsx:299) + presenting it: with N GPUs the
-frame's rows are sharded in 8-row stripes dealt round-robin (no exchange between
-samples; each pixel depends only on itself); every rank
+main() per pixel: RenderJobExecutor.tsx:299).  With N GPUs the frame's rows are
+sharded in 8-row stripes dealt round-robin (no exchange between samples; each
+pixel depends only on itself) and the job presents as the
+reference's does, every render.sampleYieldInterval samples
+(RenderJobExecutor.tsx:163; --yield-interval, 8 when sharded): every rank
 tone-maps its stripes (display.frag with depth of field off, rm_present_rows)
-and the RGBA8 rows are gathered to rank 0 over RCCL once per step and put back
-in image order, as the reference presents once per sample in its live loop
-(index.tsx:158-169).  Total work is fixed => strong scaling.
+and the RGBA8 rows are gathered to rank 0 over RCCL and put back in image order
+-- one gather per presented frame, overlapped with the render
+of the next samples; the samples between two yields go to the library in one
+rm_render_samples call.  --yield-interval 1 presents and gathers after every
+sample, like the live loop (index.tsx:158-169).  Total work is fixed => strong
+scaling.
 
 Rank 0 prints ONE JSON line.  `roofline` is the fp32-VALU roofline of the
 pixel kernel (the path has no contraction, so no MFMA; HBM traffic is ~100 B
@@ -175,6 +180,11 @@ def main():
                     help="consecutive samples that may overlap on one GPU (rm_ctx_set_samples_in_flight); default: 1 on one GPU, "
                          "so that a kernel's duration in a rocprofv3 trace is the time of a step, 4 when the frame is sharded "
                          "(a shard's launch is too small to fill the chip: a ray is a ~1 ms serial chain)")
+    ap.add_argument("--yield-interval", type=int, default=0,
+                    help="render.sampleYieldInterval of the job (RenderJobExecutor.tsx:163): a frame is presented -- and, when "
+                         "sharded, gathered -- every this many samples; the samples in between go to the library in one "
+                         "rm_render_samples call.  Default: 1 on one GPU (the live loop's value, index.tsx:166), 8 when the "
+                         "frame is sharded")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -227,7 +237,10 @@ def main():
     ctx.set_stream(render_stream.cuda_stream)
     # measured on one GPU standing in for a rank (tools/dbg/depth_sweep.py, ms per sample of a rank's stripes, depth 1/2/3/4/6):
     # whole frame 2.48/2.57/2.55/2.51/2.51, 1/2 of it 1.45/1.32/1.31/1.29/1.28, 1/4 0.88/0.70/0.70/0.68/0.66, 1/8 0.58/0.41/0.46/0.37/0.36
-    in_flight = args.in_flight if args.in_flight > 0 else (1 if world == 1 else 4)
+    # sharded, the job yields every 8 samples: a rank's 8 samples go out as ONE launch of a full frame's worth of workgroups
+    # (rm_render_samples, rm_ctx_set_sample_batch), two such launches in flight, one present + gather per yield
+    yield_interval = args.yield_interval if args.yield_interval > 0 else (1 if world == 1 else 8)
+    in_flight = args.in_flight if args.in_flight > 0 else (1 if world == 1 else 4 if yield_interval == 1 else 2)
     ctx.set_samples_in_flight(in_flight)
     tile = None
     rows_window = None
@@ -251,16 +264,27 @@ def main():
     u_step = J.uniforms_from_schema(schema, (0.5, 1.0 / 3.0))  # only randNoise changes from sample to sample
     samples = [0]
 
+    def run(n):
+        # n samples of the job: `yield_interval` of them at a time (one rm_render_samples call), then -- sharded -- the
+        # gather of the presented rows (a snapshot) is started; it runs over RCCL while the next samples render, and
+        # the frame is assembled on rank 0 before the next gather starts
+        done = 0
+        while done < n:
+            k = min(yield_interval, n - done)
+            if k == 1:
+                u_step.randNoise[0], u_step.randNoise[1] = next(h2), next(h3)
+                ctx.render_sample(scene, fb, u_step, tile, flags)
+            else:
+                ctx.render_samples(scene, fb, u_step, [(next(h2), next(h3)) for _ in range(k)], tile, flags)
+            done += k
+            samples[0] += k
+            if sharded:
+                if gatherer.pending is not None:
+                    gatherer.finish()
+                gatherer.start(planes[0], dist, fb=fb, samples=samples[0])
+
     def step():
-        # render sample n, then start the gather of its presented rows (a snapshot); the gather runs over RCCL
-        # while sample n+1 renders, and frame n is assembled on rank 0 at the start of step n+1
-        u_step.randNoise[0], u_step.randNoise[1] = next(h2), next(h3)
-        ctx.render_sample(scene, fb, u_step, tile, flags)
-        samples[0] += 1
-        if sharded:
-            if gatherer.pending is not None:
-                gatherer.finish()
-            gatherer.start(planes[0], dist, fb=fb, samples=samples[0])
+        run(1)
 
     def drain():
         if sharded and gatherer.pending is not None:
@@ -268,16 +292,14 @@ def main():
         if sharded and gatherer.aux is not None:
             torch.cuda.current_stream().wait_stream(gatherer.aux)  # the last frame is assembled before the clock stops (side-stream mode)
 
-    for _ in range(args.warmup):
-        step()
+    run(args.warmup)
     drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    drain()  # the last frame is assembled inside the timed region: K samples rendered, K frames assembled
+    run(args.steps)
+    drain()  # the last frame is assembled inside the timed region: K samples rendered, ceil(K / yield_interval) frames assembled
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -355,10 +377,11 @@ def main():
             "config": {"workload": wl["name"], "build": "strict" if args.strict else "fast",
                        "rows_per_gpu": row_count if rows_window is None else rows_window[1] - rows_window[0],
                        "pipeline": "megakernel" if args.megakernel else "wavefront" if args.wavefront else auto,
-                       "sharding": (f"{shard.STRIPE_ROWS}-row stripes round-robin over ranks; every step each rank tone-maps its rows "
-                                    f"and the {payload} rows are gathered to rank 0 over RCCL (overlapped with the next sample's render) and put back in image order")
+                       "sharding": (f"{shard.STRIPE_ROWS}-row stripes round-robin over ranks; every {yield_interval} sample(s) (render.sampleYieldInterval) each rank "
+                                    f"tone-maps its rows and the {payload} rows are gathered to rank 0 over RCCL (overlapped with the next samples' render) and put back in image order")
                        if sharded else "none",
-                       "planes": "color+normal_dof+albedo_depth fp32, accumulated in place", "samples_in_flight": in_flight},
+                       "planes": "color+normal_dof+albedo_depth fp32, accumulated in place", "samples_in_flight": in_flight,
+                       "sample_yield_interval": yield_interval},
             "roofline": roof, "cpu_baseline": cpu, "overlap": overlap,
         }
     fb.destroy()

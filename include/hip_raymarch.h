@@ -219,6 +219,14 @@ int rm_ctx_set_stream(rm_ctx* ctx, void* hip_stream);
  * there afterwards sees the sample blended.  The planes receive the same bits as without overlap.  Costs 3 planes
  * of staging per sample in flight. */
 int rm_ctx_set_samples_in_flight(rm_ctx* ctx, int n);
+/* Samples per launch of rm_render_samples (default 0 = automatic, 1 = one launch per sample, 2..8 = fixed).  A small
+ * window -- one GPU's rows of a sharded frame -- has too few workgroups to keep the chip busy to the end of a launch
+ * (a ray is a serial chain of ~1 ms); rm_render_samples therefore renders up to 8 consecutive samples of the job in
+ * ONE launch, a workgroup per (tile, sample), each sample staged separately and blended into the planes in sample
+ * order by one small kernel -- the same bits as one launch per sample.  Automatic = as many as bring the launch to
+ * about 16 384 workgroups (a whole 3840x2160 frame has 16 320, so whole frames are not batched).  Costs 3 planes of
+ * staging per sample of a batch (times the samples in flight). */
+int rm_ctx_set_sample_batch(rm_ctx* ctx, int n);
 /* Cost-ordered dispatch (default on; environment RM_COST_ORDER=0 turns it off).  From the second sample of a job on
  * (same framebuffer window, tile and scene kind, >= 512 workgroups), the pixel kernel starts its tiles in the order of
  * their cost in the previous sample, most expensive first, so that a launch does not end on a few late, long
@@ -303,7 +311,11 @@ int rm_render_sample(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* 
                      const RmRect* tile, int flags);
 
 /* `count` samples back to back, sample i using randNoise[i] (pairs); every
- * other uniform as given.  Same as `count` calls of rm_render_sample. */
+ * other uniform as given: the sample loop of a render job
+ * (RenderJobExecutor.tsx:160-222 -- only randNoise changes from sample to
+ * sample).  Same planes, bit for bit, as `count` calls of rm_render_sample;
+ * full-mode samples of the pixel kernel go out several to a launch (see
+ * rm_ctx_set_sample_batch). */
 int rm_render_samples(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* uniforms,
                       const float* rand_noise_pairs, int count, const RmRect* tile, int flags);
 

@@ -53,6 +53,10 @@ struct rm_ctx {
   hipEvent_t sp_done[RM_SP_MAX] = {}, sp_free[RM_SP_MAX] = {};
   float4* sp_stage[RM_SP_MAX] = {};
   size_t sp_capacity = 0;  // float4 elements per staged plane
+  int sp_batch_cap = 1;    // samples a slot's staging buffer holds (3 * sp_capacity elements each)
+  // Sample batch of rm_render_samples (KParams::batch): 0 = as many samples per launch as bring it to about
+  // RM_BATCH_TARGET_TILES workgroups (a whole 4K frame has 16 320), 1 = one launch per sample, 2..RM_BATCH_MAX = fixed.
+  int sample_batch = 0;
   unsigned int sp_next = 0;
   bool sp_ready = false;
   // Cost-ordered dispatch of the pixel kernel when samples run one at a time: the tiles of a job in the order of their
@@ -556,10 +560,14 @@ static int build_params(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniform
   P->retire_eps = (flags & RM_RENDER_FAST) ? ctx->retire_eps : 0.0f;
   P->stage = nullptr;
   P->stage_stride = 0;
+  P->batch = 0;
+  std::memset(P->batch_noise, 0, sizeof P->batch_noise);
   P->block_order = nullptr;
   P->block_cost = nullptr;
   return RM_OK;
 }
+
+#define RM_BATCH_TARGET_TILES 16384ll  // workgroups a batch launch of rm_render_samples aims for
 
 #define RM_MAX_MARCHES (RM_MAX_BOUNCES * (1 + RM_MAX_LIGHTS))
 #define RM_COUNTERS_PER_MARCH 8  // queue heads and parked counts of the launches of one march
@@ -739,8 +747,9 @@ static bool prefer_wavefront(const KParams& P, int flags) {
 
 static hipError_t launch_pixels_ordered(rm_ctx* ctx, const KParams& P, int flags, hipStream_t stream, int slot);
 
-// The pixel kernel of one sample on a side stream, staged, and its blend on the context's stream (see rm_ctx).
-static hipError_t launch_pixels_in_flight(rm_ctx* ctx, const KParams& P, int flags) {
+// The pixel kernel of one sample -- or of a batch of `batch` samples, randNoise pairs in `noise` -- on a side stream,
+// staged, and its blend on the context's stream (see rm_ctx).
+static hipError_t launch_pixels_in_flight(rm_ctx* ctx, const KParams& P, int flags, int batch = 1, const float* noise = nullptr) {
   hipError_t e;
   const int depth = ctx->samples_in_flight;
   // side streams are made as the depth asks for them, not all RM_SP_MAX at once: the HIP runtime deals a process's streams
@@ -753,24 +762,31 @@ static hipError_t launch_pixels_in_flight(rm_ctx* ctx, const KParams& P, int fla
   }
   ctx->sp_ready = true;
   const size_t need = (size_t)(P.ty + P.th) * (size_t)P.W;  // staged values sit at the plane index of their pixel
-  if (ctx->sp_capacity < need) {
+  if (ctx->sp_capacity < need || ctx->sp_batch_cap < batch) {
     if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
     for (int s = 0; s < RM_SP_MAX; s++) {
       if (ctx->sp_stage[s]) (void)hipFree(ctx->sp_stage[s]);
       ctx->sp_stage[s] = nullptr;
     }
+    const size_t cap = need > ctx->sp_capacity ? need : ctx->sp_capacity;
+    const int bcap = batch > ctx->sp_batch_cap ? batch : ctx->sp_batch_cap;
     ctx->sp_capacity = 0;
     for (int s = 0; s < depth; s++)
-      if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->sp_stage[s]), sizeof(float4) * 3 * need)) != hipSuccess) return e;
-    ctx->sp_capacity = need;
+      if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->sp_stage[s]), sizeof(float4) * 3 * cap * (size_t)bcap)) != hipSuccess) return e;
+    ctx->sp_capacity = cap;
+    ctx->sp_batch_cap = bcap;
   }
   const int slot = (int)(ctx->sp_next++ % (unsigned int)depth);
   if (!ctx->sp_stage[slot]) {  // the depth was raised after the buffers were made
-    if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->sp_stage[slot]), sizeof(float4) * 3 * ctx->sp_capacity)) != hipSuccess) return e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->sp_stage[slot]), sizeof(float4) * 3 * ctx->sp_capacity * (size_t)ctx->sp_batch_cap)) != hipSuccess) return e;
   }
   KParams Q = P;
   Q.stage = ctx->sp_stage[slot];
   Q.stage_stride = (long long)ctx->sp_capacity;
+  if (batch > 1) {
+    Q.batch = batch;
+    std::memcpy(Q.batch_noise, noise, sizeof(float) * 2 * (size_t)batch);
+  }
   hipStream_t side = ctx->sp_stream[slot];
   // the render reads no plane: it only has to wait until the blend that last used this staging buffer is done
   if ((e = hipStreamWaitEvent(side, ctx->sp_free[slot], 0)) != hipSuccess) return e;
@@ -895,11 +911,38 @@ int rm_render_samples(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms*
   if (count < 0 || (count > 0 && !rand_noise_pairs)) return fail(ctx, RM_ERR_INVALID, "rm_render_samples: bad count / NULL randNoise");
   if (empty) return RM_OK;
   RM_HIP(ctx, hipSetDevice(ctx->device));
-  for (int i = 0; i < count; i++) {
-    P.u.randNoise[0] = rand_noise_pairs[2 * i];
-    P.u.randNoise[1] = rand_noise_pairs[2 * i + 1];
-    RM_HIP(ctx, launch(ctx, P, flags));
+  // Samples the pixel kernel can stage (the conditions of launch()) go out in batches: one launch per batch.
+  const bool wavefront = (flags & RM_RENDER_WAVEFRONT) ? true : (flags & RM_RENDER_MEGAKERNEL) ? false : prefer_wavefront(P, flags);
+  const bool stageable = !wavefront && !(flags & RM_RENDER_NO_OVERLAP) && P.u.renderMode == 0 && P.u.reflections > 0.0f;
+  int per_launch = 1;
+  if (stageable && ctx->sample_batch != 1) {
+    per_launch = ctx->sample_batch;
+    if (per_launch == 0) {
+      int gx = 0, gy = 0;
+      rm::pixel_grid(P, &gx, &gy);
+      const long long tiles = (long long)gx * gy;
+      per_launch = tiles > 0 ? (int)(RM_BATCH_TARGET_TILES / tiles) : 1;
+    }
+    per_launch = per_launch < 1 ? 1 : per_launch > RM_BATCH_MAX ? RM_BATCH_MAX : per_launch;
   }
+  for (int i = 0; i < count;) {
+    const int n = count - i < per_launch ? count - i : per_launch;
+    if (n > 1) {
+      RM_HIP(ctx, launch_pixels_in_flight(ctx, P, flags, n, rand_noise_pairs + 2 * i));
+    } else {
+      P.u.randNoise[0] = rand_noise_pairs[2 * i];
+      P.u.randNoise[1] = rand_noise_pairs[2 * i + 1];
+      RM_HIP(ctx, launch(ctx, P, flags));
+    }
+    i += n;
+  }
+  return RM_OK;
+}
+
+int rm_ctx_set_sample_batch(rm_ctx* ctx, int n) {
+  if (!ctx) return RM_ERR_INVALID;
+  if (n < 0 || n > RM_BATCH_MAX) return fail(ctx, RM_ERR_INVALID, "rm_ctx_set_sample_batch: n must be 0 (automatic) or 1..8");
+  ctx->sample_batch = n;
   return RM_OK;
 }
 

@@ -81,6 +81,20 @@ struct FM {
   static RM_DEV float atan2(float y, float x) { return atan2f(y, x); }
   static RM_DEV void sincos(float x, float& s, float& c) { s = sin(x); c = cos(x); }
   static RM_DEV void pow_pair(float r, float n, float& r_nm1, float& r_n) { r_nm1 = pow(r, n - 1.0f); r_n = pow(r, n); }
+  // VOP3 output modifiers: the result doubled (mul:2) or quadrupled (mul:4) in the same instruction.  The hardware
+  // ignores them while MODE.IEEE is set or fp32 denormals are kept -- the state a HIP kernel starts in -- so every
+  // kernel that evaluates the power-8 Mandelbulb on this policy clears both first (omod_mode; enter_math_mode below).
+  // tools/ubench/omod_probe.hip: the modifier takes effect only with BOTH cleared, as the ISA manual says.  With the
+  // IEEE bit off v_min/v_max no longer quiet a signalling NaN (arithmetic produces none); fp32 denormals read and
+  // write as zero in those kernels.
+  static RM_DEV void omod_mode() {
+    __builtin_amdgcn_s_setreg(1 | (4 << 6) | (1 << 11), 0);  // hwreg(HW_REG_MODE, 4, 2): fp32 denormals flushed
+    __builtin_amdgcn_s_setreg(1 | (9 << 6) | (0 << 11), 0);  // hwreg(HW_REG_MODE, 9, 1): IEEE off
+  }
+  static RM_DEV float mul_x2(float a, float b) { float r; asm("v_mul_f32_e64 %0, %1, %2 mul:2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+  static RM_DEV float mul_x4(float a, float b) { float r; asm("v_mul_f32_e64 %0, %1, %2 mul:4" : "=v"(r) : "v"(a), "v"(b)); return r; }
+  static RM_DEV float fma_x2(float a, float b, float c) { float r; asm("v_fma_f32 %0, %1, %2, %3 mul:2" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+  static RM_DEV float sq_minus_half_x2(float a) { float r; asm("v_fma_f32 %0, %1, %1, -0.5 mul:2" : "=v"(r) : "v"(a)); return r; }  // 2 a^2 - 1
 };
 
 // ---- vector helpers / GLSL built-ins (semantics pinned in oracle/rm_oracle.c)
@@ -429,29 +443,32 @@ struct Sdf<RM_SCENE_MANDELBULB> {
   // Power 8 without trigonometry: with rho = |z.xy|, the angles' 8-fold multiples come from 8th powers of complex
   // numbers, each by three complex squarings.  The same function as eval_generic up to
   // rounding; 1 sqrt + 1 rsq per iteration instead of 12 transcendentals.
+  // x^2 + y^2 of a round, plus 1e-30 (the same float unless it is below 1e-23): see pow8_round
+  static RM_DEV float pow8_rho2(v3 z) { return FM::fma(z.y, z.y, FM::fma(z.x, z.x, 1e-30f)); }
   static RM_DEV void pow8_round(v3& z, float& dr, v3 pos, float rho2, float r2) {
-    // 2 transcendentals per round: r = sqrt(r2) and q = 1/rho = rsq(rho2); rho = rho2 * q.
+    // 2 transcendentals and 29 other instructions per round (it was 40 before the output modifiers).
+    // r = sqrt(r2) and q = 1/rho = rsq(rho2); rho = rho2 * q.
     // (z.z + i rho)^8 = r^8 (cos 8theta + i sin 8theta) =: A + iB is taken as it stands; the azimuth comes from the
     // UNIT vector (z.x + i z.y) / rho, whose 8th power is cos 8phi + i sin 8phi =: C + iD with no rho^8 to divide
-    // out again (two multiplications by q instead of q^2, q^4, q^8 and the product).  On the axis rho2 = 0 and
-    // q = rsq(0) = Inf would turn 0 * q into NaN: the rsq sees rho2 + 1e-30 (the same float as rho2 unless rho2 <
-    // 1e-23), so there q is finite, C + iD = 0 and B = 0 anyway (sin 8theta = 0), and the new z is
-    // (pos.x, pos.y, A + pos.z) as it should be.
+    // out again.  On the axis x = y = 0 and rsq(0) = Inf would turn 0 * q into NaN: rho2 carries 1e-30 (pow8_rho2,
+    // folded into its first fma), so there q is finite, C + iD = 0 and B = 0 anyway (sin 8theta = 0), and the new z
+    // is (pos.x, pos.y, A + pos.z) as it should be.
     const float r = FM::sqrt(r2);
-    const float q = __builtin_amdgcn_rsqf(rho2 + 1e-30f);
+    const float q = __builtin_amdgcn_rsqf(rho2);
     const float rho = rho2 * q;
     const float r4 = r2 * r2;
-    dr = FM::fma((r4 * r2 * r) * 8.0f, dr, 1.0f);
-    // three complex squarings each: re' = re^2 - im^2 (one mul + one fma), im' = 2 re im
+    dr = FM::fma_x2(FM::mul_x4(r4 * r2, r), dr, 0.5f);  // 8 r^7 dr + 1 = 2 ((4 r^7) dr + 0.5)
+    // three complex squarings each.  A + iB: re' = re^2 - im^2 (mul + fma), im' = 2 re im (one mul, doubled by its
+    // output modifier).  C + iD has modulus 1: re' = 2 re^2 - 1 (one fma, doubled), im' = 2 re im.
     float A = z.z, B = rho, C = z.x * q, D = z.y * q, t;
 #pragma unroll
     for (int s = 0; s < 3; s++) {
-      t = FM::fma(A, A, -(B * B)); B = (A + A) * B; A = t;
-      t = FM::fma(C, C, -(D * D)); D = (C + C) * D; C = t;
+      t = FM::fma(A, A, -(B * B)); B = FM::mul_x2(A, B); A = t;
+      t = FM::sq_minus_half_x2(C); D = FM::mul_x2(C, D); C = t;
     }
-    // (Packed fp32 -- v_pk_mul / v_pk_fma / v_pk_add_f32 on the pairs (A, C) and (B, D), 12 instructions instead of
-    // 24, same IEEE results per half -- was measured on the headline frame: 2.80 ms against 2.69.  A packed
-    // instruction takes two issue slots of a busy SIMD, and the SIMDs are busy.)
+    // (The same squarings written with |A + iB|^2 = r2 too -- 2 (A^2 - r2/2), one instruction less per round -- time
+    // the same and let the modulus drift faster; packed fp32 -- v_pk_mul / v_pk_fma on the pairs (A, C), (B, D) --
+    // was 2.80 ms against 2.69 on the headline frame: a packed instruction takes two issue slots of a busy SIMD.)
     z = V(FM::fma(B, C, pos.x), FM::fma(B, D, pos.y), A + pos.z);
   }
   // 0.5 log(r) r / dr with r = sqrt(r2): log2(r2) and sqrt(r2) both start from r2 (no chain through r), and the
@@ -472,7 +489,7 @@ struct Sdf<RM_SCENE_MANDELBULB> {
 #endif
 #pragma unroll
       for (int i = 0; i < 8; i++) {
-        const float rho2 = FM::fma(z.y, z.y, z.x * z.x);
+        const float rho2 = pow8_rho2(z);
         r2 = FM::fma(z.z, z.z, rho2);
         if (r2 > bail2) break;
         pow8_round(z, dr, pos, rho2, r2);
@@ -500,7 +517,7 @@ struct Sdf<RM_SCENE_MANDELBULB> {
     } else {
       const int iterations = (int)sc.p[RM_P_BULB_ITERATIONS];
       for (int i = 0; i < iterations; i++) {
-        const float rho2 = FM::fma(z.y, z.y, z.x * z.x);
+        const float rho2 = pow8_rho2(z);
         r2 = FM::fma(z.z, z.z, rho2);
         if (r2 > bail2) break;
         pow8_round(z, dr, pos, rho2, r2);
@@ -536,7 +553,7 @@ struct Sdf<RM_SCENE_MANDELBULB> {
       v3 z = p;
       float dr = 1.0f, r2 = 0.0f;
       for (int i = 0; i <= cheap_cap; i++) {
-        const float rho2 = FM::fma(z.y, z.y, z.x * z.x);
+        const float rho2 = pow8_rho2(z);
         r2 = FM::fma(z.z, z.z, rho2);
         if (r2 > bail2) { bailed = true; break; }
         if (i == cheap_cap) break;
@@ -570,6 +587,11 @@ struct Sdf<RM_KIND_BULB8> : Sdf<RM_SCENE_MANDELBULB> {
   template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds&, v3 p) { return eval_pow8_n<8>(sc, p); }
 };
+
+// kernels that may evaluate the power-8 Mandelbulb on the fast policy start with this (FM::omod_mode)
+template <int KIND, bool FAST> RM_DEV void enter_math_mode() {
+  if (FAST && (KIND == RM_SCENE_MANDELBULB || KIND == RM_KIND_BULB8)) FM::omod_mode();
+}
 
 // per-level scale factors pow(base, i), i = first .. first + RM_TAB_POW - 1,
 // computed once per workgroup with the same pow the per-evaluation GLSL uses

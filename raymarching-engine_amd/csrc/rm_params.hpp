@@ -10,6 +10,8 @@
 #define RM_TABLE_HAS_DOMAIN 2      /* the table has domain rows (RM_PRIM_REPEAT / RM_PRIM_FOLD) */
 #define RM_TABLE_UNIFORM_K 4       /* RM_TABLE_SPHERES_SMOOTH with one k for every fold: k in p[0], 0.5 / k in p[1] */
 
+#define RM_BATCH_MAX 8  /* samples one pixel-kernel launch can render (KParams::batch) */
+
 struct DevScene {
   int kind;
   int nprims;
@@ -36,6 +38,12 @@ struct KParams {
   // rm_combine_kernel applies the blend afterwards, in sample order.  nullptr = blend in the kernel.
   float4* stage;
   long long stage_stride;  // elements between the three staged planes
+  // Sample batch (rm_render_samples, staged output only): ONE launch renders `batch` consecutive samples of the job --
+  // workgroup b renders tile b / batch for sample b % batch, with randNoise batch_noise[sample] instead of u.randNoise
+  // and its output staged at stage + sample * 3 * stage_stride -- so that a small window (one GPU's share of a frame)
+  // still gives the chip a full frame's worth of workgroups.  0 or 1 = one sample.
+  int batch;
+  float batch_noise[RM_BATCH_MAX][2];
   // Cost-ordered dispatch (pixel kernel): workgroup b of the launch renders tile block_order[b], and every workgroup
   // leaves its duration in block_cost[tile] for the next sample's order (rm_order_kernel).  nullptr = in launch order.
   const unsigned int* block_order;

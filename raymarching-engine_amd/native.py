@@ -27,7 +27,7 @@ LIB_PATH = Path(os.environ.get("RM_LIB") or Path(__file__).resolve().parent / "l
 EXPORTS = [
     "rm_abi_version", "rm_material_default", "rm_ctx_create", "rm_ctx_destroy", "rm_last_error", "rm_ctx_set_stream",
     "rm_ctx_set_retire_eps", "rm_ctx_set_samples_in_flight", "rm_ctx_set_cost_order", "rm_debug_counters", "rm_sync", "rm_scene_create", "rm_scene_destroy", "rm_fb_create", "rm_fb_create_striped", "rm_fb_rows", "rm_fb_width", "rm_fb_height", "rm_fb_wrap", "rm_fb_clear", "rm_fb_destroy",
-    "rm_fb_download", "rm_fb_upload", "rm_fb_device_ptr", "rm_render_sample", "rm_render_samples", "rm_render_timed",
+    "rm_fb_download", "rm_fb_upload", "rm_fb_device_ptr", "rm_render_sample", "rm_render_samples", "rm_ctx_set_sample_batch", "rm_render_timed",
     "rm_probe", "rm_probe_camera", "rm_probe_rng", "rm_assemble_striped", "rm_assemble_striped_bytes", "rm_present", "rm_present_planes", "rm_present_device", "rm_present_rows",
 ]
 
@@ -88,6 +88,7 @@ def load_library():
         "rm_ctx_set_stream": (ip, [vp, vp]),
         "rm_ctx_set_retire_eps": (ip, [vp, C.c_float]),
         "rm_ctx_set_samples_in_flight": (ip, [vp, C.c_int]),
+        "rm_ctx_set_sample_batch": (ip, [vp, C.c_int]),
         "rm_ctx_set_cost_order": (ip, [vp, C.c_int]),
         "rm_debug_counters": (ip, [vp, C.POINTER(C.c_ulonglong), ip]),
         "rm_sync": (ip, [vp]),
@@ -169,6 +170,10 @@ class Context:
     def set_samples_in_flight(self, n: int):
         """Consecutive full-mode samples that may overlap on the GPU (1 = none); the planes get the same bits."""
         self._check(self.lib.rm_ctx_set_samples_in_flight(self.h, int(n)))
+
+    def set_sample_batch(self, n: int):
+        """Samples per launch of render_samples (0 = automatic, 1 = one launch per sample, up to 8); same bits."""
+        self._check(self.lib.rm_ctx_set_sample_batch(self.h, int(n)))
 
     def assemble_striped(self, src_ptr: int, parts: int, max_rows: int, width: int, height: int, stripe_rows: int, dst_ptr: int,
                          stream: Optional[int] = None):

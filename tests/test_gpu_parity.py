@@ -21,6 +21,7 @@ from oracle import oracle as O
 from raymarching_engine_amd import abi
 from raymarching_engine_amd import job as J
 from raymarching_engine_amd import scene as S
+from raymarching_engine_amd import shard
 
 pytestmark = pytest.mark.gpu
 
@@ -662,6 +663,74 @@ def test_samples_in_flight_leave_the_same_bits(ctx, case):
         a = render_gpu(ctx, sc, schema, noises[:3], build | MK | NO | abi.RM_RENDER_COLOR_ONLY)
         b = render_gpu(ctx, sc, schema, noises[:3], build | MK | abi.RM_RENDER_COLOR_ONLY)
         assert same_bits(a[0], b[0]).all() and not b[1].any() and not b[2].any()
+
+
+def _render_samples_gpu(ctx, sc, schema, noises, flags, tile=None, striped=None):
+    r = schema["render"]
+    h = ctx.create_scene(sc)
+    fb = (ctx.create_striped_framebuffer(r["width"], r["height"], shard.STRIPE_ROWS, *striped) if striped
+          else ctx.create_framebuffer(r["width"], r["height"]))
+    ctx.render_samples(h, fb, J.uniforms_from_schema(schema, (0.0, 0.0)), [tuple(n) for n in noises], tile, flags)
+    out = [fb.download(p) for p in (0, 1, 2)]
+    fb.destroy()
+    h.destroy()
+    return out
+
+
+@pytest.mark.parametrize("case", ["sphere_full_3b_soft_4spp", "sphere_full_mix_2spp", "mandelbulb_full_light", "csg_mixed_full_2b"])
+def test_sample_batches_leave_the_same_bits(ctx, case):
+    """rm_render_samples renders up to 8 samples of a job in ONE launch (a workgroup per
+    (tile, sample), rm_ctx_set_sample_batch) and blends them in sample order: every plane
+    ends up with exactly the bits of one rm_render_sample call per sample -- both builds,
+    additive and mix blend, counts that are no multiple of the batch, tiles, colour-only
+    renders, a striped window, with and without samples in flight on top."""
+    sc, samples, schema = GC.image_schema(case)
+    noises = GC.halton_pairs(11)
+    NO = abi.RM_RENDER_NO_OVERLAP
+    for build in (STRICT, FAST):
+        alone = render_gpu(ctx, sc, schema, noises, build | MK | NO)
+        for batch, depth in ((0, 3), (3, 1), (8, 2), (1, 3)):
+            ctx.set_sample_batch(batch)
+            ctx.set_samples_in_flight(depth)
+            try:
+                got = _render_samples_gpu(ctx, sc, schema, noises, build | MK)
+            finally:
+                ctx.set_sample_batch(0)
+                ctx.set_samples_in_flight(3)
+            for k in range(3):
+                assert same_bits(got[k], alone[k]).all(), f"build {build} batch {batch} depth {depth} plane {k}"
+        tile = abi.RmRect(5, 3, 41, 22)
+        a = render_gpu(ctx, sc, schema, noises[:5], build | MK | NO, tile=tile)
+        b = _render_samples_gpu(ctx, sc, schema, noises[:5], build | MK, tile=tile)
+        for k in range(3):
+            assert same_bits(a[k], b[k]).all(), f"tile, plane {k}"
+        a = render_gpu(ctx, sc, schema, noises[:5], build | MK | NO | abi.RM_RENDER_COLOR_ONLY)
+        b = _render_samples_gpu(ctx, sc, schema, noises[:5], build | MK | abi.RM_RENDER_COLOR_ONLY)
+        assert same_bits(a[0], b[0]).all() and not b[1].any() and not b[2].any()
+    # a striped window (one GPU's rows of a sharded frame): rows of part 1 of 3
+    r = schema["render"]
+    rows = [y for y in range(r["height"]) if (y // shard.STRIPE_ROWS) % 3 == 1]
+    got = _render_samples_gpu(ctx, sc, schema, noises, FAST | MK, striped=(3, 1))
+    alone = render_gpu(ctx, sc, schema, noises, FAST | MK | NO)
+    for k in range(3):
+        assert same_bits(got[k][:len(rows)], alone[k][rows]).all(), f"striped, plane {k}"
+
+
+def test_sample_batches_with_cost_ordered_tiles(ctx):
+    """A job of >= 512 workgroups starts its tiles in cost order from its second launch on;
+    batched launches use the same order (one entry per tile, `batch` workgroups each) and
+    still leave the bits of one launch per sample."""
+    sc, schema = _c3b(512, 512, counts=(24,))
+    noises = GC.halton_pairs(20)
+    alone = render_gpu(ctx, sc, schema, noises, FAST | MK | abi.RM_RENDER_NO_OVERLAP)
+    for batch in (4, 8):
+        ctx.set_sample_batch(batch)
+        try:
+            got = _render_samples_gpu(ctx, sc, schema, noises, FAST | MK)
+        finally:
+            ctx.set_sample_batch(0)
+        for k in range(3):
+            assert same_bits(got[k], alone[k]).all(), f"batch {batch} plane {k}"
 
 
 def test_fast_build_keeps_the_brightness_of_lit_pixels(ctx):

@@ -24,7 +24,10 @@ issue = torch.cuda.Stream()  # the stream the collective is enqueued from (dist.
 full = None
 for N in (1, 2, 4, 8):
     counts = shard.row_counts(H, N); max_rows = max(counts)
-    depth = 1 if N == 1 else int(os.environ.get("EMU_DEPTH", "4"))
+    # EMU_YIELD = render.sampleYieldInterval: 1 = present after every sample (4 samples in flight); 8 (bench.py's value for
+    # a sharded frame) = the 8 samples between two presents in one rm_render_samples call, two such batches in flight
+    Y = 1 if N == 1 else int(os.environ.get("EMU_YIELD", "8"))
+    depth = 1 if N == 1 else int(os.environ.get("EMU_DEPTH", "4" if Y == 1 else "2"))
     ctx.set_samples_in_flight(depth)
     recv = torch.zeros((N, max_rows, W, 4), dtype=torch.uint8, device=dev)
     frame = torch.empty((H, W, 4), dtype=torch.uint8, device=dev)
@@ -36,8 +39,11 @@ for N in (1, 2, 4, 8):
         h2, h3 = J.halton(2), J.halton(3)
         k = [0]
         def step(present):
-            u.randNoise[0], u.randNoise[1] = next(h2), next(h3)
-            ctx.render_sample(h, fb, u, None, abi.RM_RENDER_FAST)
+            if Y == 1:
+                u.randNoise[0], u.randNoise[1] = next(h2), next(h3)
+                ctx.render_sample(h, fb, u, None, abi.RM_RENDER_FAST)
+            else:
+                ctx.render_samples(h, fb, u, [(next(h2), next(h3)) for _ in range(Y)], None, abi.RM_RENDER_FAST)
             if present and N > 1:
                 snap = snaps[k[0] & 1]; k[0] += 1
                 ctx.present_rows(fb, k[0], snap.data_ptr(), st.cuda_stream)
@@ -48,11 +54,11 @@ for N in (1, 2, 4, 8):
                         recv[0].copy_(snap, non_blocking=True)  # stands in for the collective's local part
                     aux.wait_stream(issue)
                     ctx.assemble_striped_bytes(recv.data_ptr(), N, max_rows, W * 4, H, shard.STRIPE_ROWS, frame.data_ptr(), aux.cuda_stream)
-        for _ in range(8): step(True)
-        torch.cuda.synchronize(); t0 = time.perf_counter(); K = 60
+        for _ in range(max(2, 8 // Y)): step(True)
+        torch.cuda.synchronize(); t0 = time.perf_counter(); K = max(8, 64 // Y)
         for _ in range(K): step(True)
-        torch.cuda.synchronize(); per_rank.append((time.perf_counter() - t0) / K * 1e3)
+        torch.cuda.synchronize(); per_rank.append((time.perf_counter() - t0) / (K * Y) * 1e3)
         fb.destroy()
     if N == 1: full = per_rank[0]
-    print(f"N={N}: ms per step per rank (render x{depth} in flight + present rows{' + assemble on rank 0' if N > 1 else ''}): "
+    print(f"N={N}: ms per sample per rank (yield interval {Y}, render x{depth} in flight + present rows{' + assemble on rank 0' if N > 1 else ''}): "
           + " ".join(f"{t:.3f}" for t in per_rank) + f"   -> slowest {max(per_rank):.3f} ms, speed-up {full / max(per_rank):.2f}x of {N}")

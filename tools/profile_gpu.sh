@@ -2,7 +2,7 @@
 # rocprofv3 profile of the bench command on a GPU box; summaries land in gpurun_out/prof_<tag>/
 set -u
 TAG=${1:-r01}
-ARGS=${2:---steps 5 --warmup 2 --no-cpu-baseline}
+ARGS=${2:---steps 30 --warmup 5 --no-cpu-baseline}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
