@@ -240,7 +240,7 @@ def main():
     # sharded, the job yields every 8 samples: a rank's 8 samples go out as ONE launch of a full frame's worth of workgroups
     # (rm_render_samples, rm_ctx_set_sample_batch), two such launches in flight, one present + gather per yield
     yield_interval = args.yield_interval if args.yield_interval > 0 else (1 if world == 1 else 8)
-    in_flight = args.in_flight if args.in_flight > 0 else (1 if world == 1 else 4 if yield_interval == 1 else 2)
+    in_flight = args.in_flight if args.in_flight > 0 else (1 if world == 1 else 4 if yield_interval == 1 else 3)
     ctx.set_samples_in_flight(in_flight)
     tile = None
     rows_window = None

@@ -288,14 +288,22 @@ def do_render_job(schema: dict, context: RenderJobContext):
         for y_part in range(n):  # :148-162
             for x_part in range(n):
                 tile = tile_rect(schema, x_part, y_part)
-                for _ in range(r["samplesPerPixel"]):
+                left = r["samplesPerPixel"]
+                while left > 0:
                     if samples % r["sampleYieldInterval"] == 0:  # :163-166
                         context.native.sync()
                         present(schema, context, fb, samples)
                         yield
-                    u = uniforms_from_schema(schema, next_rand_noise())
-                    context.native.render_sample(handle, fb, u, tile, context.flags)  # :181-326
-                    samples += 1
+                    # the samples up to the next yield differ in randNoise only (:219-222): one native call for all of them
+                    k = min(left, r["sampleYieldInterval"] - samples % r["sampleYieldInterval"])
+                    noise = [next_rand_noise() for _ in range(k)]
+                    u = uniforms_from_schema(schema, noise[0])
+                    if k == 1:
+                        context.native.render_sample(handle, fb, u, tile, context.flags)  # :181-326
+                    else:
+                        context.native.render_samples(handle, fb, u, noise, tile, context.flags)
+                    samples += k
+                    left -= k
         context.fbo_delete(r["width"], r["height"], r["frameid"])  # :333-337
         context.native.sync()
         present(schema, context, fb, samples)

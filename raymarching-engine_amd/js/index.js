@@ -208,11 +208,16 @@ async function doRenderJob(schema, context) {  // RenderJobExecutor.tsx:77
   return function* (present) {
     for (let yp = 0; yp < r.subdivisions; yp++) for (let xp = 0; xp < r.subdivisions; xp++) {
       const tile = tileRect(schema, xp, yp);
-      for (let s = 0; s < r.samplesPerPixel; s++) {
+      for (let left = r.samplesPerPixel; left > 0;) {
         if (samples % r.sampleYieldInterval === 0) { addon.sync(context.ctx); present(schema, context, framebuffers, samples); yield; }
-        const u = uniformsFromSchema(schema, [halton2.next().value, halton3.next().value]);
-        addon.renderSample(context.ctx, scene, framebuffers.fb, u, tile, context.flags);
-        samples++;
+        // the samples up to the next yield differ in randNoise only (:219-222): one native call for all of them
+        const k = Math.min(left, r.sampleYieldInterval - samples % r.sampleYieldInterval);
+        const noise = new Float32Array(2 * k);
+        for (let i = 0; i < k; i++) { noise[2 * i] = halton2.next().value; noise[2 * i + 1] = halton3.next().value; }
+        const u = uniformsFromSchema(schema, [noise[0], noise[1]]);
+        if (k === 1) addon.renderSample(context.ctx, scene, framebuffers.fb, u, tile, context.flags);
+        else addon.renderSamples(context.ctx, scene, framebuffers.fb, u, noise, tile, context.flags);
+        samples += k; left -= k;
       }
     }
     context.fboDelete(r.width, r.height, r.frameid);

@@ -265,6 +265,46 @@ static napi_value RenderSample(napi_env env, napi_callback_info info) {
   return nullptr;
 }
 
+// renderSamples(ctx, scene, fb, uniforms: ArrayBuffer(sizeof RmUniforms), randNoise: Float32Array(2 * count), tile: Int32Array(4) | null, flags)
+// = rm_render_samples: the samples between two yields of a job in one call (RenderJobExecutor.tsx:160-222)
+static napi_value RenderSamples(napi_env env, napi_callback_info info) {
+  size_t argc = 7;
+  napi_value argv[7];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  rm_ctx* ctx = get_external<rm_ctx>(env, argv[0]);
+  rm_scene* scene = get_external<rm_scene>(env, argv[1]);
+  rm_fb* fb = get_external<rm_fb>(env, argv[2]);
+  void* u = nullptr;
+  size_t un = 0;
+  if (!ctx || !scene || !fb) {
+    napi_throw_type_error(env, nullptr, "renderSamples(ctx, scene, fb, ...): wrong or destroyed handle");
+    return nullptr;
+  }
+  if (!get_buffer(env, argv[3], &u, &un) || un != sizeof(RmUniforms)) {
+    napi_throw_type_error(env, nullptr, "renderSamples: uniforms must be an ArrayBuffer of sizeof(RmUniforms) bytes");
+    return nullptr;
+  }
+  void* rn = nullptr;
+  size_t rnn = 0;
+  if (!get_buffer(env, argv[4], &rn, &rnn) || rnn % (2 * sizeof(float)) != 0 || rnn > (size_t)1 << 24) {
+    napi_throw_type_error(env, nullptr, "renderSamples: randNoise must be a Float32Array of 2 * count values");
+    return nullptr;
+  }
+  RmRect tile;
+  const RmRect* tp = nullptr;
+  void* t = nullptr;
+  size_t tn = 0;
+  if (argc > 5 && get_buffer(env, argv[5], &t, &tn) && tn == sizeof(RmRect)) {
+    std::memcpy(&tile, t, sizeof tile);
+    tp = &tile;
+  }
+  int32_t flags = 0;
+  if (argc > 6) napi_get_value_int32(env, argv[6], &flags);
+  if (rm_render_samples(ctx, scene, fb, static_cast<const RmUniforms*>(u), static_cast<const float*>(rn), (int)(rnn / (2 * sizeof(float))), tp, flags) != RM_OK)
+    return throw_rm(env, ctx, "rm_render_samples");
+  return nullptr;
+}
+
 static napi_value Sizes(napi_env env, napi_callback_info) {
   napi_value o, v;
   NAPI_OK(napi_create_object(env, &o));
@@ -281,7 +321,7 @@ static napi_value Sizes(napi_env env, napi_callback_info) {
 static napi_value Init(napi_env env, napi_value exports) {
   const struct { const char* name; napi_callback fn; } fns[] = {
       {"ctxCreate", CtxCreate}, {"ctxDestroy", CtxDestroy}, {"sync", Sync}, {"sceneCreate", SceneCreate}, {"sceneDestroy", SceneDestroy},
-      {"fbCreate", FbCreate}, {"fbClear", FbClear}, {"fbDestroy", FbDestroy}, {"fbDownload", FbDownload}, {"present", Present}, {"renderSample", RenderSample},
+      {"fbCreate", FbCreate}, {"fbClear", FbClear}, {"fbDestroy", FbDestroy}, {"fbDownload", FbDownload}, {"present", Present}, {"renderSample", RenderSample}, {"renderSamples", RenderSamples},
       {"sizes", Sizes}};
   for (const auto& f : fns) {
     napi_value fn;

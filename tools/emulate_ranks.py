@@ -27,7 +27,7 @@ for N in (1, 2, 4, 8):
     # EMU_YIELD = render.sampleYieldInterval: 1 = present after every sample (4 samples in flight); 8 (bench.py's value for
     # a sharded frame) = the 8 samples between two presents in one rm_render_samples call, two such batches in flight
     Y = 1 if N == 1 else int(os.environ.get("EMU_YIELD", "8"))
-    depth = 1 if N == 1 else int(os.environ.get("EMU_DEPTH", "4" if Y == 1 else "2"))
+    depth = 1 if N == 1 else int(os.environ.get("EMU_DEPTH", "4" if Y == 1 else "3"))
     ctx.set_samples_in_flight(depth)
     recv = torch.zeros((N, max_rows, W, 4), dtype=torch.uint8, device=dev)
     frame = torch.empty((H, W, 4), dtype=torch.uint8, device=dev)

@@ -1,9 +1,9 @@
 #!/bin/bash
-# sample batches: tests, per-rank emulation with and without them, the RCCL path at one rank
+# sample batches: the GPU suite, per-rank emulation over yield interval x batches in flight
 mkdir -p gpurun_out/r2q
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "batches or in_flight" > gpurun_out/r2q/tests.txt 2>&1; tail -5 gpurun_out/r2q/tests.txt
-EMU_YIELD=8 python3 tools/emulate_ranks.py > gpurun_out/r2q/emu_yield8.txt 2>&1; tail -5 gpurun_out/r2q/emu_yield8.txt
-EMU_YIELD=4 python3 tools/emulate_ranks.py > gpurun_out/r2q/emu_yield4.txt 2>&1; tail -4 gpurun_out/r2q/emu_yield4.txt
-EMU_YIELD=1 python3 tools/emulate_ranks.py > gpurun_out/r2q/emu_yield1.txt 2>&1; tail -4 gpurun_out/r2q/emu_yield1.txt
-RM_BENCH_FORCE_DIST=1 python3 bench.py --no-cpu-baseline --yield-interval 8 > gpurun_out/r2q/force_dist_y8.log 2>&1; tail -1 gpurun_out/r2q/force_dist_y8.log | cut -c1-400
-python3 bench.py --no-cpu-baseline | cut -c1-300
+timeout 1200 python -m pytest tests -m gpu -q -x > gpurun_out/r2q/tests.txt 2>&1; tail -5 gpurun_out/r2q/tests.txt
+for cfg in "8 1" "8 2" "8 3" "4 2" "4 3" "4 4" "2 4"; do
+  set -- $cfg
+  echo "== yield $1 depth $2"; EMU_YIELD=$1 EMU_DEPTH=$2 python3 tools/emulate_ranks.py 2>&1 | grep "^N=[48]"
+done > gpurun_out/r2q/emu_sweep.txt 2>&1
+cat gpurun_out/r2q/emu_sweep.txt
