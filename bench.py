@@ -264,7 +264,10 @@ def main():
     u_step = J.uniforms_from_schema(schema, (0.5, 1.0 / 3.0))  # only randNoise changes from sample to sample
     samples = [0]
 
+    yi = [yield_interval]
+
     def run(n):
+        yield_interval = yi[0]
         # n samples of the job: `yield_interval` of them at a time (one rm_render_samples call), then -- sharded -- the
         # gather of the presented rows (a snapshot) is started; it runs over RCCL while the next samples render, and
         # the frame is assembled on rank 0 before the next gather starts
@@ -312,6 +315,33 @@ def main():
     px_frame = W * H if rows_window is None else W * (rows_window[1] - rows_window[0])
     ms_per_step = elapsed / args.steps * 1e3
     value = px_frame * args.steps / elapsed / 1e6
+
+    # for information, never `value`: the same K steps with a present + gather after EVERY sample (the live loop's
+    # sampleYieldInterval = 1), four single-sample launches in flight
+    every_sample = None
+    if sharded and yield_interval > 1:
+        yi[0] = 1
+        ctx.set_samples_in_flight(4)
+        run(min(args.warmup, 8) or 1)
+        drain()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run(args.steps)
+        drain()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        e1 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([e1], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e1 = float(t.item())
+        yi[0] = yield_interval
+        ctx.set_samples_in_flight(in_flight)
+        every_sample = {"sample_yield_interval": 1, "samples_in_flight": 4, "value": px_frame * args.steps / e1 / 1e6,
+                        "ms_per_step": e1 / args.steps * 1e3}
 
     overlap = None
     if world == 1 and not force_dist and in_flight == 1 and args.overlap_leg:
@@ -382,7 +412,7 @@ def main():
                        if sharded else "none",
                        "planes": "color+normal_dof+albedo_depth fp32, accumulated in place", "samples_in_flight": in_flight,
                        "sample_yield_interval": yield_interval},
-            "roofline": roof, "cpu_baseline": cpu, "overlap": overlap,
+            "roofline": roof, "cpu_baseline": cpu, "overlap": overlap, "present_every_sample": every_sample,
         }
     fb.destroy()
     scene.destroy()
