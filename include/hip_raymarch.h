@@ -300,6 +300,15 @@ int rm_fb_upload(rm_fb* fb, int plane, const float* host);
 /* Device address of a plane (for collectives / zero-copy wrapping). */
 void* rm_fb_device_ptr(rm_fb* fb, int plane);
 
+/* Raw device memory for hosts that have no allocator of their own: rm_present_rows, rm_present_device and
+ * rm_assemble_striped_bytes take DEVICE pointers (in the reference these are textures the GL context owns,
+ * LoadRenderJobContext.tsx:43-124; a torch host passes tensor addresses instead).  Created zero-filled; the copies
+ * are synchronous and ordered after the work on the context's stream. */
+int rm_buffer_create(rm_ctx* ctx, size_t bytes, void** device_ptr);
+int rm_buffer_destroy(rm_ctx* ctx, void* device_ptr);
+int rm_buffer_download(rm_ctx* ctx, const void* device_ptr, void* host, size_t bytes);
+int rm_buffer_upload(rm_ctx* ctx, void* device_ptr, const void* host, size_t bytes);
+
 /* ---- the hot path ------------------------------------------------------ */
 
 /* One sample of every pixel of `tile` (clipped to the framebuffer's rows):

@@ -14,15 +14,16 @@ _HERE = Path(__file__).resolve().parent
 _BUILD = _HERE / "_build"
 NAN_X86, NAN_IEEE = 0, 1
 TAN_LIBM, TAN_PORTABLE = 0, 1
+MATH_LIBM, MATH_PORTABLE = 0, 1
 
 _libs = {}
 
 
 def build(force: bool = False) -> None:
     """gcc the restatement into oracle/_build (both the plain and the flop-counting variant)."""
-    src = _HERE / "rm_oracle.c"
+    srcs = [_HERE / "rm_oracle.c", _HERE / "pm_math.h"]
     outs = [_BUILD / "librm_oracle.so", _BUILD / "librm_oracle_count.so"]
-    if not force and all(o.exists() and o.stat().st_mtime >= src.stat().st_mtime for o in outs):
+    if not force and all(o.exists() and all(o.stat().st_mtime >= src.stat().st_mtime for src in srcs) for o in outs):
         return
     subprocess.run(["make", "-C", str(_HERE), "-s", "-B"], check=True)
 
@@ -53,6 +54,7 @@ def _lib(count: bool = False):
         lib.or_present.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8)]
         lib.or_set_nan_mode.argtypes = [C.c_int]
         lib.or_set_tan_mode.argtypes = [C.c_int]
+        lib.or_set_math_mode.argtypes = [C.c_int]
         _libs[key] = lib
     return _libs[key]
 
@@ -70,6 +72,12 @@ def set_tan_mode(mode: int) -> None:
     """TAN_PORTABLE (default) or TAN_LIBM, for both library variants."""
     _lib(False).or_set_tan_mode(mode)
     _lib(True).or_set_tan_mode(mode)
+
+
+def set_math_mode(mode: int) -> None:
+    """MATH_PORTABLE (default: oracle/pm_math.h, the same text the HIP kernels compile) or MATH_LIBM, for both variants."""
+    _lib(False).or_set_math_mode(mode)
+    _lib(True).or_set_math_mode(mode)
 
 
 class Frame:

@@ -64,6 +64,30 @@ enum { OR_TAN_LIBM = 0, OR_TAN_PORTABLE = 1 };
 static int or_tan_mode = OR_TAN_PORTABLE;
 void or_set_tan_mode(int mode) { or_tan_mode = mode; }
 
+/* sin, cos, log, exp, pow, acos, atan2.  GLSL leaves their precision to the implementation, so there are no reference
+ * bits to match; what matters is that the checker and the HIP parity build compute the SAME function.
+ * OR_MATH_PORTABLE (default): oracle/pm_math.h -- double-precision series from IEEE basic operations, correctly rounded
+ * to float for all but ~1e-5 of the arguments, the same text the HIP kernels compile: bit-identical on both sides.
+ * OR_MATH_LIBM: the C library's float functions, as this file used them until round 2 (kept to show that nothing hangs
+ * on the choice: tests/test_oracle_golden.py renders the goldens' cases both ways). */
+enum { OR_MATH_LIBM = 0, OR_MATH_PORTABLE = 1 };
+static int or_math_mode = OR_MATH_PORTABLE;
+void or_set_math_mode(int mode) { or_math_mode = mode; }
+
+#define PM_FN static inline
+static inline unsigned long long PM_D2U(double x) { unsigned long long u; memcpy(&u, &x, 8); return u; }
+static inline double PM_U2D(unsigned long long u) { double x; memcpy(&x, &u, 8); return x; }
+static inline unsigned int PM_F2U(float x) { unsigned int u; memcpy(&u, &x, 4); return u; }
+#include "pm_math.h"
+
+static inline float o_sin(float x) { return or_math_mode == OR_MATH_LIBM ? sinf(x) : pm_sin(x); }
+static inline float o_cos(float x) { return or_math_mode == OR_MATH_LIBM ? cosf(x) : pm_cos(x); }
+static inline float o_log(float x) { return or_math_mode == OR_MATH_LIBM ? logf(x) : pm_log(x); }
+static inline float o_exp(float x) { return or_math_mode == OR_MATH_LIBM ? expf(x) : pm_exp(x); }
+static inline float o_pow(float x, float y) { return or_math_mode == OR_MATH_LIBM ? powf(x, y) : pm_pow(x, y); }
+static inline float o_acos(float x) { return or_math_mode == OR_MATH_LIBM ? acosf(x) : pm_acos(x); }
+static inline float o_atan2(float y, float x) { return or_math_mode == OR_MATH_LIBM ? atan2f(y, x) : pm_atan2(y, x); }
+
 static float or_tan(float x) {
   if (or_tan_mode == OR_TAN_LIBM) return tanf(x);
   float k = floorf(x * 0.636619772f + 0.5f);
@@ -103,7 +127,7 @@ static inline float gl_sign(float x) { FL(1); return (float)((x > 0.0f) - (x < 0
  * below (SwiftShader: bit-exact on 16k smooth-union folds, oracle/gl/gen_golden.py) */
 static inline float gl_mix(float x, float y, float a) { FL(3); return x + a * (y - x); }
 /* pow(x,y) for x < 0 is undefined in GLSL; SwiftShader evaluates it on |x| (probed) */
-static inline float gl_pow(float x, float y) { FL(2); return powf(fabsf(x), y); }
+static inline float gl_pow(float x, float y) { FL(2); return o_pow(fabsf(x), y); }
 
 static inline v3 V(float x, float y, float z) { v3 r = {x, y, z}; return r; }
 static inline v3 vadd(v3 a, v3 b) { FL(3); return V(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -170,10 +194,10 @@ static void box_muller(Inv* s, float* ox, float* oy) {
   s->seed += 0.123123213f;
   float u2 = gold_noise(s->tcx * 1000.0f, s->tcy * 1000.0f, gl_fract(s->u->randNoise[1] + s->seed));
   float two_pi_u2 = 2.0f * OR_PI * u2;
-  float r = sqrtf(-2.0f * logf(u1));
+  float r = sqrtf(-2.0f * o_log(u1));
   FL(8 + 2 + 3 + 4);
-  *ox = r * cosf(two_pi_u2);
-  *oy = r * sinf(two_pi_u2);
+  *ox = r * o_cos(two_pi_u2);
+  *oy = r * o_sin(two_pi_u2);
 }
 
 /* :96-101 */
@@ -257,8 +281,8 @@ static float sdf_mandelbulb(const RmSceneDesc* sc, v3 pos) {
     r = vlength(z);
     FL(1);
     if (r > bailout) break;
-    float theta = acosf(z.z / r);
-    float phi = atan2f(z.y, z.x);
+    float theta = o_acos(z.z / r);
+    float phi = o_atan2(z.y, z.x);
     FL(3);
     dr = gl_pow(r, power - 1.0f) * power * dr + 1.0f;
     FL(4);
@@ -266,11 +290,11 @@ static float sdf_mandelbulb(const RmSceneDesc* sc, v3 pos) {
     theta = theta * power;
     phi = phi * power;
     FL(2 + 4 + 3);
-    z = vscale(V(sinf(theta) * cosf(phi), sinf(phi) * sinf(theta), cosf(theta)), zr);
+    z = vscale(V(o_sin(theta) * o_cos(phi), o_sin(phi) * o_sin(theta), o_cos(theta)), zr);
     z = vadd(z, pos);
   }
   FL(4);
-  return 0.5f * logf(r) * r / dr;
+  return 0.5f * o_log(r) * r / dr;
 }
 
 /* RM_SCENE_SPHERE_GRID: examples/guide.glsl:91-102 == examples/fractal1.glsl:23-34 */
@@ -326,11 +350,11 @@ static float sdf_menger(const RmSceneDesc* sc, v3 p) {
 static v3 kifs_rotate(v3 t, const float* ang) {
   float c, s, nx, ny;
   FL(6 + 18);
-  c = cosf(ang[0]); s = sinf(ang[0]);
+  c = o_cos(ang[0]); s = o_sin(ang[0]);
   nx = t.x * c + t.y * -s; ny = t.x * s + t.y * c; t.x = nx; t.y = ny;
-  c = cosf(ang[1]); s = sinf(ang[1]);
+  c = o_cos(ang[1]); s = o_sin(ang[1]);
   nx = t.y * c + t.z * -s; ny = t.y * s + t.z * c; t.y = nx; t.z = ny;
-  c = cosf(ang[2]); s = sinf(ang[2]);
+  c = o_cos(ang[2]); s = o_sin(ang[2]);
   nx = t.x * c + t.z * -s; ny = t.x * s + t.z * c; t.x = nx; t.z = ny;
   return t;
 }
@@ -415,7 +439,7 @@ static v3 scene_emission(const RmSceneDesc* sc, v3 p) {
 /* ---- raymarcher.frag:148-175 -------------------------------------------- */
 
 /* :148-150 */
-static float inv_exp_dist(float x, float lambda) { FL(4); return -logf(1.0f - x) / lambda; }
+static float inv_exp_dist(float x, float lambda) { FL(4); return -o_log(1.0f - x) / lambda; }
 
 /* :153-160 -- forward differences */
 static v3 scene_normal(const RmSceneDesc* sc, v3 p, float delta) {
@@ -444,7 +468,7 @@ static float schlick(float cos_theta, float n1, float n2) {
 
 /* :61-65 */
 static v3 rodrigues(v3 v, v3 k, float theta) {
-  float c = cosf(theta);
+  float c = o_cos(theta);
   float s = sqrtf(1.0f - c * c);
   FL(1 + 3 + 2);
   return vadd(vadd(vscale(v, c), vscale(vcross(k, v), s)), vscale(k, vdot(k, v) * (1.0f - c)));
@@ -497,7 +521,7 @@ static void pixel_main(const RmSceneDesc* sc, const RmUniforms* u, int W, int H,
     float ax = (t2x - 0.5f) * (2.0f * OR_PI);
     float ay = (t2y - 0.5f) * OR_PI;
     FL(5 + 6 + 2);
-    dir = mat_rotate(u->rotation, V(cosf(ax) * cosf(ay), sinf(ay), sinf(ax) * cosf(ay)));
+    dir = mat_rotate(u->rotation, V(o_cos(ax) * o_cos(ay), o_sin(ay), o_sin(ax) * o_cos(ay)));
     pos = cam;
   }
 
@@ -557,7 +581,7 @@ static void pixel_main(const RmSceneDesc* sc, const RmUniforms* u, int W, int H,
 
     /* :266-271 */
     FL(4);
-    float subsurf = -1.0f / sc->material.subsurface * logf(1.0f - uniform_sample(&s));
+    float subsurf = -1.0f / sc->material.subsurface * o_log(1.0f - uniform_sample(&s));
     v3 sdir = vnormalize(sphere_sample(&s));
     sdir = V(gl_mix(dir.x, sdir.x, 1.0f), gl_mix(dir.y, sdir.y, 1.0f), gl_mix(dir.z, sdir.z, 1.0f));
     sdir = vnormalize(sdir);
@@ -762,7 +786,7 @@ void or_camera(const RmUniforms* u, int W, int H, float* out) {
         pos = vadd(cam, mat_rotate(u->rotation, V((tcx - 0.5f) * u->aspect * u->fov, (tcy - 0.5f) * 1.0f * u->fov, 0.0f)));
       } else if (u->cameraMode == 2) {
         float ax = (tcx - 0.5f) * (2.0f * OR_PI), ay = (tcy - 0.5f) * OR_PI;
-        dir = mat_rotate(u->rotation, V(cosf(ax) * cosf(ay), sinf(ay), sinf(ax) * cosf(ay)));
+        dir = mat_rotate(u->rotation, V(o_cos(ax) * o_cos(ay), o_sin(ay), o_sin(ax) * o_cos(ay)));
         pos = cam;
       }
       float* o = out + ((size_t)y * W + x) * 8;
@@ -788,7 +812,7 @@ void or_rng(const RmUniforms* u, int W, int H, int count, float* out) {
  * Textures are NEAREST + REPEAT (LoadRenderJobContext.tsx:28-37). */
 static float gaussian_blur_factor(float ox, float oy, float sigma) {
   const float PI = 3.1415926535f; /* display.frag:14 */
-  return 1.0f / (2.0f * PI * sigma * sigma) * expf(-((ox * ox + oy * oy) / (2.0f * sigma * sigma)));
+  return 1.0f / (2.0f * PI * sigma * sigma) * o_exp(-((ox * ox + oy * oy) / (2.0f * sigma * sigma)));
 }
 
 static int wrap_texel(float coord, int size) { /* NEAREST + REPEAT */

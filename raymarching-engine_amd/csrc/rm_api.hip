@@ -523,6 +523,41 @@ int rm_fb_upload(rm_fb* fb, int plane, const float* host) {
 
 void* rm_fb_device_ptr(rm_fb* fb, int plane) { return (fb && plane >= 0 && plane <= 2) ? fb->plane[plane] : nullptr; }
 
+// ---- raw device memory for hosts without an allocator of their own ---------------------
+
+int rm_buffer_create(rm_ctx* ctx, size_t bytes, void** device_ptr) {
+  if (!ctx || !device_ptr || bytes == 0 || bytes > ((size_t)1 << 36)) return fail(ctx, RM_ERR_INVALID, "rm_buffer_create: NULL argument or a size outside 1 .. 2^36 bytes");
+  RM_HIP(ctx, hipSetDevice(ctx->device));
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) return fail(ctx, RM_ERR_DEVICE, "rm_buffer_create: out of device memory");
+  hipError_t e = hipMemsetAsync(p, 0, bytes, ctx->stream);
+  if (e != hipSuccess) { (void)hipFree(p); return fail(ctx, RM_ERR_DEVICE, std::string("rm_buffer_create: ") + hipGetErrorString(e)); }
+  *device_ptr = p;
+  return RM_OK;
+}
+
+int rm_buffer_destroy(rm_ctx* ctx, void* device_ptr) {
+  if (!ctx) return RM_ERR_INVALID;
+  if (!device_ptr) return RM_OK;
+  RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  RM_HIP(ctx, hipFree(device_ptr));
+  return RM_OK;
+}
+
+int rm_buffer_download(rm_ctx* ctx, const void* device_ptr, void* host, size_t bytes) {
+  if (!ctx || !device_ptr || !host) return fail(ctx, RM_ERR_INVALID, "rm_buffer_download: NULL argument");
+  RM_HIP(ctx, hipMemcpyAsync(host, device_ptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RM_OK;
+}
+
+int rm_buffer_upload(rm_ctx* ctx, void* device_ptr, const void* host, size_t bytes) {
+  if (!ctx || !device_ptr || !host) return fail(ctx, RM_ERR_INVALID, "rm_buffer_upload: NULL argument");
+  RM_HIP(ctx, hipMemcpyAsync(device_ptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RM_OK;
+}
+
 // ---- the hot path ---------------------------------------------------------------
 
 static int build_params(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* u, const RmRect* tile, int flags,

@@ -46,6 +46,8 @@ RM_DEV v3 operator*(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
 RM_DEV v3 adds(v3 a, float s) { return V(a.x + s, a.y + s, a.z + s); }
 RM_DEV v3 vabs(v3 a) { return V(fabsf(a.x), fabsf(a.y), fabsf(a.z)); }
 
+#include "rm_pm_math.hpp"
+
 // ---- math policies --------------------------------------------------------------
 
 struct PM {
@@ -54,16 +56,17 @@ struct PM {
   static RM_DEV float rcp(float x) { return 1.0f / x; }
   static RM_DEV float div(float a, float b) { return a / b; }
   static RM_DEV float sqrt(float x) { return sqrtf(x); }
-  // |x|: oracle/rm_oracle.c gl_pow.  A square is a square: pow(x, 2.) = x * x, correctly rounded (every use of the
-  // path with that exponent has it as a literal -- the GGX term :371, schlick's r0 :173 -- so the test folds away
-  // and ~80 instructions of the library pow with it)
-  static RM_DEV float pow(float x, float y) { return y == 2.0f ? x * x : powf(fabsf(x), y); }
-  static RM_DEV float log(float x) { return logf(x); }
-  static RM_DEV float sin(float x) { return sinf(x); }
-  static RM_DEV float cos(float x) { return cosf(x); }
-  static RM_DEV float acos(float x) { return acosf(x); }
-  static RM_DEV float atan2(float y, float x) { return atan2f(y, x); }
-  static RM_DEV void sincos(float x, float& s, float& c) { sincosf(x, &s, &c); }  // the bits of sinf and cosf
+  // Transcendentals: rm_pm_math.hpp, the same text as the oracle's.  pow: on |x| (oracle/rm_oracle.c gl_pow; GLSL leaves
+  // a negative base undefined, SwiftShader takes |x|); pm_pow returns x * x for the exponent 2 -- every use of the path
+  // with that exponent has it as a literal (the GGX term :371, schlick's r0 :173), so the test folds away.
+  static RM_DEV float pow(float x, float y) { return pm_pow(fabsf(x), y); }
+  static RM_DEV float log(float x) { return pm_log(x); }
+  static RM_DEV float exp(float x) { return pm_exp(x); }
+  static RM_DEV float sin(float x) { return pm_sin(x); }
+  static RM_DEV float cos(float x) { return pm_cos(x); }
+  static RM_DEV float acos(float x) { return pm_acos(x); }
+  static RM_DEV float atan2(float y, float x) { return pm_atan2(y, x); }
+  static RM_DEV void sincos(float x, float& s, float& c) { pm_sincos(x, &s, &c); }  // one reduction, the bits of sin and cos
   static RM_DEV void pow_pair(float r, float n, float& r_nm1, float& r_n) { r_nm1 = pow(r, n - 1.0f); r_n = pow(r, n); }
 };
 
@@ -200,9 +203,9 @@ RM_DEV void box_muller(Rng& r, float& ox, float& oy) {
   float b = r.n1 + r.seed;
   const float u2 = gold_noise(r, b - floorf(b));
   const float two_pi_u2 = 2.0f * 3.141592f * u2;
-  const float rad = sqrtf(-2.0f * logf(u1));
+  const float rad = sqrtf(-2.0f * PM::log(u1));
   float sn, cs;
-  sincosf(two_pi_u2, &sn, &cs);  // one range reduction for both
+  PM::sincos(two_pi_u2, sn, cs);  // one range reduction for both
   ox = rad * cs;
   oy = rad * sn;
 }
@@ -360,11 +363,11 @@ struct Sdf<RM_SCENE_TABLE> {
     q = V(M::div(q.x, scale), M::div(q.y, scale), M::div(q.z, scale));
     q = vabs(q) - off;
     float c, s, nx, ny;
-    c = cosf(ang.x); s = sinf(ang.x);
+    PM::sincos(ang.x, s, c);  // angles of a table row: precise in both builds
     nx = M::fma(q.y, -s, q.x * c); ny = M::fma(q.y, c, q.x * s); q.x = nx; q.y = ny;
-    c = cosf(ang.y); s = sinf(ang.y);
+    PM::sincos(ang.y, s, c);
     nx = M::fma(q.z, -s, q.y * c); ny = M::fma(q.z, c, q.y * s); q.y = nx; q.z = ny;
-    c = cosf(ang.z); s = sinf(ang.z);
+    PM::sincos(ang.z, s, c);
     nx = M::fma(q.z, -s, q.x * c); ny = M::fma(q.z, c, q.x * s); q.x = nx; q.z = ny;
     return q;
   }
@@ -669,7 +672,7 @@ struct KifsTrig {
 };
 RM_DEV KifsTrig kifs_trig(const DevScene& sc) {
   const float* a = &sc.p[RM_P_KIFS_ANGLES];
-  return KifsTrig{cosf(a[0]), sinf(a[0]), cosf(a[1]), sinf(a[1]), cosf(a[2]), sinf(a[2])};
+  return KifsTrig{PM::cos(a[0]), PM::sin(a[0]), PM::cos(a[1]), PM::sin(a[1]), PM::cos(a[2]), PM::sin(a[2])};
 }
 template <class M>
 RM_DEV v3 kifs_rotate(v3 t, const KifsTrig& g) {
@@ -749,7 +752,7 @@ RM_DEV v3 scene_emission(const DevScene& sc, v3 p) {
 // (-0 / 0): the same values without the logarithm and the division.
 RM_DEV float inv_exp_dist(float x, float lambda) {
   if (__float_as_uint(lambda) == 0u) return (1.0f - x == 1.0f) ? __builtin_nanf("") : __builtin_inff();
-  return -logf(1.0f - x) / lambda;
+  return -PM::log(1.0f - x) / lambda;
 }
 
 // :172-175
@@ -760,7 +763,7 @@ RM_DEV float schlick(float cos_theta, float n1, float n2) {
 
 // :61-65
 RM_DEV v3 rodrigues(v3 v, v3 k, float theta) {
-  const float c = cosf(theta);
+  const float c = PM::cos(theta);
   const float s = sqrtf(1.0f - c * c);
   return v * c + cross(k, v) * s + k * (dot<PM>(k, v) * (1.0f - c));
 }

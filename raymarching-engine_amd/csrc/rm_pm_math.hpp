@@ -1,0 +1,139 @@
+// rm_pm_math.hpp -- the transcendentals of the parity arithmetic (policy PM, rm_device.hpp).
+// Below the marker line this file is, character for character, oracle/pm_math.h below its leading comment: the
+// oracle (the checker) and these kernels compile the SAME sequence of IEEE double operations, so the strict build and
+// the oracle agree on every sine, logarithm and power bit for bit (tests/test_host_cpu.py compares the two files).
+// Double precision on purpose: the series are short, fp64 add/mul run at half the fp32 rate on gfx950, and the
+// parity build is not the fast path; the fast build uses these only in the shading between the marches.
+#pragma once
+#define PM_FN static __device__ __forceinline__
+#define PM_D2U(x) ((unsigned long long)__double_as_longlong(x))
+#define PM_U2D(u) __longlong_as_double((long long)(u))
+#define PM_F2U(x) __float_as_uint(x)
+// ---- shared text (oracle/pm_math.h) ----
+#define PM_PIO2_HI 1.5707963267341256      /* the first 31 bits of pi/2: k * PM_PIO2_HI is exact for |k| < 2^22 */
+#define PM_PIO2_LO 6.077100506506192e-11   /* pi/2 - PM_PIO2_HI */
+#define PM_LN2_HI 0.6931471803691238       /* the first 32 bits of ln 2 */
+#define PM_LN2_LO 1.9082149292705877e-10   /* ln 2 - PM_LN2_HI */
+#define PM_PI 3.141592653589793
+#define PM_PI_2 1.5707963267948966
+#define PM_PI_4 0.7853981633974483
+
+/* sin and cos of a double: exact reduction for |x| < 3e6, abs. error < 1e-7 up to 1e9; NaN once the reduction has no
+ * correct digit left (|x| beyond ~1e15), for +-Inf and for NaN.  The path's arguments are a few turns at most. */
+PM_FN void pm_sincos_d(double x, double* s, double* c) {
+  const double k = rint(x * 0.6366197723675814);               /* nearest multiple of pi/2 */
+  const double r = (x - k * PM_PIO2_HI) - k * PM_PIO2_LO;      /* |r| <= pi/4 */
+  if (!(r >= -1.0 && r <= 1.0)) { *s = *c = (double)__builtin_nanf(""); return; }  /* |x| beyond ~1e15, Inf, NaN */
+  const double z = r * r;
+  const double sr = r + r * z * (-0.16666666666666666 + z * (0.008333333333333333 + z * (
+      -0.0001984126984126984 + z * (2.7557319223985893e-06 + z * (-2.505210838544172e-08 + z * (
+      1.6059043836821613e-10 + z * (-7.647163731819816e-13)))))));
+  const double cr = 1.0 - 0.5 * z + z * z * (0.041666666666666664 + z * (-0.001388888888888889 + z * (
+      2.48015873015873e-05 + z * (-2.755731922398589e-07 + z * (2.08767569878681e-09 + z * (
+      -1.1470745597729725e-11 + z * (4.779477332387385e-14)))))));
+  const double q = k - 4.0 * floor(k * 0.25);                  /* quadrant 0..3 (NaN for a NaN argument) */
+  if (q == 1.0) { *s = cr; *c = -sr; }
+  else if (q == 2.0) { *s = -sr; *c = -cr; }
+  else if (q == 3.0) { *s = -cr; *c = sr; }
+  else { *s = sr; *c = cr; }
+}
+
+/* natural logarithm of a positive, finite, normal double */
+PM_FN double pm_log_d(double x) {
+  const unsigned long long b = PM_D2U(x);
+  double e = (double)((int)((b >> 52) & 0x7ffull) - 1023);
+  double m = PM_U2D((b & 0x000fffffffffffffull) | 0x3ff0000000000000ull);  /* [1, 2) */
+  if (m > 1.4142135623730951) { m = m * 0.5; e = e + 1.0; }                /* [sqrt 1/2, sqrt 2] */
+  const double t = (m - 1.0) / (m + 1.0);                                    /* log m = 2 atanh t, |t| <= 0.1716 */
+  const double z = t * t;
+  const double p = z * (0.3333333333333333 + z * (0.2 + z * (0.14285714285714285 + z * (
+      0.1111111111111111 + z * (0.09090909090909091 + z * (0.07692307692307693 + z * (
+      0.06666666666666667 + z * (0.058823529411764705 + z * (0.05263157894736842 + z * (
+      0.047619047619047616))))))))));
+  return (e * PM_LN2_HI + 2.0 * t) + (2.0 * t * p + e * PM_LN2_LO);
+}
+
+/* e^t for -150 <= t <= 150 */
+PM_FN double pm_exp_d(double t) {
+  const double k = rint(t * 1.4426950408889634);
+  const double r = (t - k * PM_LN2_HI) - k * PM_LN2_LO;        /* |r| <= ln 2 / 2 */
+  const double p = 1.0 + r + r * r * (0.5 + r * (0.16666666666666666 + r * (0.041666666666666664 + r * (
+      0.008333333333333333 + r * (0.001388888888888889 + r * (0.0001984126984126984 + r * (
+      2.48015873015873e-05 + r * (2.7557319223985893e-06 + r * (2.755731922398589e-07 + r * (
+      2.505210838544172e-08 + r * (2.08767569878681e-09 + r * (1.6059043836821613e-10))))))))))));
+  const double scale = PM_U2D((unsigned long long)((int)k + 1023) << 52);  /* 2^k, normal: |k| <= 217 */
+  return p * scale;
+}
+
+/* arc tangent of a finite double t >= 0 */
+PM_FN double pm_atan_pos_d(double t) {
+  double base = 0.0;
+  if (t > 2.414213562373095) { t = -1.0 / t; base = PM_PI_2; }                      /* atan t = pi/2 - atan(1/t) */
+  else if (t > 0.41421356237309503) { t = (t - 1.0) / (t + 1.0); base = PM_PI_4; }  /* atan t = pi/4 + atan((t-1)/(t+1)) */
+  const double z = t * t;                                                              /* |t| <= tan(pi/8) */
+  return base + (t + t * z * (-0.3333333333333333 + z * (0.2 + z * (-0.14285714285714285 + z * (
+      0.1111111111111111 + z * (-0.09090909090909091 + z * (0.07692307692307693 + z * (
+      -0.06666666666666667 + z * (0.058823529411764705 + z * (-0.05263157894736842 + z * (
+      0.047619047619047616 + z * (-0.043478260869565216 + z * (0.04 + z * (-0.037037037037037035 + z * (
+      0.034482758620689655 + z * (-0.03225806451612903))))))))))))))));
+}
+
+PM_FN float pm_sin(float x) { double s, c; pm_sincos_d((double)x, &s, &c); return (float)s; }
+PM_FN float pm_cos(float x) { double s, c; pm_sincos_d((double)x, &s, &c); return (float)c; }
+PM_FN void pm_sincos(float x, float* s, float* c) { double sd, cd; pm_sincos_d((double)x, &sd, &cd); *s = (float)sd; *c = (float)cd; }
+
+/* log(x): NaN for x < 0 or NaN, -Inf for +-0, +Inf for +Inf */
+PM_FN float pm_log(float x) {
+  if (x != x || x < 0.0f) return x != x ? x : __builtin_nanf("");
+  if (x == 0.0f) return -__builtin_inff();
+  if (x == __builtin_inff()) return x;
+  return (float)pm_log_d((double)x);
+}
+
+/* exp(x): 0 for very negative, +Inf for very positive arguments, NaN for NaN */
+PM_FN float pm_exp(float x) {
+  if (x != x) return x;
+  if (x > 100.0f) return __builtin_inff();
+  if (x < -120.0f) return 0.0f;
+  return (float)pm_exp_d((double)x);
+}
+
+/* pow(x, y) for x >= 0 (GLSL leaves x < 0 undefined; callers pass |x|): the cases of C's powf for a non-negative base */
+PM_FN float pm_pow(float x, float y) {
+  if (y == 2.0f) return x * x;  /* exactly what correct rounding gives, without the 1-in-10^5 */
+  if (y == 0.0f || x == 1.0f) return 1.0f;
+  if (x != x || y != y) return x + y;
+  if (x < 0.0f) return __builtin_nanf("");
+  const float inf = __builtin_inff();
+  if (x == 0.0f) return y > 0.0f ? 0.0f : inf;
+  if (y == inf || y == -inf) return ((x > 1.0f) == (y > 0.0f)) ? inf : 0.0f;
+  if (x == inf) return y > 0.0f ? inf : 0.0f;
+  double t = (double)y * pm_log_d((double)x);
+  if (t > 100.0) return inf;
+  if (t < -120.0) return 0.0f;
+  return (float)pm_exp_d(t);
+}
+
+/* acos(x): NaN outside [-1, 1] */
+PM_FN float pm_acos(float x) {
+  if (x != x || x > 1.0f || x < -1.0f) return x != x ? x : __builtin_nanf("");
+  if (x == -1.0f) return (float)PM_PI;
+  const double d = (double)x;
+  return (float)(2.0 * pm_atan_pos_d(sqrt((1.0 - d) / (1.0 + d))));
+}
+
+/* atan2(y, x) with C's conventions for zeros and infinities */
+PM_FN float pm_atan2(float y, float x) {
+  if (x != x || y != y) return x + y;
+  const float inf = __builtin_inff();
+  const int xneg = (int)(PM_F2U(x) >> 31), yneg = (int)(PM_F2U(y) >> 31);
+  const float ax = xneg ? -x : x, ay = yneg ? -y : y;
+  double a;                                   /* the angle of (|x|, |y|) in [0, pi/2] */
+  if (ay == 0.0f) a = 0.0;
+  else if (ax == 0.0f) a = PM_PI_2;
+  else if (ay == inf) a = ax == inf ? PM_PI_4 : PM_PI_2;
+  else if (ax == inf) a = 0.0;
+  else a = pm_atan_pos_d((double)ay / (double)ax);
+  if (xneg) a = PM_PI - a;
+  return yneg ? -(float)a : (float)a;
+}

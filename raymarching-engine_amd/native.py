@@ -27,7 +27,7 @@ LIB_PATH = Path(os.environ.get("RM_LIB") or Path(__file__).resolve().parent / "l
 EXPORTS = [
     "rm_abi_version", "rm_material_default", "rm_ctx_create", "rm_ctx_destroy", "rm_last_error", "rm_ctx_set_stream",
     "rm_ctx_set_retire_eps", "rm_ctx_set_samples_in_flight", "rm_ctx_set_cost_order", "rm_debug_counters", "rm_sync", "rm_scene_create", "rm_scene_destroy", "rm_fb_create", "rm_fb_create_striped", "rm_fb_rows", "rm_fb_width", "rm_fb_height", "rm_fb_wrap", "rm_fb_clear", "rm_fb_destroy",
-    "rm_fb_download", "rm_fb_upload", "rm_fb_device_ptr", "rm_render_sample", "rm_render_samples", "rm_ctx_set_sample_batch", "rm_render_timed",
+    "rm_fb_download", "rm_fb_upload", "rm_fb_device_ptr", "rm_buffer_create", "rm_buffer_destroy", "rm_buffer_download", "rm_buffer_upload", "rm_render_sample", "rm_render_samples", "rm_ctx_set_sample_batch", "rm_render_timed",
     "rm_probe", "rm_probe_camera", "rm_probe_rng", "rm_assemble_striped", "rm_assemble_striped_bytes", "rm_present", "rm_present_planes", "rm_present_device", "rm_present_rows",
 ]
 
@@ -89,6 +89,10 @@ def load_library():
         "rm_ctx_set_retire_eps": (ip, [vp, C.c_float]),
         "rm_ctx_set_samples_in_flight": (ip, [vp, C.c_int]),
         "rm_ctx_set_sample_batch": (ip, [vp, C.c_int]),
+        "rm_buffer_create": (ip, [vp, C.c_size_t, C.POINTER(C.c_void_p)]),
+        "rm_buffer_destroy": (ip, [vp, vp]),
+        "rm_buffer_download": (ip, [vp, vp, vp, C.c_size_t]),
+        "rm_buffer_upload": (ip, [vp, vp, vp, C.c_size_t]),
         "rm_ctx_set_cost_order": (ip, [vp, C.c_int]),
         "rm_debug_counters": (ip, [vp, C.POINTER(C.c_ulonglong), ip]),
         "rm_sync": (ip, [vp]),
@@ -138,6 +142,31 @@ def _fp(a: np.ndarray):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
 
+class DeviceBuffer:
+    """rm_buffer_*: `nbytes` of device memory owned by the library; .ptr is the device address."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = C.c_void_p()
+        ctx._check(ctx.lib.rm_buffer_create(ctx.h, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def download(self, dtype=np.uint8) -> np.ndarray:
+        out = np.empty(self.nbytes // np.dtype(dtype).itemsize, dtype)
+        self.ctx._check(self.ctx.lib.rm_buffer_download(self.ctx.h, self.ptr, out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
+    def upload(self, a: np.ndarray):
+        a = np.ascontiguousarray(a)
+        assert a.nbytes <= self.nbytes
+        self.ctx._check(self.ctx.lib.rm_buffer_upload(self.ctx.h, self.ptr, a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def destroy(self):
+        if self.ptr:
+            self.ctx._check(self.ctx.lib.rm_buffer_destroy(self.ctx.h, self.ptr))
+            self.ptr = None
+
+
 class Context:
     def __init__(self, device: int = 0):
         self.lib = load_library()
@@ -170,6 +199,10 @@ class Context:
     def set_samples_in_flight(self, n: int):
         """Consecutive full-mode samples that may overlap on the GPU (1 = none); the planes get the same bits."""
         self._check(self.lib.rm_ctx_set_samples_in_flight(self.h, int(n)))
+
+    def buffer(self, nbytes: int) -> "DeviceBuffer":
+        """Zero-filled raw device memory (for rm_present_rows / rm_assemble_striped_bytes on hosts without torch)."""
+        return DeviceBuffer(self, nbytes)
 
     def set_sample_batch(self, n: int):
         """Samples per launch of render_samples (0 = automatic, 1 = one launch per sample, up to 8); same bits."""

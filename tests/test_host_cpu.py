@@ -212,3 +212,82 @@ def test_reference_scissor_option():
     assert (t.x, t.y, t.w, t.h) == (30, 20, 60, 40)  # scissor(30, 20, 60, 40): to the right and top edges
     t = J.tile_rect(schema, 1, 1)
     assert (t.x, t.y, t.w, t.h) == (30, 20, 30, 20)
+
+
+def test_portable_math_text_is_shared_by_oracle_and_kernels():
+    """The transcendentals of the parity arithmetic exist twice -- oracle/pm_math.h for the checker,
+    csrc/rm_pm_math.hpp for the HIP kernels (the product links nothing from oracle/) -- and must be the same
+    sequence of operations: from the first constant on, the two files are the same text."""
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    a = (root / "oracle" / "pm_math.h").read_text()
+    b = (root / "raymarching-engine_amd" / "csrc" / "rm_pm_math.hpp").read_text()
+    mark = "#define PM_PIO2_HI"
+    assert mark in a and mark in b
+    assert a[a.index(mark):] == b[b.index(mark):]
+    assert "PM_FN" in a and "__device__" in b[:b.index(mark)]
+
+
+def test_portable_math_is_correctly_rounded_on_samples():
+    """oracle/pm_math.h against numpy's double-precision functions rounded to float: equal on every sample of the
+    ranges the path uses (the double series are good to ~1e-14; a float disagrees only when the true value is
+    that close to a rounding boundary)."""
+    import ctypes as C
+    import subprocess
+    import tempfile
+
+    import numpy as np
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    src = r"""
+#include <math.h>
+#include <string.h>
+#define PM_FN static inline
+static inline unsigned long long PM_D2U(double x) { unsigned long long u; memcpy(&u, &x, 8); return u; }
+static inline double PM_U2D(unsigned long long u) { double x; memcpy(&x, &u, 8); return x; }
+static inline unsigned int PM_F2U(float x) { unsigned int u; memcpy(&u, &x, 4); return u; }
+#include "pm_math.h"
+#define F1(n) void t_##n(const float* x, float* o, int c) { for (int i = 0; i < c; i++) o[i] = pm_##n(x[i]); }
+F1(sin) F1(cos) F1(log) F1(exp) F1(acos)
+void t_pow(const float* x, const float* y, float* o, int c) { for (int i = 0; i < c; i++) o[i] = pm_pow(x[i], y[i]); }
+void t_atan2(const float* y, const float* x, float* o, int c) { for (int i = 0; i < c; i++) o[i] = pm_atan2(y[i], x[i]); }
+"""
+    with tempfile.TemporaryDirectory() as d:
+        (Path(d) / "t.c").write_text(src)
+        subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-I", str(root / "oracle"), str(Path(d) / "t.c"), "-o", str(Path(d) / "t.so"), "-lm"], check=True)
+        lib = C.CDLL(str(Path(d) / "t.so"))
+
+        def call(name, *args):
+            args = [np.ascontiguousarray(a, np.float32) for a in args]
+            out = np.empty_like(args[0])
+            getattr(lib, name)(*[a.ctypes.data_as(C.c_void_p) for a in args], out.ctypes.data_as(C.c_void_p), C.c_int(len(out)))
+            return out
+
+        rng = np.random.default_rng(5)
+        n = 200_000
+        same = lambda got, want: ((got == want.astype(np.float32)) | (np.isnan(got) & np.isnan(want))).all()
+        x = rng.uniform(-60, 60, n).astype(np.float32)
+        assert same(call("t_sin", x), np.sin(x.astype(np.float64))) and same(call("t_cos", x), np.cos(x.astype(np.float64)))
+        x = np.exp(rng.uniform(-80, 80, n)).astype(np.float32)
+        assert same(call("t_log", x), np.log(x.astype(np.float64)))
+        x = rng.uniform(-85, 85, n).astype(np.float32)
+        assert same(call("t_exp", x), np.exp(x.astype(np.float64)))
+        x = rng.uniform(-1, 1, n).astype(np.float32)
+        assert same(call("t_acos", x), np.arccos(x.astype(np.float64)))
+        a, b = np.exp(rng.uniform(-3, 3, n)).astype(np.float32), rng.uniform(-10, 10, n).astype(np.float32)
+        assert same(call("t_pow", a, b), np.power(a.astype(np.float64), b.astype(np.float64)))
+        y, x = rng.normal(size=n).astype(np.float32), rng.normal(size=n).astype(np.float32)
+        assert same(call("t_atan2", y, x), np.arctan2(y.astype(np.float64), x.astype(np.float64)))
+        # the conventions of C's functions at the edges
+        inf, nan = np.float32(np.inf), np.float32(np.nan)
+        edge = np.array([0.0, -0.0, 1.0, -1.0, inf, -inf, nan, 2.0, 0.5], np.float32)
+        ys, xs = [v.ravel() for v in np.meshgrid(edge, edge)]
+        got, want = call("t_atan2", ys, xs), np.arctan2(ys.astype(np.float64), xs.astype(np.float64))
+        assert same(got, want) and (np.signbit(got) == np.signbit(want))[~np.isnan(want)].all()
+        with np.errstate(all="ignore"):
+            assert same(call("t_log", edge), np.log(edge.astype(np.float64)))
+            assert same(call("t_acos", edge), np.arccos(edge.astype(np.float64)))
+            assert same(call("t_pow", np.abs(xs), ys), np.power(np.abs(xs).astype(np.float64), ys.astype(np.float64)))
+        assert np.isnan(call("t_sin", np.array([inf, nan, 1e30], np.float32))).all()
