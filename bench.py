@@ -109,6 +109,9 @@ def cpu_baseline(sc, schema, target_seconds=12.0):
 
     O.build()
     O.set_tan_mode(O.TAN_PORTABLE)
+    # the C library's float transcendentals: what a CPU port would call, and about twice as fast as the portable
+    # double-precision ones the oracle uses as the bit-exact checker (oracle/pm_math.h) -- the faster one is the baseline
+    O.set_math_mode(O.MATH_LIBM)
     W, H = schema["render"]["width"], schema["render"]["height"]
     u = J.uniforms_from_schema(schema, (0.5, 1.0 / 3.0))
     cores = O.host_cores()
@@ -130,7 +133,7 @@ def cpu_baseline(sc, schema, target_seconds=12.0):
     px = len(rows) * W
     return {"value": px / t / 1e6, "unit": "Mpixels/s", "cores": cores, "kind": "port",
             "sample": f"every {max(1, H // n)}th row of the {W}x{H} frame ({len(rows)} rows, {px} pixel-samples, {t:.1f} s), "
-                      "oracle/rm_oracle.c with OpenMP over the rows"}
+                      "oracle/rm_oracle.c with OpenMP over the rows, libm transcendentals"}
 
 
 def self_launch(args):

@@ -2,13 +2,18 @@
 committed goldens.  All of these need a real MI355X: run with -m gpu.
 
 Bars:
-  * bit-exact: the random stream, texcoord, the camera block, and every scene
-    whose SDF is + - * / sqrt floor abs min max only (strict build);
-  * scenes through pow/sin/cos/acos/atan/log: ocml and libm are both ~1 ulp
-    libraries but not the same bits, so a stated tolerance;
-  * whole images: fraction of pixels whose relative difference exceeds 1e-5
-    (a last-bit difference at a silhouette or a branch pick is a different
-    pixel), plus bit-exact invariances at full size.
+  * strict build against the oracle: BIT-EXACT everywhere -- the random
+    stream, texcoord, the camera block, every SDF, castRay, normals, whole
+    images of every scene at every size.  Scenes through pow / sin / cos /
+    acos / atan / log included: the oracle and the kernels compile the same
+    transcendentals (oracle/pm_math.h = csrc/rm_pm_math.hpp);
+  * strict build against the reference GLSL's goldens (SwiftShader's own
+    transcendentals and min/max conventions): bit-exact where the scene has
+    none, otherwise the fraction of pixels whose relative difference exceeds
+    1e-5 (a last-bit difference at a silhouette or a branch pick is a
+    different pixel; SURVEY.md 7.3);
+  * fast build: statistics against the strict build / the oracle, per-pixel
+    agreement printed and bounded from below.
 """
 import os
 import tempfile
@@ -109,10 +114,7 @@ def test_camera_block(ctx, mode):
     schema = J.make_schema(GC.build_scene("sphere"), 240, 135, camera=mode, rotation=GC.ROT, position=(0.3, -0.2, -3.0), dof_distance=2.5)
     u = J.uniforms_from_schema(schema, (0.5, 1 / 3))
     got, want = ctx.probe_camera(u, 240, 135), O.camera(u, 240, 135)
-    if mode == "panoramic":  # sin/cos: ocml vs libm
-        assert np.abs(got - want).max() <= 5e-7
-    else:
-        assert same_bits(got, want).all()
+    assert same_bits(got, want).all()  # panoramic included: sin / cos are the same text on both sides
 
 
 @pytest.mark.parametrize("name", list(GC.SCENES))
@@ -122,13 +124,9 @@ def test_sdf_probe(ctx, name):
     h = ctx.create_scene(sc)
     got = ctx.probe(h, abi.RM_PROBE_SDF, z["points"])
     want = O.eval_sdf(sc, z["points"])
+    assert same_bits(got, want).all()  # every scene: the oracle's bits
     if name in ("sphere", "csg64", "csg_mixed", "lattice"):
-        assert same_bits(got, want).all()
-        assert same_bits(got, z["sdf"]).all()  # = the reference GLSL's bits
-    else:
-        d = np.abs(got - want)
-        p99, mx = {"mandelbulb": (2e-6, 2e-4)}.get(name, (2e-6, 4e-6))
-        assert np.percentile(d, 99) <= p99 and d.max() <= mx
+        assert same_bits(got, z["sdf"]).all()  # no transcendentals: = the reference GLSL's bits under SwiftShader too
     # fast build: hardware-rate divide/sqrt/transcendentals
     fast = ctx.probe(h, abi.RM_PROBE_SDF, z["points"], flags=FAST)
     d = np.abs(fast - want) / np.maximum(1.0, np.abs(want))
@@ -146,14 +144,9 @@ def test_cast_ray_and_normal_probe(ctx, name):
     want = O.cast_ray(sc, z["rays"], steps)
     n_got = ctx.probe(h, abi.RM_PROBE_NORMAL, z["normal_points"], 1e-5)
     n_want = O.normal(sc, z["normal_points"], 1e-5)
+    assert same_bits(got, want).all() and same_bits(n_got, n_want).all()  # every scene: the oracle's bits
     if name in ("sphere", "csg64", "lattice"):
-        assert same_bits(got, want).all() and same_bits(got, z["end"]).all()
-        assert same_bits(n_got, n_want).all()
-    else:
-        fin = np.isfinite(want).all(1)
-        assert np.mean(fin == np.isfinite(got).all(1)) >= 0.999
-        d = rel_diff(want[fin], got[fin]).max(1)
-        assert np.percentile(d, 95) <= {"mandelbulb": 2e-2}.get(name, 1e-5)
+        assert same_bits(got, z["end"]).all()  # no transcendentals: = the reference GLSL's bits under SwiftShader too
     h.destroy()
 
 
@@ -170,34 +163,23 @@ def test_material_probe(ctx):
 
 # ---- whole main() -------------------------------------------------------------
 
-# fraction of pixels allowed to differ by more than 1e-5 from the oracle (strict build)
-IMAGE_BARS = {"mandelbulb_preview": 0.03, "mandelbulb_full_light": 0.08, "fractal1_full_2b": 0.05, "tree_preview": 0.02,
-              "sphere_full_dof_fog": 0.02, "csg_mixed_full_2b": 0.02,
-              # round 2, measured colour / normal plane (the normal plane's bar is twice the colour's):
-              # 0.006/0.062, 0.004/0.000, 0.025/0.044, 0.023/0.055, 0.105/0.105, 0.002/0.000, 0.000/0.000
-              "fractal1_live_default": 0.035, "menger_full_2b": 0.015, "tree_full_2b": 0.04, "smooth_tree_full_2b": 0.04,
-              "rotation_fractal_full_2b": 0.12, "sphere_sss_full_3b": 0.01, "sphere_full_3lights": 0.005,
-              "csg_repeat_fold_full_2b": 0.06, "csg_kifs_full_2b": 0.07}
-
-
 @pytest.mark.parametrize("pipeline", [MK, WF], ids=["megakernel", "wavefront"])
 @pytest.mark.parametrize("case", list(GC.IMAGES))
 def test_whole_main_image_vs_oracle(ctx, case, pipeline):
+    """The strict build against the oracle: BIT-IDENTICAL planes on every case -- also where the path goes through
+    sines, logarithms and powers (Mandelbulb, KIFS folds, Box-Muller, schlick), because both sides compile the same
+    transcendentals (oracle/pm_math.h = csrc/rm_pm_math.hpp); any NaN counts as equal to any NaN.  (Until round 2
+    the two sides used libm and ocml and up to 12 % of the pixels of a chaotic scene differed by > 1e-5.)"""
     sc, samples, schema = GC.image_schema(case)
     z = load("image_" + case)
     noises = z["rand_noise"]
     got = render_gpu(ctx, sc, schema, noises, STRICT | pipeline)
     want = render_oracle(sc, schema, noises, nan_mode=O.NAN_IEEE)
     full = schema["render"]["renderMode"] == "full"
-    bar = IMAGE_BARS.get(case, 0.005)
     for k in range(3 if full else 1):
-        d = rel_diff(want[k], got[k]).max(-1)
-        # plane 1 holds the forward-difference normal (delta = 1e-5, on the fp32
-        # noise floor): where sdf() goes through ocml vs libm transcendentals it
-        # differs in more pixels than the colour does
-        bar_k = bar * (2.0 if k == 1 else 1.0)
-        print(f"{case} plane {k}: {np.mean(d > 1e-5):.4f} of pixels differ from the oracle by > 1e-5 (bar {bar_k})")
-        assert np.mean(d > 1e-5) <= bar_k, f"plane {k}: {np.mean(d > 1e-5):.4f} of pixels differ from the oracle"
+        eq = same_bits(want[k], got[k])
+        print(f"{case} plane {k}: bit-equal to the oracle {eq.mean():.6f}")
+        assert eq.all(), f"plane {k}: {1.0 - eq.mean():.6f} of the values differ from the oracle"
     # against the reference GLSL itself.  It ran under the x86 min/max NaN
     # convention (SwiftShader), the GPU uses IEEE minNum/maxNum: compare the
     # pixels on which the two conventions agree (per the oracle run both ways)
@@ -291,21 +273,19 @@ def _c3b(width=3840, height=2160, counts=(256,)):
 # Two 128x32 crops of the headline frame, both across the fractal's silhouette (left edge at mid height, and the upper
 # right where the light falls): 30-40 % sky, 20-25 % lit surface, the rest surface in shadow.
 C3B_CROPS = {"left": (1340, 1064), "lit": (2336, 1280)}
-# What each build achieves against the oracle (printed by the test) and its bar, a little below the achieved value so that a
-# regression shows.  Measured on MI355X, round 2, identical for both pipelines:
-#   strict left: within 1e-3 0.8860, within 1e-5 0.8159, bit-equal 0.7837, mean error 0.0186
-#   fast   left: within 1e-3 0.8879, within 1e-5 0.8186, bit-equal 0.7839, mean error 0.0036
-#   strict lit : within 1e-3 0.8403, within 1e-5 0.7815, bit-equal 0.7407, mean error 0.0054
-#   fast   lit : within 1e-3 0.8367, within 1e-5 0.7810, bit-equal 0.7402, mean error 0.0098
+# The strict build is BIT-IDENTICAL to the oracle on these crops (same transcendentals on both sides since round 2:
+# oracle/pm_math.h = csrc/rm_pm_math.hpp).  What the fast build achieves against the oracle (printed by the test) and its
+# bar, a little below the achieved value so that a regression shows.  Measured on MI355X, round 2, identical for both
+# pipelines:
+#   fast   left: within 1e-3 0.8684, within 1e-5 0.8071, bit-equal 0.8013, mean error 0.0049
+#   fast   lit : within 1e-3 0.8328, within 1e-5 0.7754, bit-equal 0.7700, mean error 0.0077
 # (within = fraction of crop pixels within 1e-3 / 1e-5, relative to max(1, |want|); mean error = |mean(got) - mean(want)| /
 # mean(want) over the crop.)  The pixels that differ are lit surface pixels: the delta = 1e-5 normal of a point that the
-# march reached with different last bits (ocml vs libm in the strict build, the trig-free estimator in the fast one) is a
-# different sample of the same noisy normal; the fast build is no further from the oracle than the strict one.
+# march reached with different last bits (the trig-free estimator on hardware-rate operations) is a different sample of
+# the same noisy normal.  Sky pixels are bit-identical in both builds (the march has no part in their colour).
 C3B_CROP_BARS = {
-    ("strict", "left"): dict(within_1e3=0.86, within_1e5=0.79, mean_err=0.03),
-    ("fast", "left"): dict(within_1e3=0.86, within_1e5=0.79, mean_err=0.03),
-    ("strict", "lit"): dict(within_1e3=0.81, within_1e5=0.75, mean_err=0.03),
-    ("fast", "lit"): dict(within_1e3=0.80, within_1e5=0.75, mean_err=0.03),
+    ("fast", "left"): dict(within_1e3=0.85, within_1e5=0.79, mean_err=0.03),
+    ("fast", "lit"): dict(within_1e3=0.81, within_1e5=0.75, mean_err=0.03),
 }
 
 
@@ -315,35 +295,38 @@ C3B_CROP_BARS = {
 def test_c3b_crop_matches_oracle(ctx, build, pipeline, crop):
     """Headline config (Mandelbulb 3840x2160, full, [256], 1 light): 128x32
     crops across the fractal's silhouette rendered with global coordinates,
-    against the oracle on the same pixels.  Sky pixels must match exactly.  On
-    the fractal itself the distance estimator iterates z -> z^8 + c eight
-    times, which amplifies the last-bit differences between ocml and libm
-    (strict build) or the trig-free evaluation (fast build), and the shading
-    adds forward-difference normals with delta = 1e-5: the strict build is held
-    to per-pixel bars, the fast build to a statistical one (its per-pixel
-    agreement is printed, and bounded from below so that a regression shows)."""
+    against the oracle on the same pixels.  The strict build must give the
+    oracle's bits on all three planes.  The fast build evaluates the distance
+    estimator trig-free on hardware-rate operations, and the estimator iterates
+    z -> z^8 + c eight times under forward-difference normals with delta =
+    1e-5, which amplifies last-bit differences: it is held to a statistical
+    bar (its per-pixel agreement is printed, and bounded from below so that a
+    regression shows); its sky pixels must still match exactly."""
     sc, schema = _c3b()
     (x0, y0), w, h = C3B_CROPS[crop], 128, 32
     tile = abi.RmRect(x0, y0, w, h)
     noises = GC.halton_pairs(1)
     flags = STRICT if build == "strict" else FAST
-    got = render_gpu(ctx, sc, schema, noises, flags | pipeline, rows=(y0, h), tile=tile)
-    want = render_oracle(sc, schema, noises, rows=(y0, h), tile=(x0, y0, w, h))
-    depth = want[2][:, x0 : x0 + w, 3]
-    got, want = got[0][:, x0 : x0 + w], want[0][:, x0 : x0 + w]
-    d = rel_diff(want, got).max(-1)
+    got3 = render_gpu(ctx, sc, schema, noises, flags | pipeline, rows=(y0, h), tile=tile)
+    want3 = render_oracle(sc, schema, noises, rows=(y0, h), tile=(x0, y0, w, h))
+    depth = want3[2][:, x0 : x0 + w, 3]
+    got, want = got3[0][:, x0 : x0 + w], want3[0][:, x0 : x0 + w]
     sky = depth > 1e5  # the camera ray left the scene: the escape branch puts it 1e6 away (raymarcher.frag:278-283)
     assert 0.05 < sky.mean() < 0.95, "the crop should straddle the silhouette"
+    if build == "strict":
+        for k in range(3):
+            assert same_bits(got3[k], want3[k]).all(), f"plane {k}"
+        return
+    d = rel_diff(want, got).max(-1)
     bars = C3B_CROP_BARS[(build, crop)]
     w3, w5 = float(np.mean(d <= 1e-3)), float(np.mean(d <= 1e-5))
     merr = float(abs(got[..., :3].mean() - want[..., :3].mean()) / want[..., :3].mean())
     print(f"\nc3b {crop} crop {build}: within 1e-3 {w3:.4f} (bar {bars['within_1e3']}), within 1e-5 {w5:.4f} (bar {bars['within_1e5']}), "
           f"bit-equal {float(np.mean(d == 0)):.4f}, mean error {merr:.5f} (bar {bars['mean_err']}), lit pixels {float(np.mean((want[..., :3].sum(-1) > 0.02) & ~sky)):.3f}; "
-          f"sky pixels {float(sky.mean()):.3f}: bit-equal {float((d[sky] == 0).mean()):.4f}, max {float(d[sky].max()):.3g}")
+          f"sky pixels {float(sky.mean()):.3f}: bit-equal {float((d[sky] == 0).mean()):.4f}")
     # an escaped ray is moved 1e6 along its direction and then lit like a surface point (raymarcher.frag:278-283,
-    # :354-373): its colour passes through pow / log / sincos of the shading (ocml against libm, 1-ulp libraries with
-    # different last bits), in both builds alike -- the march has no part in it
-    assert (d[sky] <= 1e-4).all() and (d[sky] == 0).mean() >= 0.85
+    # :354-373): the shading is the parity arithmetic in both builds, the march has no part in it
+    assert (d[sky] == 0).all()
     assert w3 >= bars["within_1e3"] and w5 >= bars["within_1e5"] and merr <= bars["mean_err"]
     assert np.array_equal(got[..., 3], want[..., 3])
 
@@ -351,11 +334,9 @@ def test_c3b_crop_matches_oracle(ctx, build, pipeline, crop):
 @pytest.mark.parametrize("mode", ["preview", "full"])
 def test_c2_full_size(ctx, mode):
     """BASELINE.json configs[1]: the single sphere at 1920x1080, preview [128] and full [128] + 1 light, the whole
-    frame against the oracle, both implementations (raymarcher.frag:178-388).  The SDF is + - * / sqrt only, so
-    everything that depends on the march alone is BIT-EXACT: the preview image, and in full mode the normal plane and
-    the sample count.  Full-mode colour, albedo and depth also pass through pow / log / sincos in the shading (GGX term
-    :371, schlick :172-175, sphereSample :96-101 -> the offset ray position :334), where ocml and libm are 1-ulp
-    libraries with different last bits: those planes are held to 1e-5 relative (fractions printed)."""
+    frame against the oracle, both implementations (raymarcher.frag:178-388): every plane BIT-EXACT -- the march
+    (+ - * / sqrt only) and the shading's pow / log / sincos (GGX term :371, schlick :172-175, sphereSample :96-101),
+    which the oracle and the strict build take from the same text (oracle/pm_math.h = csrc/rm_pm_math.hpp)."""
     sc = S.single_sphere()
     lights = GC.LIGHT if mode == "full" else ()
     schema = J.make_schema(sc, 1920, 1080, counts=(128,), render_mode=mode, position=(0, 0, -3.0), lights=lights)
@@ -363,17 +344,9 @@ def test_c2_full_size(ctx, mode):
     want = render_oracle(sc, schema, noises)
     for mk in (MK, WF):
         got = render_gpu(ctx, sc, schema, noises, STRICT | mk)
-        if mode == "preview":
-            eq = same_bits(want[0], got[0])
-            assert eq.all(), f"preview pipeline {mk}: {int((~eq).sum())} values differ"
-            continue
-        assert same_bits(want[1], got[1]).all(), "normal + dofRadius plane"
-        assert np.array_equal(want[0][..., 3], got[0][..., 3])
-        for k in (0, 2):
-            d = rel_diff(want[k], got[k]).max(-1)
-            print(f"\nc2 full plane {k} pipeline {mk}: bit-equal {float(np.mean(d == 0)):.5f}, within 1e-6 {float(np.mean(d <= 1e-6)):.5f}, "
-                  f"within 1e-5 {float(np.mean(d <= 1e-5)):.5f}, max {float(d.max()):.3g}")
-            assert np.mean(d <= 1e-5) >= 0.999
+        for k in range(1 if mode == "preview" else 3):
+            eq = same_bits(want[k], got[k])
+            assert eq.all(), f"{mode} pipeline {mk} plane {k}: {int((~eq).sum())} values differ"
 
 
 def test_c3b_full_size_256_steps_striped_equals_single(ctx):
@@ -472,9 +445,9 @@ C45 = {
 @pytest.mark.parametrize("cfg", ["c4", "c5"])
 def test_c4_c5_crops_match_oracle(ctx, cfg, build):
     """64-primitive smooth-union CSG at 4096^2 (full [128], 1 light) and 8192^2 (full [128,64,64], soft light): a
-    256x64 crop straddling the silhouette, as a GPU of the 8-way split holds it (global coordinates).  The SDF is
-    + - * / sqrt min max only: the strict build is held to (near) bit equality; the fast build (FMA, v_rcp, v_sqrt)
-    moves hit points by ulps, which the random walk after bounce 0 amplifies: statistical bar, per-pixel agreement printed."""
+    256x64 crop straddling the silhouette, as a GPU of the 8-way split holds it (global coordinates).  The strict
+    build gives the oracle's bits on all three planes; the fast build (FMA, v_rcp, v_sqrt) moves hit points by ulps,
+    which the random walk after bounce 0 amplifies: statistical bar, per-pixel agreement printed."""
     c = C45[cfg]
     sc = S.csg64()
     schema = J.make_schema(sc, c["w"], c["h"], counts=c["counts"], render_mode="full", position=(0, 0, -5.0), lights=getattr(GC, c["light"]))
@@ -491,10 +464,10 @@ def test_c4_c5_crops_match_oracle(ctx, cfg, build):
     w5 = float(np.mean(d <= 1e-5))
     merr = float(abs(g[..., :3].mean() - w[..., :3].mean()) / w[..., :3].mean())
     print(f"\n{cfg} crop {build}: bit-equal {float(np.mean(d == 0)):.4f}, within 1e-5 {w5:.4f}, within 1e-3 {float(np.mean(d <= 1e-3)):.4f}, mean error {merr:.5f}")
-    # measured (MI355X, round 2): c4 strict bit-equal 1.0000; c4 fast bit-equal 0.981, mean error 0.0095;
-    #                             c5 strict bit-equal 0.966, within 1e-5 0.9915 (shading pow/log/sincos, 3 bounces); c5 fast within 1e-3 0.951, mean error 0.0025
+    # measured (MI355X, round 2): c4 fast bit-equal 0.981, mean error 0.0095; c5 fast within 1e-3 0.951, mean error 0.0025
     if build == "strict":
-        assert w5 >= (0.999 if cfg == "c4" else 0.98)
+        for k in range(3):
+            assert same_bits(got[k], want[k]).all(), f"plane {k}"
     else:
         assert merr <= 0.03 and float(np.mean(d <= 1e-3)) >= (0.97 if cfg == "c4" else 0.93)
     assert np.array_equal(g[..., 3], w[..., 3])
@@ -526,17 +499,19 @@ def test_c4_fast_build_statistics_vs_oracle(ctx):
 
 @pytest.mark.parametrize("name", ["display_dof", "display_nodof"])
 def test_present_pass(ctx, name):
-    """rm_present (display.frag:16-64) on the golden's accumulated planes: within one
-    code value of the oracle and of the reference's canvas; and on a rendered frame."""
+    """rm_present (display.frag:16-64) on the golden's accumulated planes: the oracle's
+    bytes exactly (same exp / pow text on both sides, same taps in the same order), within one
+    code value of the reference's canvas (SwiftShader's own exp / pow); and on a rendered frame."""
     z = load(name)
     h, w = z["color"].shape[:2]
     fb = ctx.create_framebuffer(w, h)
     fb.upload(0, z["color"])
     fb.upload(1, z["normal_dof"])
     got = fb.present(int(z["samples"]))
-    for want in (O.present(z["color"], z["normal_dof"], int(z["samples"])), z["rgba8"]):
-        d = np.abs(got.astype(int) - want.astype(int))
-        assert d.max() <= 1 and np.mean(d == 0) >= 0.99
+    assert np.array_equal(got, O.present(z["color"], z["normal_dof"], int(z["samples"])))
+    d = np.abs(got.astype(int) - z["rgba8"].astype(int))
+    print(f"{name}: code values equal to the reference's canvas {np.mean(d == 0):.6f}, max difference {d.max()}")
+    assert d.max() <= 1 and np.mean(d == 0) >= 0.995
     from raymarching_engine_amd import capture, native
 
     path = os.path.join(tempfile.mkdtemp(), "frame.png")  # the capture of index.tsx:470-476
@@ -552,7 +527,7 @@ def test_present_pass(ctx, name):
 
 def test_present_pass_blur_radii_and_wrap(ctx):
     """The LDS-staged blur on a frame whose DoF radius runs from 0 to the 16-pixel cap across the image, borders
-    included (REPEAT taps wrap): the same RGBA8 as the oracle's display.frag within one code value, and tiles
+    included (REPEAT taps wrap): the same RGBA8 as the oracle's display.frag, byte for byte, and tiles
     without blur (radius 0 everywhere) equal the unblurred tone map exactly."""
     rng = np.random.default_rng(11)
     w, h, n = 203, 117, 4
@@ -567,9 +542,8 @@ def test_present_pass_blur_radii_and_wrap(ctx):
     fb.upload(1, ndof)
     got = fb.present(n)
     want = O.present(color, ndof, n)
-    d = np.abs(got.astype(int) - want.astype(int))
-    assert d.max() <= 1 and np.mean(d == 0) >= 0.99, (d.max(), np.mean(d == 0))
-    assert np.array_equal(got[:, :16], O.present(color, None, n)[:, :16]) or np.abs(got[:, :16].astype(int) - O.present(color, None, n)[:, :16].astype(int)).max() <= 1
+    assert np.array_equal(got, want)
+    assert np.array_equal(got[:, :16], O.present(color, None, n)[:, :16])
     fb.destroy()
 
 
