@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RM_ABI_VERSION 2
+#define RM_ABI_VERSION 3 /* 3: rm_ctx_set_sample_batch, rm_buffer_* (additions only) */
 
 #define RM_MAX_BOUNCES 10 /* raymarchingStepCountsArray[10], raymarcher.frag:31 */
 #define RM_MAX_LIGHTS 10  /* lightPositions[10],             raymarcher.frag:37-39 */
