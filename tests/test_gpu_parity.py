@@ -349,6 +349,21 @@ def test_c2_full_size(ctx, mode):
             assert eq.all(), f"{mode} pipeline {mk} plane {k}: {int((~eq).sum())} values differ"
 
 
+def test_headline_frame_strict_equals_oracle_on_rows_across_the_frame(ctx):
+    """The headline configuration at its full size (Mandelbulb 3840x2160, full, [256], 1 light), strict build: the
+    whole frame rendered on the GPU; the oracle renders every 24th row of it (90 rows spread over the whole height,
+    345 600 pixel-samples of 517 distance evaluations each) -- the colour of those rows is BIT-IDENTICAL."""
+    sc, schema = _c3b()
+    noise = GC.halton_pairs(1)[0]
+    got = render_gpu(ctx, sc, schema, [noise], STRICT)[0]
+    rows = list(range(12, 2160, 24))
+    _, want = O.render_rows(sc, J.uniforms_from_schema(schema, tuple(noise)), 3840, 2160, rows, threads=ORACLE_THREADS)
+    eq = same_bits(got[rows], want)
+    hit = want[..., :3].sum(-1) > 0
+    print(f"\nheadline frame, strict build, {len(rows)} rows: bit-equal {eq.mean():.7f}; pixels with light on them {hit.mean():.3f}")
+    assert eq.all() and hit.mean() > 0.05
+
+
 def test_c3b_full_size_256_steps_striped_equals_single(ctx):
     """The headline configuration itself (3840x2160, [256], 1 light, fast build): what 8 GPUs of a row-striped run
     hold, assembled, is bit-identical to the single-frame render, all three planes."""
@@ -471,6 +486,30 @@ def test_c4_c5_crops_match_oracle(ctx, cfg, build):
     else:
         assert merr <= 0.03 and float(np.mean(d <= 1e-3)) >= (0.97 if cfg == "c4" else 0.93)
     assert np.array_equal(g[..., 3], w[..., 3])
+
+
+@pytest.mark.parametrize("cfg", ["c4", "c5"])
+def test_c4_c5_full_frames_strict_equal_oracle_on_rows_across_the_frame(ctx, cfg):
+    """BASELINE.json configs[3] / [4] at their full sizes (4096^2 and 8192^2; the library picks the wavefront pipeline
+    for them), strict build, one sample: the oracle renders 32 / 16 rows spread over the whole height and their colour
+    is BIT-IDENTICAL."""
+    c = C45[cfg]
+    sc = S.csg64()
+    schema = J.make_schema(sc, c["w"], c["h"], counts=c["counts"], render_mode="full", position=(0, 0, -5.0), lights=getattr(GC, c["light"]))
+    noise = GC.halton_pairs(1)[0]
+    h = ctx.create_scene(sc)
+    fb = ctx.create_framebuffer(c["w"], c["h"])
+    ctx.render_sample(h, fb, J.uniforms_from_schema(schema, tuple(noise)), None, STRICT)
+    got = fb.download(0)
+    fb.destroy()
+    h.destroy()
+    n = 32 if cfg == "c4" else 16
+    k = c["h"] // n
+    rows = list(range(k // 2, c["h"], k))
+    _, want = O.render_rows(sc, J.uniforms_from_schema(schema, tuple(noise)), c["w"], c["h"], rows, threads=ORACLE_THREADS)
+    eq = same_bits(got[rows], want)
+    print(f"\n{cfg} full frame, strict build, {len(rows)} rows: bit-equal {eq.mean():.7f}")
+    assert eq.all()
 
 
 def test_c4_fast_build_statistics_vs_oracle(ctx):
