@@ -9,8 +9,8 @@ payloads:
   tone-maps the stripes it holds (rm_present_rows = display.frag with blur
   radius 0, the same bytes rm_present gives) and 4 bytes per pixel travel --
   a quarter of the fp32 colour plane.  At 3840x2160 over 8 GPUs rank 0 takes in
-  7/8 x 33 MB per presented frame (62 GB/s at a 0.47 ms step, one xGMI link's
-  worth spread over seven).
+  7/8 x 33 MB per presented frame (83 GB/s with a present after every 0.35-ms
+  sample, 13 GB/s with a present per 8 samples, spread over seven xGMI links).
 * "f32": the accumulated colour plane itself (16 bytes per pixel), for hosts that
   want the radiance (depth of field on: the blur needs neighbour rows, so the
   frame is gathered and rm_present_planes runs on rank 0), and for the CPU tests.
