@@ -381,6 +381,14 @@ def main():
         try:
             cj = json.load(open(os.path.join(ROOT, "profiles", "r02_counters.json")))
             ent = cj.get(args.workload + ("_strict" if args.strict else "_fast"))
+            # the counters belong to the kernel sources they were measured on (tools/update_counters.py records their hash):
+            # after a source change they are withheld until re-measured
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("update_counters", os.path.join(ROOT, "tools", "update_counters.py"))
+            uc = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(uc)
+            if ent and ent.get("kernel_source_sha256") != uc.kernel_source_hash():
+                ent = None
             if ent and not args.wavefront and rows_window is None:
                 traffic = ent["hbm_bytes_per_frame"] * px_launch / (W * H)
                 executed = ent["executed_lane_flops_per_frame"] * px_launch / (W * H)
