@@ -65,7 +65,7 @@ SCENES = {
 
 # scenes whose SDF the oracle reproduces bit for bit (only + - * / sqrt floor
 # abs min max); the others go through sin/cos/acos/atan/pow/log where
-# SwiftShader and libm differ in the last bits (or much more: see test tolerances)
+# SwiftShader and the oracle (either of its math modes) differ in the last bits (or much more: see test tolerances)
 SDF_BIT_EXACT = ("sphere", "sphere_sss", "csg64", "csg_mixed", "csg_repeat_fold", "lattice", "fractal1")
 
 IMG_W, IMG_H = 64, 32
