@@ -246,6 +246,10 @@ int rm_ctx_set_retire_eps(rm_ctx* ctx, float eps);
  * -DRM_WF_STATS (zeros otherwise): out16[8*shadow + 4*pass2 + {0,1,2}] =
  * rays marched, lane-steps, wave-steps since the last reset. */
 int rm_debug_counters(rm_ctx* ctx, unsigned long long* out16, int reset);
+/* Free and total memory of the context's GPU (hipMemGetInfo): what a host sizes its frames against -- the planes of
+ * a W x H frame take 48 W H bytes, staging 48 W H per sample in flight or in a batch, the wavefront pipeline 240 bytes
+ * per pixel of a launch (the reference asks MAX_TEXTURE_SIZE instead). */
+int rm_device_memory(rm_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 /* Completion point: the reference's generator yield / present cadence
  * (RenderJobExecutor.tsx:163-166) maps to "enqueue samples, rm_sync, present". */
 int rm_sync(rm_ctx* ctx);
@@ -303,7 +307,8 @@ void* rm_fb_device_ptr(rm_fb* fb, int plane);
 /* Raw device memory for hosts that have no allocator of their own: rm_present_rows, rm_present_device and
  * rm_assemble_striped_bytes take DEVICE pointers (in the reference these are textures the GL context owns,
  * LoadRenderJobContext.tsx:43-124; a torch host passes tensor addresses instead).  Created zero-filled; the copies
- * are synchronous and ordered after the work on the context's stream. */
+ * take the buffer's base address and at most its size, are synchronous and ordered after the work on the context's
+ * stream; rm_ctx_destroy frees what is left. */
 int rm_buffer_create(rm_ctx* ctx, size_t bytes, void** device_ptr);
 int rm_buffer_destroy(rm_ctx* ctx, void* device_ptr);
 int rm_buffer_download(rm_ctx* ctx, const void* device_ptr, void* host, size_t bytes);

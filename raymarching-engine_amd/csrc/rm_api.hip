@@ -11,6 +11,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/hip_raymarch.h"
@@ -81,6 +82,7 @@ struct rm_ctx {
   hipStream_t lpt_stream = nullptr;
   bool lpt_enabled = true;
   hipEvent_t switch_ev = nullptr;  // orders the old stream before the new one in rm_ctx_set_stream
+  std::unordered_map<void*, size_t> buffers;  // rm_buffer_create: base address -> bytes
   uchar4* present_buf = nullptr;   // device staging of rm_present / rm_present_planes, grown on demand
   size_t present_cap = 0;          // pixels
   std::string error;
@@ -204,6 +206,7 @@ void rm_ctx_destroy(rm_ctx* ctx) {
     if (ctx->sp_stage[s]) (void)hipFree(ctx->sp_stage[s]);
   }
   if (ctx->present_buf) (void)hipFree(ctx->present_buf);
+  for (auto& b : ctx->buffers) (void)hipFree(b.first);  // rm_buffer_create'd memory the host did not destroy
   if (ctx->switch_ev) (void)hipEventDestroy(ctx->switch_ev);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -255,6 +258,13 @@ int rm_debug_counters(rm_ctx* ctx, unsigned long long* out16, int reset) {
   RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   RM_HIP(ctx, hipMemcpy(out16, ctx->stats, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost));
   if (reset) RM_HIP(ctx, hipMemset(ctx->stats, 0, sizeof(unsigned long long) * 16));
+  return RM_OK;
+}
+
+int rm_device_memory(rm_ctx* ctx, size_t* free_bytes, size_t* total_bytes) {
+  if (!ctx || !free_bytes || !total_bytes) return fail(ctx, RM_ERR_INVALID, "rm_device_memory: NULL argument");
+  RM_HIP(ctx, hipSetDevice(ctx->device));
+  RM_HIP(ctx, hipMemGetInfo(free_bytes, total_bytes));
   return RM_OK;
 }
 
@@ -532,6 +542,7 @@ int rm_buffer_create(rm_ctx* ctx, size_t bytes, void** device_ptr) {
   if (hipMalloc(&p, bytes) != hipSuccess) return fail(ctx, RM_ERR_DEVICE, "rm_buffer_create: out of device memory");
   hipError_t e = hipMemsetAsync(p, 0, bytes, ctx->stream);
   if (e != hipSuccess) { (void)hipFree(p); return fail(ctx, RM_ERR_DEVICE, std::string("rm_buffer_create: ") + hipGetErrorString(e)); }
+  ctx->buffers[p] = bytes;
   *device_ptr = p;
   return RM_OK;
 }
@@ -539,20 +550,32 @@ int rm_buffer_create(rm_ctx* ctx, size_t bytes, void** device_ptr) {
 int rm_buffer_destroy(rm_ctx* ctx, void* device_ptr) {
   if (!ctx) return RM_ERR_INVALID;
   if (!device_ptr) return RM_OK;
+  auto it = ctx->buffers.find(device_ptr);
+  if (it == ctx->buffers.end()) return fail(ctx, RM_ERR_INVALID, "rm_buffer_destroy: not a buffer of this context");
   RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->buffers.erase(it);
   RM_HIP(ctx, hipFree(device_ptr));
   return RM_OK;
 }
 
+// the copies take the buffer's base address and at most its size
+static int buffer_check(rm_ctx* ctx, const void* device_ptr, const void* host, size_t bytes, const char* what) {
+  if (!ctx || !device_ptr || !host) return fail(ctx, RM_ERR_INVALID, std::string(what) + ": NULL argument");
+  auto it = ctx->buffers.find(const_cast<void*>(device_ptr));
+  if (it == ctx->buffers.end()) return fail(ctx, RM_ERR_INVALID, std::string(what) + ": not a buffer of this context");
+  if (bytes > it->second) return fail(ctx, RM_ERR_INVALID, std::string(what) + ": more bytes than the buffer holds");
+  return RM_OK;
+}
+
 int rm_buffer_download(rm_ctx* ctx, const void* device_ptr, void* host, size_t bytes) {
-  if (!ctx || !device_ptr || !host) return fail(ctx, RM_ERR_INVALID, "rm_buffer_download: NULL argument");
+  if (int rc = buffer_check(ctx, device_ptr, host, bytes, "rm_buffer_download")) return rc;
   RM_HIP(ctx, hipMemcpyAsync(host, device_ptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
   RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return RM_OK;
 }
 
 int rm_buffer_upload(rm_ctx* ctx, void* device_ptr, const void* host, size_t bytes) {
-  if (!ctx || !device_ptr || !host) return fail(ctx, RM_ERR_INVALID, "rm_buffer_upload: NULL argument");
+  if (int rc = buffer_check(ctx, device_ptr, host, bytes, "rm_buffer_upload")) return rc;
   RM_HIP(ctx, hipMemcpyAsync(device_ptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
   RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return RM_OK;

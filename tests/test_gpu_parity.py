@@ -729,6 +729,68 @@ def test_sample_batches_leave_the_same_bits(ctx, case):
         assert same_bits(got[k][:len(rows)], alone[k][rows]).all(), f"striped, plane {k}"
 
 
+def test_contexts_give_their_memory_back(ctx):
+    """A context that has been through every path -- framebuffers, a striped window, samples in flight, a sample
+    batch, the wavefront pipeline, cost-ordered dispatch, the present pass, device buffers (one of them never destroyed)
+    -- returns all of its device memory when it is closed.  The first few contexts of a process also make the HIP
+    runtime allocate what it keeps for good (code objects, the scratch of each hardware queue its streams land on:
+    ~0.5 GB, tools/dbg/leak_probe.py), so the measurement starts after four of them: over the next eight the GPU's free
+    memory does not move."""
+    from raymarching_engine_amd import native
+
+    total = ctx.device_memory()[1]
+    assert total > 100 * 2 ** 30  # an MI355X: 288 GB
+    sc, schema = _c3b(640, 512, counts=(16,))
+    noises = GC.halton_pairs(9)
+
+    def one_context():
+        c = native.Context(0)
+        h = c.create_scene(sc)
+        fb = c.create_framebuffer(640, 512)
+        sfb = c.create_striped_framebuffer(640, 512, shard.STRIPE_ROWS, 3, 1)
+        c.set_samples_in_flight(3)
+        for n in noises[:3]:
+            c.render_sample(h, fb, J.uniforms_from_schema(schema, tuple(n)), None, FAST)
+        c.render_samples(h, sfb, J.uniforms_from_schema(schema, (0.0, 0.0)), [tuple(n) for n in noises], None, FAST)
+        c.render_sample(h, fb, J.uniforms_from_schema(schema, tuple(noises[0])), None, STRICT | WF)
+        fb.present(4)
+        out = c.buffer(640 * 512 * 4)
+        c.present_rows(sfb, 9, out.ptr)
+        c.buffer(1 << 20)  # left to rm_ctx_destroy
+        c.sync()
+        for obj in (out, sfb, fb, h):
+            obj.destroy()
+        c.close()
+
+    for _ in range(4):
+        one_context()
+    free0 = ctx.device_memory()[0]
+    for _ in range(8):
+        one_context()
+    free1 = ctx.device_memory()[0]
+    print(f"\nfree device memory before / after 8 contexts: {free0 / 2**20:.0f} / {free1 / 2**20:.0f} MiB")
+    assert abs(free0 - free1) < 32 * 2 ** 20
+
+
+def test_device_buffers_are_bounds_checked(ctx):
+    """rm_buffer_*: copies take a buffer's base address and at most its size; foreign pointers are refused."""
+    import ctypes as C
+
+    from raymarching_engine_amd import native
+
+    b = ctx.buffer(1000)
+    data = (np.arange(1000) % 251).astype(np.uint8)
+    b.upload(data)
+    assert np.array_equal(b.download(), data)
+    big = np.zeros(1001, np.uint8)
+    for fn, ptr in ((ctx.lib.rm_buffer_download, b.ptr), (ctx.lib.rm_buffer_upload, b.ptr), (ctx.lib.rm_buffer_download, b.ptr + 16)):
+        assert fn(ctx.h, C.c_void_p(ptr), big.ctypes.data_as(C.c_void_p), big.nbytes if ptr == b.ptr else 8) != abi.RM_OK
+    assert ctx.lib.rm_buffer_destroy(ctx.h, C.c_void_p(b.ptr + 16)) != abi.RM_OK
+    b.destroy()
+    with pytest.raises(native.RmError):
+        ctx.buffer(0)
+
+
 def test_sample_batch_setting_is_validated(ctx):
     for bad in (-1, 9):
         with pytest.raises(Exception, match="rm_ctx_set_sample_batch"):
