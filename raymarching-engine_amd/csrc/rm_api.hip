@@ -619,6 +619,7 @@ static int build_params(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniform
   P->stage = nullptr;
   P->stage_stride = 0;
   P->batch = 0;
+  P->tile_wide = 0;
   std::memset(P->batch_noise, 0, sizeof P->batch_noise);
   P->block_order = nullptr;
   P->block_cost = nullptr;
@@ -979,7 +980,7 @@ int rm_render_samples(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms*
       int gx = 0, gy = 0;
       rm::pixel_grid(P, &gx, &gy);
       const long long tiles = (long long)gx * gy;
-      per_launch = tiles > 0 ? (int)(RM_BATCH_TARGET_TILES / tiles) : 1;
+      per_launch = tiles > 0 ? (int)((RM_BATCH_TARGET_TILES + tiles / 2) / tiles) : 1;  // to the nearest: a 1/8 shard of the headline frame has 2 160 tiles -> 8
     }
     per_launch = per_launch < 1 ? 1 : per_launch > RM_BATCH_MAX ? RM_BATCH_MAX : per_launch;
   }
