@@ -43,7 +43,7 @@ struct KParams {
   // and its output staged at stage + sample * 3 * stage_stride -- so that a small window (one GPU's share of a frame)
   // still gives the chip a full frame's worth of workgroups.  0 or 1 = one sample.
   int batch;
-  int tile_wide;  // set by the launcher: 8-wave workgroups cover 32 x 16 pixels instead of 16 x 32 (rm_kernels.inc BlockShape)
+  int tile_wide;  // set by the launcher: 0 = the kind's own tile; n > 0 = 8-wave workgroups with 2^(n-1) waves across (3: 32 x 16 pixels instead of 16 x 32; rm_kernels.inc BlockShape)
   float batch_noise[RM_BATCH_MAX][2];
   // Cost-ordered dispatch (pixel kernel): workgroup b of the launch renders tile block_order[b], and every workgroup
   // leaves its duration in block_cost[tile] for the next sample's order (rm_order_kernel).  nullptr = in launch order.
