@@ -791,6 +791,57 @@ def test_device_buffers_are_bounds_checked(ctx):
         ctx.buffer(0)
 
 
+def test_random_jobs_through_the_staged_paths_leave_the_same_bits(ctx):
+    """Thirty random jobs -- scene, frame size, tile, a striped window or not, both builds, additive or mix blend, with
+    or without the G-buffer, 1..12 samples, batch size 0..8, 1..4 launches in flight, cost order on or off -- through
+    rm_render_samples: every plane equals one NO_OVERLAP rm_render_sample call per sample, bit for bit."""
+    rng = np.random.default_rng(2024)
+    scenes = [("sphere", S.single_sphere(), (0, 0, -3.0)), ("csg_mixed", GC.build_scene("csg_mixed"), (0.3, 0.2, -4.0)), ("bulb", S.Mandelbulb(), (0, 0, -2.5))]
+    NO = abi.RM_RENDER_NO_OVERLAP
+    try:
+        for it in range(30):
+            name, sc, pos = scenes[rng.integers(len(scenes))]
+            w, h = int(rng.integers(40, 640)), int(rng.integers(24, 600))
+            counts = tuple(int(c) for c in rng.integers(4, 28, size=rng.integers(1, 3)))
+            schema = J.make_schema(sc, w, h, counts=counts, render_mode="full", position=pos, lights=GC.LIGHT if rng.random() < 0.7 else (),
+                                   blend_mode="mix" if rng.random() < 0.25 else "additive")
+            n = int(rng.integers(1, 13))
+            noises = GC.halton_pairs(n)
+            flags = (FAST if rng.random() < 0.6 else STRICT) | MK | (abi.RM_RENDER_COLOR_ONLY if rng.random() < 0.2 else 0)
+            tile = None
+            if rng.random() < 0.4:
+                tx, ty = int(rng.integers(0, w // 2)), int(rng.integers(0, h // 2))
+                tile = abi.RmRect(tx, ty, int(rng.integers(1, w - tx + 1)), int(rng.integers(1, h - ty + 1)))
+            striped = None
+            if rng.random() < 0.4:
+                parts = int(rng.integers(2, 6))
+                striped = (parts, int(rng.integers(parts)))
+            batch, depth, order = int(rng.integers(0, 9)), int(rng.integers(1, 5)), bool(rng.random() < 0.7)
+            hnd = ctx.create_scene(sc)
+
+            def frames(staged):
+                fb = (ctx.create_striped_framebuffer(w, h, shard.STRIPE_ROWS, *striped) if striped else ctx.create_framebuffer(w, h))
+                if staged:
+                    ctx.render_samples(hnd, fb, J.uniforms_from_schema(schema, (0.0, 0.0)), [tuple(x) for x in noises], tile, flags)
+                else:
+                    for x in noises:
+                        ctx.render_sample(hnd, fb, J.uniforms_from_schema(schema, tuple(x)), tile, flags | NO)
+                out = [fb.download(k) for k in range(3)]
+                fb.destroy()
+                return out
+
+            ctx.set_sample_batch(1); ctx.set_samples_in_flight(1); ctx.set_cost_order(True)
+            want = frames(False)
+            ctx.set_sample_batch(batch); ctx.set_samples_in_flight(depth); ctx.set_cost_order(order)
+            got = frames(True)
+            hnd.destroy()
+            for k in range(3):
+                assert same_bits(got[k], want[k]).all(), (f"job {it}: {name} {w}x{h} counts {counts} n {n} flags {flags} tile "
+                                                          f"{(tile.x, tile.y, tile.w, tile.h) if tile else None} striped {striped} batch {batch} depth {depth} order {order}: plane {k}")
+    finally:
+        ctx.set_sample_batch(0); ctx.set_samples_in_flight(3); ctx.set_cost_order(True)
+
+
 def test_sample_batch_setting_is_validated(ctx):
     for bad in (-1, 9):
         with pytest.raises(Exception, match="rm_ctx_set_sample_batch"):
