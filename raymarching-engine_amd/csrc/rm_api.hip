@@ -590,6 +590,9 @@ static int build_params(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniform
   if (u->renderMode != 0 && u->renderMode != 1) return fail(ctx, RM_ERR_INVALID, "render: renderMode must be 0 (full) or 1 (preview)");
   if (!(u->reflections >= 0.0f && u->reflections <= (float)RM_MAX_BOUNCES)) return fail(ctx, RM_ERR_INVALID, "render: reflections must be in 0..10 (raymarchingStepCountsArray[10])");
   if (u->lightCount < 0 || u->lightCount > RM_MAX_LIGHTS) return fail(ctx, RM_ERR_INVALID, "render: lightCount must be in 0..10");
+  // `for (float i = 0.; i < steps; i++)` (raymarcher.frag:165, :210) never ends once i stops growing at 2^24
+  for (int b = 0; b < RM_MAX_BOUNCES; b++)
+    if (u->raymarchingStepCountsArray[b] > 1048576.0f) return fail(ctx, RM_ERR_INVALID, "render: a step count above 2^20");
   const bool color_only = (flags & RM_RENDER_COLOR_ONLY) != 0;
   if (!color_only && u->renderMode == 0 && (!fb->plane[1] || !fb->plane[2]))
     return fail(ctx, RM_ERR_INVALID, "render: framebuffer has no G-buffer planes; pass RM_RENDER_COLOR_ONLY");
