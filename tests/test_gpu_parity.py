@@ -873,6 +873,80 @@ def test_random_jobs_strict_build_equals_the_oracle_bit_for_bit(ctx):
     assert np.median(distinct) > 500 and min(hits) < 0.5 < max(hits)
 
 
+def test_random_jobs_partitions_and_implementations_leave_the_same_bits(ctx):
+    """150 random jobs (scenes, cameras, lights, modes as above; both builds): the whole frame by the pixel kernel is
+    the reference; the same frame through the OTHER implementation, and cut up at random -- two row windows, striped
+    parts as the ranks of a sharded run hold them, a grid of tiles -- through a random implementation, gives the same
+    bits in every plane."""
+    rng = np.random.default_rng(4242)
+    for it in range(int(os.environ.get("RM_RANDOM_JOBS2", "150"))):
+        sc, pos = _random_scene(rng)
+        w, h = int(rng.integers(24, 96)), int(rng.integers(16, 80))
+        mode = "preview" if rng.random() < 0.25 else "full"
+        counts = tuple(int(c) for c in rng.integers(6, 32, size=rng.integers(1, 4)))
+        lights = [J.point_light(tuple(rng.uniform(-4, 4, 3)), size=float(rng.choice([0.0, 0.3]))) for _ in range(int(rng.integers(0, 3)))]
+        cam = ("perspective", "perspective", "orthographic", "panoramic")[rng.integers(0, 4)]
+        schema = J.make_schema(sc, w, h, counts=counts, render_mode=mode, position=tuple(np.array(pos) + rng.uniform(-0.2, 0.2, 3)),
+                               rotation=GC.ROT if rng.random() < 0.5 else None, camera=cam, fov=float(rng.uniform(0.8, 1.8)) if cam != "orthographic" else float(rng.uniform(2.0, 5.0)),
+                               lights=lights, fog_density=float(rng.choice([0.0, 0.0, 0.1])), dof_amount=float(rng.choice([0.0, 0.0, 0.05])))
+        noises = GC.halton_pairs(int(rng.integers(1, 3)))
+        build = FAST if rng.random() < 0.5 else STRICT
+        planes = 3 if mode == "full" else 1
+        hnd = ctx.create_scene(sc)
+
+        def render(fb, tile, pipe):
+            for x in noises:
+                ctx.render_sample(hnd, fb, J.uniforms_from_schema(schema, tuple(x)), tile, build | pipe)
+
+        fb = ctx.create_framebuffer(w, h)
+        render(fb, None, MK)
+        want = [fb.download(k) for k in range(planes)]
+        fb.destroy()
+        what = rng.integers(0, 4)
+        stripes = (h + shard.STRIPE_ROWS - 1) // shard.STRIPE_ROWS
+        if what == 2 and stripes < 2:
+            what = 1  # too low for two striped parts (a part without rows is refused)
+        pipe = (MK, WF)[rng.integers(0, 2)]
+        if what == 0:  # the other implementation, whole frame
+            fb = ctx.create_framebuffer(w, h)
+            render(fb, None, WF)
+            got = [fb.download(k) for k in range(planes)]
+            fb.destroy()
+        elif what == 1:  # two row windows
+            cut = int(rng.integers(1, h))
+            got = []
+            pieces = []
+            for rb, rc in ((0, cut), (cut, h - cut)):
+                fb = ctx.create_framebuffer(w, h, rb, rc)
+                render(fb, None, pipe)
+                pieces.append([fb.download(k) for k in range(planes)])
+                fb.destroy()
+            got = [np.concatenate([pc[k] for pc in pieces], 0) for k in range(planes)]
+        elif what == 2:  # striped parts
+            parts = int(rng.integers(2, min(5, stripes) + 1))
+            pieces = []
+            for part in range(parts):
+                fb = ctx.create_striped_framebuffer(w, h, shard.STRIPE_ROWS, parts, part)
+                render(fb, None, pipe)
+                pieces.append([fb.download(k) for k in range(planes)])
+                fb.destroy()
+            got = [shard.assemble([pc[k] for pc in pieces], h) for k in range(planes)]
+        else:  # a grid of tiles into one framebuffer
+            fb = ctx.create_framebuffer(w, h)
+            xs = sorted({0, w, *[int(v) for v in rng.integers(1, w, size=2)]})
+            ys = sorted({0, h, *[int(v) for v in rng.integers(1, h, size=2)]})
+            for x in noises:  # sample by sample, tile by tile (accumulation per pixel is in sample order either way)
+                for y0, y1 in zip(ys[:-1], ys[1:]):
+                    for x0, x1 in zip(xs[:-1], xs[1:]):
+                        ctx.render_sample(hnd, fb, J.uniforms_from_schema(schema, tuple(x)), abi.RmRect(x0, y0, x1 - x0, y1 - y0), build | pipe)
+            got = [fb.download(k) for k in range(planes)]
+            fb.destroy()
+        hnd.destroy()
+        for k in range(planes):
+            assert same_bits(got[k], want[k]).all(), (f"job {it}: {type(sc).__name__} {w}x{h} {mode} counts {counts} cam {cam} lights {len(lights)} "
+                                                      f"build {build} partition {what} pipeline {pipe}: plane {k}")
+
+
 def test_random_jobs_through_the_staged_paths_leave_the_same_bits(ctx):
     """Thirty random jobs -- scene, frame size, tile, a striped window or not, both builds, additive or mix blend, with
     or without the G-buffer, 1..12 samples, batch size 0..8, 1..4 launches in flight, cost order on or off -- through
