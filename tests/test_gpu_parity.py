@@ -729,6 +729,64 @@ def test_sample_batches_leave_the_same_bits(ctx, case):
         assert same_bits(got[k][:len(rows)], alone[k][rows]).all(), f"striped, plane {k}"
 
 
+def test_random_present_passes_equal_the_oracle_byte_for_byte(ctx):
+    """60 random accumulated frames -- sizes that are no multiple of the 16x16 present tile, radiances over six decades
+    with zeros, negative and non-finite values, depth-of-field radii from 0 through the 16-pixel cap in patches and
+    ramps, 1..500 samples, with and without the DoF plane -- through rm_present: the oracle's display.frag, byte for byte."""
+    rng = np.random.default_rng(99)
+    for it in range(60):
+        w, h = int(rng.integers(5, 150)), int(rng.integers(5, 120))
+        n = int(rng.choice([1, 2, 7, 64, 500]))
+        color = (10.0 ** rng.uniform(-4, 2, (h, w, 4)) * n).astype(np.float32)
+        color[rng.random((h, w)) < 0.05] = 0.0
+        if rng.random() < 0.3:
+            color[rng.random((h, w)) < 0.01] = np.float32(np.nan)
+            color[rng.random((h, w)) < 0.01] = np.float32(np.inf)
+            color[rng.random((h, w)) < 0.01] *= -1.0
+        ndof = None
+        if rng.random() < 0.75:
+            ndof = rng.normal(size=(h, w, 4)).astype(np.float32)
+            radius = np.zeros((h, w), np.float32)
+            if rng.random() < 0.7:
+                radius += np.linspace(0.0, float(rng.uniform(0.0, 0.12)) * n, w, dtype=np.float32)[None, :]
+            if rng.random() < 0.5:
+                y0, x0 = int(rng.integers(0, h)), int(rng.integers(0, w))
+                radius[y0 : y0 + int(rng.integers(1, 40)), x0 : x0 + int(rng.integers(1, 40))] = float(rng.uniform(0.0, 0.2)) * n
+            ndof[..., 3] = radius
+        fb = ctx.create_framebuffer(w, h)
+        fb.upload(0, color)
+        if ndof is not None:
+            fb.upload(1, ndof)
+            got = fb.present(n)
+        else:
+            got = np.empty((h, w, 4), np.uint8)
+            import ctypes as C
+            ctx._check(ctx.lib.rm_present_planes(ctx.h, C.c_void_p(fb.device_ptr(0)), None, w, h, n, got.ctypes.data_as(C.POINTER(C.c_uint8))))
+        fb.destroy()
+        want = O.present(color, ndof, n)
+        assert np.array_equal(got, want), f"frame {it}: {w}x{h}, {n} samples, dof plane {ndof is not None}: {int((got != want).sum())} bytes differ"
+
+
+def test_nasty_inputs_through_the_c_abi_always_return():
+    """tools/dbg/abuse_fuzz.py in a process of its own (a call that did not return would be stopped by the timeout):
+    1500 scene descriptions and uniform blocks drawn from {0, -0, +-1, 1e-30, 1e30, +-Inf, NaN, ...} with out-of-range
+    kinds, operators, counts and enums.  Every call returns -- RM_OK, or an error code with a message -- and every
+    render that was accepted completes (9 000 cases have been run)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dbg", "abuse_fuzz.py"), "1500"], capture_output=True, text=True, timeout=180,
+                       env=dict(os.environ, SEED="7"))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    last = r.stdout.strip().splitlines()[-1]
+    print(last)
+    import re
+
+    m = re.search(r"scenes accepted (\d+) / refused (\d+); renders completed (\d+) / refused (\d+)", last)
+    assert m and int(m.group(1)) > 300 and int(m.group(2)) > 300 and int(m.group(3)) > 200 and int(m.group(4)) > 50
+
+
 def test_contexts_give_their_memory_back(ctx):
     """A context that has been through every path -- framebuffers, a striped window, samples in flight, a sample
     batch, the wavefront pipeline, cost-ordered dispatch, the present pass, device buffers (one of them never destroyed)
