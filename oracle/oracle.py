@@ -36,8 +36,7 @@ def _lib(count: bool = False):
     key = bool(count)
     if key not in _libs:
         path = _BUILD / ("librm_oracle_count.so" if count else "librm_oracle.so")
-        if not path.exists():
-            build()
+        build()  # no-op unless a library is missing or older than its sources (a stale checker is worse than none)
         lib = C.CDLL(str(path))
         fp = C.POINTER(C.c_float)
         lib.or_render.restype = C.c_uint64

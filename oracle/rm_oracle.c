@@ -109,14 +109,27 @@ static float or_tan(float x) {
 
 typedef struct { float x, y, z; } v3;
 
+/* OR_NAN_IEEE: IEEE 754-2019 maximumNumber / minimumNumber as v_max_f32 / v_min_f32 compute them -- the operand that
+ * is not NaN wins, and +0 is greater than -0.  (C's fmaxf / fminf leave the zeros' order open and glibc returns its second
+ * operand on a tie: the random probes of the GPU tests found sdf(p) = -0 here against +0 there at non-finite points.) */
 static inline float gl_max(float x, float y) {
   FL(1);
-  if (or_nan_mode == OR_NAN_IEEE) return fmaxf(x, y);
+  if (or_nan_mode == OR_NAN_IEEE) {
+    if (x != x) return y;
+    if (y != y) return x;
+    if (x == y) { uint32_t a, b; memcpy(&a, &x, 4); memcpy(&b, &y, 4); a &= b; memcpy(&x, &a, 4); return x; }  /* +0 unless both are -0 */
+    return x > y ? x : y;
+  }
   return x > y ? x : y;
 }
 static inline float gl_min(float x, float y) {
   FL(1);
-  if (or_nan_mode == OR_NAN_IEEE) return fminf(x, y);
+  if (or_nan_mode == OR_NAN_IEEE) {
+    if (x != x) return y;
+    if (y != y) return x;
+    if (x == y) { uint32_t a, b; memcpy(&a, &x, 4); memcpy(&b, &y, 4); a |= b; memcpy(&x, &a, 4); return x; }  /* -0 if either is */
+    return x < y ? x : y;
+  }
   return x < y ? x : y;
 }
 static inline float gl_clamp(float x, float lo, float hi) { return gl_min(gl_max(x, lo), hi); }

@@ -341,13 +341,14 @@ int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out) {
   s->dev.kind = desc->kind;
   s->dev.nprims = desc->kind == RM_SCENE_TABLE ? desc->nprims : 0;
   if (desc->kind == RM_SCENE_TABLE) {
-    bool spheres_smooth = true, domain = false;
+    bool spheres_smooth = true, domain = false, boxes = false;
     for (int i = 0; i < desc->nprims; i++) {
       const int type = desc->prims[i].type & 0xff, op = (desc->prims[i].type >> 8) & 0xff;
       if (type != RM_PRIM_SPHERE || (i > 0 && op != RM_OP_SMOOTH_UNION)) spheres_smooth = false;
       if (type == RM_PRIM_REPEAT || type == RM_PRIM_FOLD) domain = true;
+      if (type == RM_PRIM_BOX) boxes = true;
     }
-    s->dev.table_flags = (spheres_smooth ? RM_TABLE_SPHERES_SMOOTH : 0) | (domain ? RM_TABLE_HAS_DOMAIN : 0);
+    s->dev.table_flags = (spheres_smooth ? RM_TABLE_SPHERES_SMOOTH : 0) | (domain ? RM_TABLE_HAS_DOMAIN : 0) | (boxes ? 0 : RM_TABLE_NO_BOXES);
     if (spheres_smooth && desc->nprims >= 2 && desc->nprims * 3 <= RM_MAX_PRIMS * 2) {  // one smooth-union radius for the whole table (the usual case): it travels as a kernel argument, and a compact image of the rows fits behind them in LDS
       bool one_k = true;
       for (int i = 2; i < desc->nprims; i++) one_k = one_k && desc->prims[i].k == desc->prims[1].k;

@@ -285,9 +285,12 @@ struct Sdf;
 template <>
 struct Sdf<RM_SCENE_TABLE> {
   static constexpr bool has_cost_classes = false;  // every evaluation costs the same
-  // sdf of a point with a non-finite coordinate is +-Inf or NaN (|p - c| is), so the forward-difference
-  // normal there is (NaN, NaN, NaN) whatever the table holds: sceneNormal may skip its four evaluations
-  static constexpr bool nonfinite_normal_is_nan = true;
+  // A sphere's distance at a point with a non-finite coordinate is +-Inf or NaN (|p - c| is), and every operator and
+  // domain row hands that on, so the forward-difference normal there is (NaN, NaN, NaN): sceneNormal may skip its four
+  // evaluations -- unless the table has a box: sdBox takes max(q, 0), which DROPS a NaN (maxNum), so a point like
+  // (NaN, 1, 1) has a finite distance to a box and a finite normal (found by the random probes of the test suite; an
+  // escaping ray never gets there, its finite coordinates turn NaN with the first 0 * Inf)
+  static RM_DEV bool nonfinite_normal_is_nan(const DevScene& sc) { return (sc.table_flags & RM_TABLE_NO_BOXES) != 0; }
   static RM_DEV void stage(const DevScene& sc, SceneLds& lds) {
     const float4* src = reinterpret_cast<const float4*>(sc.prims);
     if (sc.table_flags & RM_TABLE_UNIFORM_K) {  // spheres, one k: also a compact image, (centre, radius) per row, behind the rows:
@@ -546,7 +549,7 @@ struct Sdf<RM_SCENE_MANDELBULB> {
   // more than `cap` rounds; otherwise the same bits as eval().  The wavefront
   // march uses it to keep cheap and expensive rays in separate waves.
   static constexpr bool has_cost_classes = true;
-  static constexpr bool nonfinite_normal_is_nan = true;  // |z| is Inf or NaN there: the estimate is Inf or NaN
+  static RM_DEV bool nonfinite_normal_is_nan(const DevScene&) { return true; }  // |z| is Inf or NaN there: the estimate is Inf or NaN
   static constexpr int cheap_cap = 2;
   template <class M>
   static RM_DEV bool eval_cheap(const DevScene& sc, const SceneLds& lds, v3 p, float& d) {
@@ -610,7 +613,7 @@ RM_DEV void stage_pow_table(SceneLds& lds, float base, float first) {
 template <>
 struct Sdf<RM_SCENE_SPHERE_GRID> {
   static constexpr bool has_cost_classes = false;  // every evaluation costs the same
-  static constexpr bool nonfinite_normal_is_nan = false;  // not shown for this kind: always evaluate
+  static RM_DEV bool nonfinite_normal_is_nan(const DevScene&) { return false; }  // not shown for this kind: always evaluate
   static RM_DEV void stage(const DevScene& sc, SceneLds& lds) { stage_pow_table(lds, sc.p[RM_P_GRID_SCALE], -1.0f); }
   template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds& lds, v3 p) {
@@ -634,7 +637,7 @@ struct Sdf<RM_SCENE_SPHERE_GRID> {
 template <>
 struct Sdf<RM_SCENE_SPHERE_LATTICE> {
   static constexpr bool has_cost_classes = false;  // every evaluation costs the same
-  static constexpr bool nonfinite_normal_is_nan = false;  // not shown for this kind: always evaluate
+  static RM_DEV bool nonfinite_normal_is_nan(const DevScene&) { return false; }  // not shown for this kind: always evaluate
   static RM_DEV void stage(const DevScene&, SceneLds&) {}
   template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds&, v3 p) {
@@ -648,7 +651,7 @@ struct Sdf<RM_SCENE_SPHERE_LATTICE> {
 template <>
 struct Sdf<RM_SCENE_MENGER> {
   static constexpr bool has_cost_classes = false;  // every evaluation costs the same
-  static constexpr bool nonfinite_normal_is_nan = false;  // not shown for this kind: always evaluate
+  static RM_DEV bool nonfinite_normal_is_nan(const DevScene&) { return false; }  // not shown for this kind: always evaluate
   static RM_DEV void stage(const DevScene&, SceneLds& lds) { stage_pow_table(lds, 0.33333333333333f, 1.0f); }
   template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds& lds, v3 p) {
@@ -690,7 +693,7 @@ RM_DEV v3 kifs_rotate(v3 t, const KifsTrig& g) {
 template <>
 struct Sdf<RM_SCENE_KIFS_TREE> {
   static constexpr bool has_cost_classes = false;  // every evaluation costs the same
-  static constexpr bool nonfinite_normal_is_nan = false;  // not shown for this kind: always evaluate
+  static RM_DEV bool nonfinite_normal_is_nan(const DevScene&) { return false; }  // not shown for this kind: always evaluate
   static RM_DEV void stage(const DevScene& sc, SceneLds& lds) { stage_pow_table(lds, sc.p[RM_P_KIFS_SCALE], 0.0f); }
   template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds& lds, v3 p) {
@@ -717,7 +720,7 @@ struct Sdf<RM_SCENE_KIFS_TREE> {
 template <>
 struct Sdf<RM_SCENE_KIFS_BOX> {
   static constexpr bool has_cost_classes = false;  // every evaluation costs the same
-  static constexpr bool nonfinite_normal_is_nan = false;  // not shown for this kind: always evaluate
+  static RM_DEV bool nonfinite_normal_is_nan(const DevScene&) { return false; }  // not shown for this kind: always evaluate
   static RM_DEV void stage(const DevScene&, SceneLds&) {}
   template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds&, v3 p) {

@@ -8,6 +8,7 @@
 // table_flags of DevScene (set by rm_scene_create)
 #define RM_TABLE_SPHERES_SMOOTH 1  /* every row is a sphere and every fold after the first a smooth union */
 #define RM_TABLE_HAS_DOMAIN 2      /* the table has domain rows (RM_PRIM_REPEAT / RM_PRIM_FOLD) */
+#define RM_TABLE_NO_BOXES 8         /* no RM_PRIM_BOX row: the sdf of a point with a non-finite coordinate is itself non-finite */
 #define RM_TABLE_UNIFORM_K 4       /* RM_TABLE_SPHERES_SMOOTH with one k for every fold: k in p[0], 0.5 / k in p[1] */
 
 #define RM_BATCH_MAX 8  /* samples one pixel-kernel launch can render (KParams::batch) */

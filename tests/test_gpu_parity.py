@@ -931,6 +931,37 @@ def test_random_jobs_strict_build_equals_the_oracle_bit_for_bit(ctx):
     assert np.median(distinct) > 500 and min(hits) < 0.5 < max(hits)
 
 
+def test_random_scenes_probes_equal_the_oracle_bit_for_bit(ctx):
+    """200 random scenes (as above): sdf on 300 points -- near, far, on the axes, huge, non-finite --, castRay from 120
+    random rays for a random step count, forward-difference normals and the material functions: the strict build's bits
+    are the oracle's; and the camera block and the random stream for random uniforms."""
+    rng = np.random.default_rng(31337)
+    special = np.array([0.0, -0.0, 1.0, -1.0, 1e-20, 1e20, 3e38, np.inf, -np.inf, np.nan], np.float32)
+    for it in range(int(os.environ.get("RM_RANDOM_SCENES", "200"))):
+        sc, pos = _random_scene(rng)
+        h = ctx.create_scene(sc)
+        pts = rng.normal(scale=float(rng.choice([0.5, 2.0, 10.0])), size=(300, 3)).astype(np.float32)
+        pts[:20] = rng.choice(special, size=(20, 3))
+        pts[20:26] = np.eye(3, dtype=np.float32).repeat(2, 0) * np.float32(rng.uniform(0.1, 3.0))
+        assert same_bits(ctx.probe(h, abi.RM_PROBE_SDF, pts), O.eval_sdf(sc, pts)).all(), f"scene {it} {type(sc).__name__}: sdf"
+        assert same_bits(ctx.probe(h, abi.RM_PROBE_NORMAL, pts, 1e-5), O.normal(sc, pts, 1e-5)).all(), f"scene {it} {type(sc).__name__}: normal"
+        assert same_bits(ctx.probe(h, abi.RM_PROBE_MATERIAL, pts), O.material(sc, pts)).all(), f"scene {it} {type(sc).__name__}: material"
+        org = (np.array(pos, np.float32) + rng.normal(scale=0.3, size=(120, 3))).astype(np.float32)
+        dirs = rng.normal(size=(120, 3)).astype(np.float32)
+        dirs /= np.linalg.norm(dirs, axis=1, keepdims=True).astype(np.float32)
+        rays = np.concatenate([org, dirs], 1).astype(np.float32)
+        steps = float(rng.choice([0.0, 1.0, 7.0, 33.0, 64.0, 12.5]))
+        assert same_bits(ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps), O.cast_ray(sc, rays, steps)).all(), f"scene {it} {type(sc).__name__}: castRay {steps}"
+        h.destroy()
+        w, hh = int(rng.integers(3, 70)), int(rng.integers(3, 50))
+        cam = ("perspective", "orthographic", "panoramic")[rng.integers(0, 3)]
+        schema = J.make_schema(sc, w, hh, camera=cam, rotation=GC.ROT if rng.random() < 0.5 else None, position=tuple(rng.uniform(-3, 3, 3)),
+                               fov=float(rng.uniform(0.3, 2.5)), dof_amount=float(rng.choice([0.0, 0.1])), dof_distance=float(rng.uniform(0.5, 5.0)))
+        u = J.uniforms_from_schema(schema, (float(rng.random()), float(rng.random())))
+        assert same_bits(ctx.probe_camera(u, w, hh), O.camera(u, w, hh)).all(), f"scene {it}: camera {cam} {w}x{hh}"
+        assert same_bits(ctx.probe_rng(u, w, hh, 5), O.rng(u, w, hh, 5)).all(), f"scene {it}: rng {w}x{hh}"
+
+
 def test_random_jobs_partitions_and_implementations_leave_the_same_bits(ctx):
     """150 random jobs (scenes, cameras, lights, modes as above; both builds): the whole frame by the pixel kernel is
     the reference; the same frame through the OTHER implementation, and cut up at random -- two row windows, striped
