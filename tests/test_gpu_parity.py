@@ -787,6 +787,29 @@ def test_nasty_inputs_through_the_c_abi_always_return():
     assert m and int(m.group(1)) > 300 and int(m.group(2)) > 300 and int(m.group(3)) > 200 and int(m.group(4)) > 50
 
 
+def test_random_striped_assemblies_equal_numpy(ctx):
+    """rm_assemble_striped_bytes on 80 random layouts -- frame height 1..300, rows of 4..6000 bytes (multiples of 4, so both
+    the 16-byte and the 4-byte copy kernels run), 1..9 parts, stripes of 1..16 rows, windows padded to the largest part --
+    puts every row where shard.assemble puts it."""
+    rng = np.random.default_rng(808)
+    for it in range(80):
+        H, parts, stripe = int(rng.integers(1, 301)), int(rng.integers(1, 10)), int(rng.integers(1, 17))
+        row_bytes = 4 * int(rng.integers(1, 1501)) if rng.random() < 0.5 else 16 * int(rng.integers(1, 376))
+        counts = shard.row_counts(H, parts, stripe)
+        max_rows = max(max(counts), 1)
+        src = rng.integers(0, 256, size=(parts, max_rows, row_bytes), dtype=np.uint8)
+        want = np.empty((H, row_bytes), np.uint8)
+        for part in range(parts):
+            rows = shard.owned_rows(H, parts, part, stripe)
+            want[rows] = src[part, : len(rows)]
+        bsrc, bdst = ctx.buffer(src.nbytes), ctx.buffer(H * row_bytes)
+        bsrc.upload(src)
+        ctx.assemble_striped_bytes(bsrc.ptr, parts, max_rows, row_bytes, H, stripe, bdst.ptr)
+        got = bdst.download().reshape(H, row_bytes)
+        bsrc.destroy(); bdst.destroy()
+        assert np.array_equal(got, want), f"layout {it}: H {H} parts {parts} stripe {stripe} row_bytes {row_bytes}"
+
+
 def test_contexts_give_their_memory_back(ctx):
     """A context that has been through every path -- framebuffers, a striped window, samples in flight, a sample
     batch, the wavefront pipeline, cost-ordered dispatch, the present pass, device buffers (one of them never destroyed)
