@@ -1,0 +1,91 @@
+"""tests/golden/random_tables.npz: the reference's own sdf() and castRay() (raymarcher.frag:163-170) run under software GL
+on RANDOM scenes of the composition API -- primitive tables of 1..10 spheres / boxes under every operator, a third of
+them behind a repeat and / or an unrotated fold row -- at random points and along random rays.  These scenes are
++ - * / sqrt floor abs min max only, so the reference's bits are the bar: the oracle (CPU tests) and the HIP strict build
+(GPU tests) must reproduce them exactly.  Build-container only (needs /root/reference and the kaleido wheel):
+    python oracle/gl/gen_random_golden.py [scenes]
+The file holds numbers only: per scene the table rows, the points / rays, and the reference's outputs."""
+from __future__ import annotations
+
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests")); sys.path.insert(0, str(Path(__file__).resolve().parent))
+import glref  # noqa: E402
+from gen_golden import FETCH, pack  # noqa: E402
+from raymarching_engine_amd import abi, scene as S  # noqa: E402
+
+N_SCENES = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+W = H = 16  # 256 points / rays per scene
+STEPS = 24.0
+
+
+def survives_translation(v: np.float32) -> bool:
+    """Chrome 88's ANGLE re-emits a shader's float constants with 8 significant digits before the backend compiles
+    it (measured: 2 of 241 random constants come back one ulp off, whether written with 17 digits, with the shortest
+    round-trip form or as uintBitsToFloat -- exactly those that '%.8g' does not round-trip).  A scene constant that does
+    not survive that is a different scene under this GL stack, so the random scenes only use constants that do."""
+    return np.float32(float("%.8g" % float(v))) == np.float32(v)
+
+
+def random_table(rng) -> S.CsgScene:
+    def f32(v):
+        v = np.float32(v)
+        while not survives_translation(v):
+            v = np.nextafter(v, np.float32(0.0))
+        return float(v)
+
+    sc = S.CsgScene()
+    if rng.random() < 0.3:
+        sc.repeat(tuple(f32(v) for v in rng.uniform(2.5, 4.0, 3)))
+    if rng.random() < 0.3:
+        sc.fold(f32(rng.uniform(0.6, 0.9)), tuple(f32(v) for v in rng.uniform(0.1, 0.5, 3)))
+    for i in range(int(rng.integers(1, 11))):
+        if i:
+            op = rng.integers(0, 4)
+            if op == 0: sc.union()
+            elif op == 1: sc.smooth_union(f32(rng.uniform(0.05, 0.5)))
+            elif op == 2: sc.subtract()
+            else: sc.intersect()
+        c = tuple(f32(v) for v in rng.uniform(-1.2, 1.2, 3))
+        if rng.random() < 0.6: sc.sphere(c, f32(rng.uniform(0.2, 0.9)))
+        else: sc.box(c, tuple(f32(v) for v in rng.uniform(0.15, 0.8, 3)))
+    return sc
+
+
+def rows_of(sc) -> np.ndarray:
+    return np.array([[p.type & 0xff, (p.type >> 8) & 0xff, p.k, *p.center, *p.size] for p in sc.prims()], np.float32)
+
+
+def main():
+    rng = np.random.default_rng(20261003)
+    out = {}
+    for i in range(N_SCENES):
+        sc = random_table(rng)
+        text, uni = sc.glsl(), dict(sc.custom_shader_parameters())
+        pts = rng.normal(scale=float(rng.choice([0.7, 2.0, 6.0])), size=(W * H, 3)).astype(np.float32)
+        frag = glref.splice(text, "void main(void){ " + FETCH + " fragColor = vec4(sdf(t.xyz), 0.0, 0.0, 0.0); }")
+        g = glref.run_gl(frag, W, H, uni, init_prev0=pack(pts, W, H))["planes"][0]
+        org = np.array([0.2, 0.1, -4.0], np.float32)
+        dirs = rng.normal(size=(W * H, 3)).astype(np.float32); dirs[:, 2] = np.abs(dirs[:, 2]) + np.float32(1.5)
+        dirs = (dirs / np.linalg.norm(dirs, axis=1, keepdims=True)).astype(np.float32)
+        u2 = dict(uni); u2["position"] = glref.u_float(*[float(v) for v in org]); u2["hsteps"] = glref.u_float(STEPS)
+        harness = "uniform float hsteps;\nvoid main(void){ " + FETCH + " vec3 e = castRay(position, t.xyz, hsteps); fragColor = vec4(e, sdf(e)); }"
+        e = glref.run_gl(glref.splice(text, harness), W, H, u2, init_prev0=pack(dirs, W, H))["planes"][0].reshape(-1, 4)
+        out[f"rows_{i}"] = rows_of(sc)
+        out[f"points_{i}"] = pts
+        out[f"sdf_{i}"] = g[..., 0].reshape(-1).astype(np.float32)
+        out[f"rays_{i}"] = np.concatenate([np.tile(org, (W * H, 1)), dirs], 1).astype(np.float32)
+        out[f"end_{i}"] = e[:, :3].astype(np.float32)
+        print(f"scene {i}: {len(out[f'rows_{i}'])} rows, finite ends {np.isfinite(e[:, :3]).all(1).mean():.2f}")
+    out["count"] = np.int32(N_SCENES); out["steps"] = np.float32(STEPS)
+    dest = ROOT / "tests" / "golden" / "random_tables.npz"
+    np.savez_compressed(dest, **out)
+    print("wrote", dest, dest.stat().st_size, "B")
+
+
+if __name__ == "__main__":
+    main()

@@ -24,7 +24,10 @@ from . import abi
 
 
 def _f(x: float) -> str:
-    """GLSL float literal that round-trips the fp32 value."""
+    """GLSL float literal that round-trips the fp32 value.  (A conforming GLSL front end parses it to exactly that
+    float.  Chrome 88's ANGLE -- the software-GL stack the goldens are made with -- re-emits a shader's constants with 8
+    significant digits before its backend compiles it, so about 1 % of arbitrary constants arrive one ulp off there,
+    whatever the literal's form: oracle/gl/gen_random_golden.py, which only uses constants that survive that.)"""
     import numpy as np
 
     v = float(np.float32(x))

@@ -149,3 +149,23 @@ def camera_rays(position, w: int = 64, h: int = 32, fov: float = 1.5) -> np.ndar
     d /= np.linalg.norm(d, axis=-1, keepdims=True)
     o = np.broadcast_to(np.asarray(position, np.float64), d.shape)
     return np.concatenate([o, d], -1).reshape(-1, 6).astype(np.float32)
+
+
+def table_from_rows(rows):
+    """A CsgScene from the rows tests/golden/random_tables.npz stores: (prim, op, k, centre[3], size[3]) per row."""
+    from raymarching_engine_amd import abi, scene as S
+
+    sc = S.CsgScene()
+    for prim, op, k, cx, cy, cz, sx, sy, sz in [[float(v) for v in r] for r in rows]:
+        prim, op = int(prim), int(op)
+        if prim == abi.RM_PRIM_REPEAT:
+            sc.repeat((sx, sy, sz))
+        elif prim == abi.RM_PRIM_FOLD:
+            sc.fold(k, (cx, cy, cz), (sx, sy, sz))
+        else:
+            {abi.RM_OP_UNION: sc.union, abi.RM_OP_SUBTRACT: sc.subtract, abi.RM_OP_INTERSECT: sc.intersect}.get(op, lambda: sc.smooth_union(k))()
+            if prim == abi.RM_PRIM_SPHERE:
+                sc.sphere((cx, cy, cz), sx)
+            else:
+                sc.box((cx, cy, cz), (sx, sy, sz))
+    return sc

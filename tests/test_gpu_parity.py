@@ -954,6 +954,18 @@ def test_random_jobs_strict_build_equals_the_oracle_bit_for_bit(ctx):
     assert np.median(distinct) > 500 and min(hits) < 0.5 < max(hits)
 
 
+def test_random_tables_match_the_reference_glsl_bit_for_bit(ctx):
+    """tests/golden/random_tables.npz: the reference's own sdf() and castRay() under software GL on 24 random primitive
+    tables -- the strict build reproduces the REFERENCE's bits (not just the oracle's) at every point and ray."""
+    z = load("random_tables")
+    for i in range(int(z["count"])):
+        sc = GC.table_from_rows(z[f"rows_{i}"])
+        h = ctx.create_scene(sc)
+        assert same_bits(ctx.probe(h, abi.RM_PROBE_SDF, z[f"points_{i}"]), z[f"sdf_{i}"]).all(), f"scene {i}: sdf"
+        assert same_bits(ctx.probe(h, abi.RM_PROBE_CAST_RAY, z[f"rays_{i}"], float(z["steps"])), z[f"end_{i}"]).all(), f"scene {i}: castRay"
+        h.destroy()
+
+
 def test_random_scenes_probes_equal_the_oracle_bit_for_bit(ctx):
     """200 random scenes (as above): sdf on 300 points -- near, far, on the axes, huge, non-finite --, castRay from 120
     random rays for a random step count, forward-difference normals and the material functions: the strict build's bits
