@@ -36,6 +36,57 @@ SYNTHETIC = {
 }
 
 
+def random_texts(count: int = 160, seed: int = 11):
+    """Scene texts from a little grammar -- uniform declarations of every type (and things that only look like them),
+    annotation comments with plausible and with broken values, block comments, code lines, odd spacing, CRLF -- so
+    that the scanner's restatement is pinned well outside what the example files and the hand-written texts do."""
+    import random
+
+    rnd = random.Random(seed)
+    types = ["float", "float", "float", "vec2", "vec3", "vec3", "vec4", "int", "ivec2", "ivec3", "uint", "uvec3", "uvec4", "sampler2D", "mat4", "bool", "double"]
+    names = ["a", "b2", "radius", "big_sphere", "Color", "x_y", "_u", "k9", "sdfScale", "time"]
+    numbers = ["0", "1", "-1", "0.5", "-2.75", "1e3", "1.5e-2", ".25", "3.", "+4", "abc", "0.5x", "", "1,2", "1,2,3", "0.1,0.2,0.3,0.4", "1, 2, 3", "nan", "Infinity", "-0"]
+    words = ["log", "linear", "color", "position", "numerical", "slider", "color/position", "numerical/slider", "weird", "\"quoted words here\"", "\"a, b\"", "\"\"", "unterminated\"", "\"open"]
+    keys = ["name", "min", "max", "step", "sensitivity", "scale", "default", "tooltip", "format", "bogus", "Name", "min "]
+
+    def annotation():
+        parts = []
+        for _ in range(rnd.randint(1, 4)):
+            k = rnd.choice(keys)
+            v = rnd.choice(words) if k in ("name", "tooltip", "format", "scale", "Name") and rnd.random() < 0.8 else rnd.choice(numbers)
+            sep = rnd.choice(["=", "=", "=", " = ", "= ", " =", ":", ""])
+            parts.append("@" + k + sep + v)
+        return rnd.choice([" ", "  ", "\t", ""]).join(parts) if rnd.random() < 0.15 else " ".join(parts)
+
+    def uniform():
+        t, n = rnd.choice(types), rnd.choice(names)
+        form = rnd.random()
+        if form < 0.75: return f"uniform {t} {n};"
+        if form < 0.82: return f"uniform  {t}   {n} ;"
+        if form < 0.88: return f"uniform {t} {n}[3];"
+        if form < 0.93: return f"nonuniform {t} {n};"
+        if form < 0.97: return f"uniform {t} {n}, {n}2;"
+        return f"uniform {t};"
+
+    out = {}
+    for i in range(count):
+        lines = []
+        for _ in range(rnd.randint(0, 9)):
+            r = rnd.random()
+            if r < 0.35: lines.append(uniform() + (" //" + annotation() if rnd.random() < 0.6 else ""))
+            elif r < 0.50: lines.append("//" + rnd.choice(["", " ", "/"]) + annotation())
+            elif r < 0.60: lines.append("/* " + annotation() + rnd.choice(["\n   ", " "]) + annotation() + " */")
+            elif r < 0.68: lines.append(uniform() + " " + uniform() + " //" + annotation())
+            elif r < 0.80: lines.append(rnd.choice(["float sdf(vec3 p) { return length(p) - 1.0; }", "vec3 sceneDiffuseColor(vec3 position) { return vec3(0.6); }",
+                                                    "// a plain comment", "#define N 3", "float x = 1.0; // @notanannotation", "/* unterminated block", "*/", "int uniformity = 0;"]))
+            elif r < 0.85: lines.append("")
+            elif r < 0.92: lines.append("   " + uniform() + "\t//" + annotation())
+            else: lines.append("//@" + rnd.choice(keys) + "=" + rnd.choice(numbers) + " trailing words")
+        eol = "\r\n" if rnd.random() < 0.1 else "\n"
+        out[f"random_{i:03d}"] = eol.join(lines) + (eol if lines and rnd.random() < 0.8 else "")
+    return out
+
+
 def strip_types(ts: str) -> str:
     s = ts
     s = re.sub(r"^import[\s\S]*?;\s*$", "", s, flags=re.M)                       # imports (the harness provides the names)
@@ -55,6 +106,7 @@ def main():
     validate = (REF / "src/settings/shader-editor/Validate.tsx").read_text()
     m = re.search(r"export const uniformVariableRegex =\s*(/.*?/g);", validate, re.S)
     assert m, "uniformVariableRegex not found"
+    SYNTHETIC.update(random_texts())
     texts = dict(SYNTHETIC)
     for sub in ("public/examples", "dist/examples"):
         d = REF / sub

@@ -22,9 +22,19 @@ float sdf(vec3 p) { return length(p) - shellRadius; }
 
 
 def _norm(entry):
+    """Non-finite numbers as JavaScript's String() writes them (the fixture is JSON), also inside lists."""
     import math
 
-    return {k: ("NaN" if isinstance(v, float) and math.isnan(v) else v) for k, v in entry.items()}
+    def one(v):
+        if isinstance(v, float) and math.isnan(v):
+            return "NaN"
+        if isinstance(v, float) and math.isinf(v):
+            return "Infinity" if v > 0 else "-Infinity"
+        if isinstance(v, list):
+            return [one(x) for x in v]
+        return v
+
+    return {k: one(v) for k, v in entry.items()}
 
 
 def _fixture():
