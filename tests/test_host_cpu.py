@@ -291,3 +291,19 @@ void t_atan2(const float* y, const float* x, float* o, int c) { for (int i = 0; 
             assert same(call("t_acos", edge), np.arccos(edge.astype(np.float64)))
             assert same(call("t_pow", np.abs(xs), ys), np.power(np.abs(xs).astype(np.float64), ys.astype(np.float64)))
         assert np.isnan(call("t_sin", np.array([inf, nan, 1e30], np.float32))).all()
+
+
+def test_halton_equals_the_reference_generator():
+    """job.halton against the first 2048 values of the reference's own generator (Halton.tsx:1-19, run under node by
+    oracle/ts/gen_halton_golden.py) for bases 2, 3, 5 and 7: the same doubles, bit for bit."""
+    import json
+    import struct
+    from pathlib import Path
+
+    from raymarching_engine_amd import job as J
+
+    fx = json.loads((Path(__file__).parent / "golden" / "halton_reference.json").read_text())["values"]
+    for base, vals in fx.items():
+        g = J.halton(int(base))
+        got = [struct.pack(">d", next(g)).hex() for _ in vals]
+        assert got == vals, f"base {base}: first difference at {next(i for i, (a, b) in enumerate(zip(got, vals)) if a != b)}"
