@@ -26,6 +26,38 @@ const rm = require("./index.js");
     process.stdout.write(JSON.stringify({ prims: Buffer.from(d.prims).toString("hex"), glsl: sc.glsl() }));
     return;
   }
+  if (mode === "replay") {  // no GPU needed: doRenderJob over the schemas of tests/golden/host_reference.json.gz with the addon's calls recorded
+    const fx = JSON.parse(require("zlib").gunzipSync(fs.readFileSync(process.argv[4])).toString());
+    const a = rm.addon;
+    let events = null;
+    a.ctxCreate = () => ({}); a.ctxDestroy = () => {}; a.sync = () => {}; a.sceneCreate = () => ({}); a.sceneDestroy = () => {};
+    a.fbCreate = () => ({}); a.fbClear = () => {}; a.fbDestroy = () => {};
+    a.renderSample = (c, sc, fb, u, tile, flags) => events.push({ draw: { tile: Array.from(tile || []), uniforms: Buffer.from(u).toString("hex") } });
+    a.renderSamples = (c, sc, fb, u, noise, tile, flags) => {
+      for (let i = 0; i < noise.length / 2; i++) {
+        const v = Buffer.from(Buffer.from(u));  // a copy of the block, randNoise of sample i written over it
+        v.writeFloatLE(noise[2 * i], rm.U_OFFSET.randNoise); v.writeFloatLE(noise[2 * i + 1], rm.U_OFFSET.randNoise + 4);
+        events.push({ draw: { tile: Array.from(tile || []), uniforms: v.toString("hex") } });
+      }
+    };
+    const ctx = new rm.RenderJobContext(0, rm.RM.RENDER_STRICT);
+    const del = ctx.fboDelete.bind(ctx);
+    ctx.fboDelete = (w, h, id) => { events.push({ fboDelete: [w, h, id] }); del(w, h, id); };
+    rm.resetHalton();
+    const all = [];
+    const scene = rm.singleSphere();
+    for (const schema0 of fx.schemas) {
+      const schema = Object.assign({}, schema0, { sdfScene: scene, render: Object.assign({}, schema0.render, { referenceScissor: true }) });
+      events = [];
+      const gen = (await rm.doRenderJob(schema, ctx))((s, c, fb, n) => events.push({ present: n }));
+      let r = gen.next();
+      while (!r.done) { events.push({ yield: 1 }); r = gen.next(); }
+      events.push({ done: r.value });
+      all.push(events);
+    }
+    fs.writeFileSync(out, JSON.stringify(all));
+    return;
+  }
   if (mode === "layout") {  // no GPU needed: the uniform block bytes and the scene description
     const u = rm.uniformsFromSchema(schema, [0.5, 1 / 3]);
     const d = schema.sdfScene.desc();

@@ -307,3 +307,109 @@ def test_halton_equals_the_reference_generator():
         g = J.halton(int(base))
         got = [struct.pack(">d", next(g)).hex() for _ in vals]
         assert got == vals, f"base {base}: first difference at {next(i for i, (a, b) in enumerate(zip(got, vals)) if a != b)}"
+
+
+def test_render_job_host_replays_the_reference_loop_call_by_call():
+    """tests/golden/host_reference.json.gz holds what the reference's OWN render-job generator does
+    (RenderJobExecutor.tsx:147-339, run under node against a recording WebGL mock by oracle/ts/gen_host_golden.py) for 40
+    random RenderJobSchemas in a row: every present(n), yield, gl.scissor rectangle, uniform value of every draw, the
+    fbo.delete and the return value.  job.do_render_job, driven with the same schemas (the Halton pair continuing across
+    jobs, as in the page), produces the same events: same presents and yields at the same sample counts, the same
+    rectangle (render.referenceScissor: the reference's gl.scissor arguments as GL reads them), the same uniform values
+    to the last float32 bit."""
+    import ctypes as C
+    import gzip
+    import json
+    from pathlib import Path
+
+    import numpy as np
+
+    from raymarching_engine_amd import abi, job as J, scene as S
+
+    fx = json.loads(gzip.open(Path(__file__).parent / "golden" / "host_reference.json.gz").read())
+
+    class FakeFb:
+        def __init__(self): self.cleared = 0
+        def clear(self): self.cleared += 1
+        def destroy(self): pass
+
+    class FakeNative:
+        def __init__(self, events): self.events = events
+        def sync(self): pass
+        def create_framebuffer(self, *a): return FakeFb()
+        def render_sample(self, handle, fb, u, tile, flags):
+            self.events.append(("draw", (tile.x, tile.y, tile.w, tile.h), bytes(u)))
+        def render_samples(self, handle, fb, u, noises, tile, flags):
+            for n in noises:
+                v = abi.RmUniforms.from_buffer_copy(bytes(u))
+                v.randNoise[0], v.randNoise[1] = n
+                self.render_sample(handle, fb, v, tile, flags)
+
+    class FakeContext(J.RenderJobContext):
+        def __init__(self, events):
+            self.native, self.flags, self.rows = FakeNative(events), 0, None
+            self._scenes, self._live, self._purgatory = {}, {}, []
+            self.events = events
+        def get_scene(self, scene): return object()
+        def fbo_delete(self, w, h, frameid):
+            self.events.append(("fboDelete", (w, h, frameid)))
+            super().fbo_delete(w, h, frameid)
+
+    J.reset_halton()
+    sc = S.single_sphere()
+    for k, (schema, want) in enumerate(zip(fx["schemas"], fx["events"])):
+        schema = dict(schema, sdfScene=sc, render=dict(schema["render"], referenceScissor=True))
+        events = []
+        ctx = FakeContext(events)
+        gen = J.do_render_job(schema, ctx)(lambda s, c, fb, n: events.append(("present", n)))
+        try:
+            while True:
+                next(gen)
+                events.append(("yield", 1))
+        except StopIteration as stop:
+            events.append(("done", stop.value))
+        compare_host_events(k, schema, events, want)
+
+
+def compare_host_events(k, schema, events, want):
+    """events: ("present", n) | ("yield", 1) | ("draw", (x, y, w, h), bytes of RmUniforms) | ("fboDelete", (w, h, id)) | ("done", value)
+    against the reference's recorded events of the same job (tests/golden/host_reference.json.gz)."""
+    import numpy as np
+
+    from raymarching_engine_amd import abi
+
+    f32 = lambda xs: np.array([float(x) if not isinstance(x, str) else float(x.replace("Infinity", "inf")) for x in xs], np.float32)
+    want = [e for e in want if "blit" not in e]
+    assert len(events) == len(want), f"job {k}: {len(events)} events against the reference's {len(want)}"
+    W, H = schema["render"]["width"], schema["render"]["height"]
+    for i, (got, ref) in enumerate(zip(events, want)):
+        kind = next(iter(ref))
+        assert got[0] == kind, f"job {k} event {i}: {got[0]} against {kind}"
+        if kind == "present":
+            assert got[1] == ref["present"], f"job {k} event {i}"
+        elif kind == "fboDelete":
+            assert list(got[1]) == ref["fboDelete"]
+        elif kind == "done":
+            assert got[1] == ref["done"]
+        elif kind == "draw":
+            x, y, w, h = ref["draw"]["scissor"]  # the reference's arguments as GL reads them: (x, y, width, height), clipped to the image
+            assert tuple(got[1]) == (x, y, min(w, W - x), min(h, H - y)), f"job {k} event {i}: tile {got[1]} against scissor {ref['draw']['scissor']}"
+            u = abi.RmUniforms.from_buffer_copy(got[2])
+            ru = ref["draw"]["uniforms"]
+            n_counts, n_lights = len(schema["reflectionIterationCounts"]), len(schema["lights"])
+            mine = {"blendWithPreviousFactor": [u.blendWithPreviousFactor], "randNoise": list(u.randNoise), "position": list(u.position), "dofAmount": [u.dofAmount],
+                    "dofFocalPlaneDistance": [u.dofFocalPlaneDistance], "cameraMode": [u.cameraMode], "fov": [u.fov], "reflections": [u.reflections],
+                    "raymarchingSteps": [u.raymarchingSteps], "indirectLightingRaymarchingSteps": [u.indirectLightingRaymarchingSteps], "aspect": [u.aspect],
+                    "fogDensity": [u.fogDensity], "exposure": [u.exposure], "blendMode": [u.blendMode], "renderMode": [u.renderMode], "lightCount": [u.lightCount],
+                    "showDofFocalPlane": [u.showDofFocalPlane], "raymarchingStepCountsArray": list(u.raymarchingStepCountsArray)[:n_counts], "rotation": list(u.rotation)}
+            if n_lights:
+                mine["lightPositions"] = [c for j in range(n_lights) for c in u.lightPositions[j]]
+                mine["lightColors"] = [c for j in range(n_lights) for c in u.lightColors[j]]
+                mine["lightSizes"] = list(u.lightSizes)[:n_lights]
+            for name, vals in mine.items():
+                assert name in ru, f"job {k}: the reference does not set {name}"
+                a, b = f32(vals), f32(ru[name])
+                assert a.shape == b.shape and (a.view(np.uint32) == b.view(np.uint32)).all(), f"job {k} event {i}: uniform {name}: {vals} against {ru[name]}"
+            extra = set(ru) - set(mine) - {"previousColor", "previousNormalAndDofRadius", "previousAlbedoAndDepth"}
+            # with no light the reference leaves the light arrays as an earlier job set them (lightCount = 0 makes them dead)
+            assert extra <= ({"lightPositions", "lightColors", "lightSizes"} if not n_lights else set()), f"job {k}: uniforms of the reference not compared: {extra}"

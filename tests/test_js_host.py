@@ -110,3 +110,30 @@ def test_js_do_render_job_matches_oracle(tmp_path):
     want = O.present(planes, None, 3)  # dof amount 0: no blur, so the colour plane alone decides
     dd = np.abs(shown.astype(int) - want.astype(int))
     assert dd.max() <= 1 and np.mean(dd == 0) >= 0.99
+
+
+def test_js_render_job_host_replays_the_reference_loop_call_by_call(tmp_path):
+    """js/index.js doRenderJob over the 40 random schemas of tests/golden/host_reference.json.gz with the addon's calls
+    recorded (no GPU): the same presents, yields, tiles and uniform blocks, to the float32 bit, as the reference's own
+    generator (RenderJobExecutor.tsx:147-339 under node against a WebGL mock; oracle/ts/gen_host_golden.py)."""
+    import gzip
+
+    from test_host_cpu import compare_host_events
+
+    fixture = ROOT / "tests" / "golden" / "host_reference.json.gz"
+    out = tmp_path / "events.json"
+    subprocess.run(["node", str(JS / "render_cli.js"), str(out), "replay", str(fixture)], check=True, timeout=120)
+    fx = json.loads(gzip.open(fixture).read())
+    got_all = json.loads(out.read_text())
+    assert len(got_all) == len(fx["schemas"]) == 40
+    for k, (schema, got, want) in enumerate(zip(fx["schemas"], got_all, fx["events"])):
+        events = []
+        for e in got:
+            kind = next(iter(e))
+            if kind == "draw":
+                events.append(("draw", tuple(e["draw"]["tile"]), bytes.fromhex(e["draw"]["uniforms"])))
+            elif kind == "fboDelete":
+                events.append(("fboDelete", tuple(e["fboDelete"])))
+            else:
+                events.append((kind, e[kind]))
+        compare_host_events(k, schema, events, want)
