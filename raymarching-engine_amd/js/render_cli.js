@@ -26,6 +26,23 @@ const rm = require("./index.js");
     process.stdout.write(JSON.stringify({ prims: Buffer.from(d.prims).toString("hex"), glsl: sc.glsl() }));
     return;
   }
+  if (mode === "fbo") {  // no GPU needed: RenderJobContext.fboCreate / fboDelete over the operations of tests/golden/fbo_reference.json
+    const fx = JSON.parse(fs.readFileSync(process.argv[4]).toString());
+    const a = rm.addon;
+    let serial = 0, log = [];
+    a.ctxCreate = () => ({}); a.fbCreate = () => { const uid = ++serial; log.push(["created", uid]); return { uid }; };
+    a.fbClear = (fb) => log.push(["cleared", fb.uid]); a.fbDestroy = (fb) => log.push(["destroyed", fb.uid]);
+    const ctx = new rm.RenderJobContext(0, rm.RM.RENDER_STRICT);
+    const got = [];
+    for (const [op, w, h, f] of fx.ops) {
+      log = [];
+      let uid = null;
+      if (op === "create") uid = ctx.fboCreate(w, h, f).fb.uid; else ctx.fboDelete(w, h, f);
+      got.push([uid, log]);
+    }
+    fs.writeFileSync(out, JSON.stringify(got));
+    return;
+  }
   if (mode === "replay") {  // no GPU needed: doRenderJob over the schemas of tests/golden/host_reference.json.gz with the addon's calls recorded
     const fx = JSON.parse(require("zlib").gunzipSync(fs.readFileSync(process.argv[4])).toString());
     const a = rm.addon;

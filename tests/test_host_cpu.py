@@ -413,3 +413,56 @@ def compare_host_events(k, schema, events, want):
             extra = set(ru) - set(mine) - {"previousColor", "previousNormalAndDofRadius", "previousAlbedoAndDepth"}
             # with no light the reference leaves the light arrays as an earlier job set them (lightCount = 0 makes them dead)
             assert extra <= ({"lightPositions", "lightColors", "lightSizes"} if not n_lights else set()), f"job {k}: uniforms of the reference not compared: {extra}"
+
+
+def fbo_events_equal(results, got):
+    """got[i] = (uid or None, [("created", uid) | ("cleared", uid) | ("destroyed", uid), ...]) per operation, against the fixture."""
+    assert len(got) == len(results)
+    for i, (ref, (uid, events)) in enumerate(zip(results, got)):
+        assert uid == ref["result"], f"operation {i}: framebuffer set {uid} against the reference's {ref['result']}"
+        want = [(k, e[k]) for e in ref["events"] for k in ("created", "cleared", "destroyed") if k in e]
+        assert events == want, f"operation {i}: {events} against {want}"
+
+
+def test_framebuffer_cache_replays_the_reference_cache_operation_by_operation():
+    """tests/golden/fbo_reference.json: what the reference's context.fbo (LoadRenderJobContext.tsx:160-250, run under node by
+    oracle/ts/gen_fbo_golden.py) does for 600 random create / delete operations over 12 keys: which framebuffer set comes
+    back (fresh, still live, or out of the purgatory), when `prev` is cleared (a parked set taken up under a new
+    frameid), which sets the purgatory evicts.  job.RenderJobContext.fbo_create / fbo_delete do the same, operation by
+    operation."""
+    import json
+    from pathlib import Path
+
+    from raymarching_engine_amd import job as J
+
+    fx = json.loads((Path(__file__).parent / "golden" / "fbo_reference.json").read_text())
+    log = []
+
+    class FakeFb:
+        serial = 0
+        def __init__(self):
+            FakeFb.serial += 1
+            self.uid = FakeFb.serial
+            log.append(("created", self.uid))
+        def clear(self): log.append(("cleared", self.uid))
+        def destroy(self): log.append(("destroyed", self.uid))
+
+    class FakeNative:
+        def create_framebuffer(self, *a): return FakeFb()
+
+    class Ctx(J.RenderJobContext):
+        def __init__(self):
+            self.native, self.flags, self.rows = FakeNative(), 0, None
+            self._scenes, self._live, self._purgatory = {}, {}, []
+
+    c = Ctx()
+    got = []
+    for op, w, h, f in fx["ops"]:
+        del log[:]
+        uid = None
+        if op == "create":
+            uid = c.fbo_create(w, h, f).uid
+        else:
+            c.fbo_delete(w, h, f)
+        got.append((uid, list(log)))
+    fbo_events_equal(fx["results"], got)

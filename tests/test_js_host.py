@@ -137,3 +137,15 @@ def test_js_render_job_host_replays_the_reference_loop_call_by_call(tmp_path):
             else:
                 events.append((kind, e[kind]))
         compare_host_events(k, schema, events, want)
+
+
+def test_js_framebuffer_cache_replays_the_reference_cache(tmp_path):
+    """js/index.js RenderJobContext.fboCreate / fboDelete over the 600 operations of tests/golden/fbo_reference.json (the
+    reference's own cache under node): the same framebuffer sets, clears and evictions, operation by operation."""
+    from test_host_cpu import fbo_events_equal
+
+    fixture = ROOT / "tests" / "golden" / "fbo_reference.json"
+    out = tmp_path / "fbo.json"
+    subprocess.run(["node", str(JS / "render_cli.js"), str(out), "fbo", str(fixture)], check=True, timeout=60)
+    got = [(uid, [tuple(e) for e in events]) for uid, events in json.loads(out.read_text())]
+    fbo_events_equal(json.loads(fixture.read_text())["results"], got)
