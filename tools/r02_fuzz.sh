@@ -1,0 +1,11 @@
+#!/bin/bash
+# the randomised tests of the GPU suite at 50-100x their default counts, for the record
+mkdir -p gpurun_out/r2fuzz
+{
+date
+RM_RANDOM_JOBS=20000 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -s -k "random_jobs_strict" 2>&1 | grep "random jobs\|passed\|failed"
+RM_RANDOM_SCENES=20000 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "random_scenes_probes" 2>&1 | tail -1
+RM_RANDOM_JOBS2=20000 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "random_jobs_partitions" 2>&1 | tail -1
+for s in 11 12 13; do SEED=$s timeout 300 python3 tools/dbg/abuse_fuzz.py 10000 2>&1 | tail -1; done
+date
+} | tee gpurun_out/r2fuzz/log.txt
