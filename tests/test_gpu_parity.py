@@ -997,6 +997,39 @@ def test_random_scenes_probes_equal_the_oracle_bit_for_bit(ctx):
         assert same_bits(ctx.probe_rng(u, w, hh, 5), O.rng(u, w, hh, 5)).all(), f"scene {it}: rng {w}x{hh}"
 
 
+def test_random_jobs_fast_build_estimates_what_the_strict_build_estimates(ctx):
+    """60 random full-mode jobs (scenes of every kind, cameras, 0-2 lights, 1-3 bounces of >= 128 steps -- enough for a sky
+    ray to overflow): the image mean of 32 fast samples against 32 strict samples with the same random
+    stream differs by no more than four times what 32 strict samples with ANOTHER stream differ by (the Monte-Carlo
+    yardstick), plus 1 % of the mean, and the two builds agree on which pixels are finite.  (tools/dbg/
+    fast_vs_strict_fuzz.py is the study this comes from.)"""
+    rng = np.random.default_rng(2026)
+    spp = 32
+    noise = GC.halton_pairs(2 * spp)
+    worst = 0.0
+    for it in range(60):
+        sc, pos = _random_scene(rng)
+        counts = tuple(int(c) for c in rng.integers(128, 200, size=rng.integers(1, 4)))
+        lights = [J.point_light(tuple(rng.uniform(-4, 4, 3)), size=float(rng.choice([0.0, 0.3]))) for _ in range(int(rng.integers(0, 3)))]
+        cam = ("perspective", "perspective", "orthographic", "panoramic")[rng.integers(0, 4)]
+        schema = J.make_schema(sc, 96, 64, counts=counts, render_mode="full", position=tuple(np.array(pos) + rng.uniform(-0.2, 0.2, 3)), rotation=GC.ROT if rng.random() < 0.5 else None,
+                               camera=cam, fov=float(rng.uniform(0.8, 1.8)) if cam != "orthographic" else float(rng.uniform(2.0, 5.0)), lights=lights, fog_density=float(rng.choice([0.0, 0.0, 0.1])))
+        s1 = render_gpu(ctx, sc, schema, noise[:spp], STRICT)[0][..., :3] / spp
+        fa = render_gpu(ctx, sc, schema, noise[:spp], FAST)[0][..., :3] / spp
+        s2 = render_gpu(ctx, sc, schema, noise[spp:], STRICT)[0][..., :3] / spp
+        f1, f2, f3 = (np.isfinite(a).all(-1) for a in (s1, fa, s2))
+        assert (f1 == f2).mean() >= 0.98, f"job {it}: the builds disagree on which pixels are finite"
+        fin = f1 & f2 & f3
+        if fin.mean() < 0.2:
+            continue
+        m = float(s1[fin].mean())
+        d_fast, d_mc = float(abs(fa[fin].mean() - m)), float(abs(s2[fin].mean() - m))
+        worst = max(worst, d_fast / (4 * d_mc + 0.01 * abs(m) + 2e-4))
+        assert d_fast <= 4 * d_mc + 0.01 * abs(m) + 2e-4, (f"job {it}: {type(sc).__name__} counts {counts} cam {cam} lights {len(lights)}: mean {m:.5f}, "
+                                                          f"fast - strict {d_fast:.2e}, strict' - strict {d_mc:.2e}")
+    print(f"\nrandom jobs, fast against strict: largest |difference of the means| / allowance {worst:.3f}")
+
+
 def test_random_jobs_partitions_and_implementations_leave_the_same_bits(ctx):
     """150 random jobs (scenes, cameras, lights, modes as above; both builds): the whole frame by the pixel kernel is
     the reference; the same frame through the OTHER implementation, and cut up at random -- two row windows, striped

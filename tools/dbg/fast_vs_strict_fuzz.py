@@ -19,7 +19,8 @@ flagged = 0; ratios = []
 for it in range(n_jobs):
     sc, pos = tg._random_scene(rng)
     w, h = 96, 64
-    counts = tuple(int(c) for c in rng.integers(24, 96, size=rng.integers(1, 4)))
+    lo = int(os.environ.get("MIN_STEPS", "24"))
+    counts = tuple(int(c) for c in rng.integers(lo, lo + 72, size=rng.integers(1, 4)))
     lights = [J.point_light(tuple(rng.uniform(-4, 4, 3)), size=float(rng.choice([0.0, 0.3]))) for _ in range(int(rng.integers(0, 3)))]
     cam = ("perspective", "perspective", "orthographic", "panoramic")[rng.integers(0, 4)]
     schema = J.make_schema(sc, w, h, counts=counts, render_mode="full", position=tuple(np.array(pos) + rng.uniform(-0.2, 0.2, 3)), rotation=GC.ROT if rng.random() < 0.5 else None,
