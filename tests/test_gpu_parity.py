@@ -1036,9 +1036,11 @@ def test_random_jobs_partitions_and_implementations_leave_the_same_bits(ctx):
     parts as the ranks of a sharded run hold them, a grid of tiles -- through a random implementation, gives the same
     bits in every plane."""
     rng = np.random.default_rng(4242)
+    scale = int(os.environ.get("RM_RANDOM_SCALE", "1"))  # larger frames: the wavefront pipeline's bands, cost-ordered tiles
     for it in range(int(os.environ.get("RM_RANDOM_JOBS2", "150"))):
         sc, pos = _random_scene(rng)
-        w, h = int(rng.integers(24, 96)), int(rng.integers(16, 80))
+        big = scale if scale > 1 else (6 if it % 10 == 9 else 1)  # every tenth job is a frame of up to 576 x 480
+        w, h = int(rng.integers(24, 96)) * big, int(rng.integers(16, 80)) * big
         mode = "preview" if rng.random() < 0.25 else "full"
         counts = tuple(int(c) for c in rng.integers(6, 32, size=rng.integers(1, 4)))
         lights = [J.point_light(tuple(rng.uniform(-4, 4, 3)), size=float(rng.choice([0.0, 0.3]))) for _ in range(int(rng.integers(0, 3)))]
