@@ -143,7 +143,7 @@ def self_launch(args):
     import torch  # importing torch and counting devices does not initialise the GPU
 
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and os.environ.get("RM_BENCH_SHARE_GPU") != "1":  # (testing aid: every rank on GPU 0, see main)
         sys.exit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -207,6 +207,11 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the product has no CPU path")
+    # RM_BENCH_SHARE_GPU=1 (testing aid, with RM_BENCH_BACKEND=gloo): every rank uses GPU 0, so that the whole N > 1 control
+    # flow -- rendezvous, sharding, yields, gathers, assembly, the max over ranks -- runs on a box with one GPU
+    share_gpu = os.environ.get("RM_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         sys.exit(f"bench.py: rank {rank} wants GPU {local_rank} but only {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local_rank)
@@ -220,7 +225,11 @@ def main():
         if force_dist and world == 1:
             for key, val in (("MASTER_PORT", "29511"), ("RANK", "0"), ("WORLD_SIZE", "1")):
                 os.environ.setdefault(key, val)
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("RM_BENCH_BACKEND", "nccl")  # "gloo": testing aid, the gathered rows travel through host memory
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     sharded = world > 1 or force_dist
 
     wl, sc, schema = make_workload(args.workload)

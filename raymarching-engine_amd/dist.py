@@ -104,6 +104,13 @@ class FrameGatherer:
                 snap.copy_(plane)
             if self.aux is not None:
                 self.aux.wait_stream(cur)  # the snapshot is complete; the previous frame's assembly is earlier on aux
+            if dist.get_backend() == "gloo":
+                # testing aid (several ranks sharing ONE GPU cannot use RCCL): the rows travel through host memory
+                host = snap.cpu()
+                recv_host = [torch.empty_like(host) for _ in range(self.world)] if self.rank == self.dst else None
+                work = dist.gather(host, recv_host, dst=self.dst, async_op=True)
+                self.pending = (work, k, recv_host)
+                return self.pending
             with torch.cuda.stream(self.aux if self.aux is not None else cur):
                 work = dist.gather(snap, self.recv if self.rank == self.dst else None, dst=self.dst, async_op=True)
             self.pending = (work, k)
@@ -120,13 +127,17 @@ class FrameGatherer:
         if self.world == 1 and not self.force:
             return handle
         assert self.pending is not None and (handle is None or handle is self.pending)
-        work, k = self.pending
+        work, k = self.pending[0], self.pending[1]
+        recv_host = self.pending[2] if len(self.pending) > 2 else None
         self.pending = None
         torch = self.torch
         if self.snaps is not None:
             on = self.stream()
             with torch.cuda.stream(on):
-                work.wait()  # a stream-level wait, not a host one
+                work.wait()  # a stream-level wait, not a host one (gloo: a host wait)
+                if recv_host is not None:
+                    for p in range(self.world):
+                        self.recv[p].copy_(recv_host[p], non_blocking=False)
                 ev = torch.cuda.Event()
                 ev.record(on)
                 self.snap_free[k] = ev

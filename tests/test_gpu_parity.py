@@ -1485,3 +1485,29 @@ def test_bench_under_the_drivers_launcher_with_one_rank(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["steps"] == 4 and out["warmup"] == 2 and out["value"] > 100.0
     assert "gathered to rank 0 over RCCL" in out["config"]["sharding"] and out["roofline"]["frac"] > 0.2
+
+
+def test_bench_with_four_ranks_sharing_this_gpu(tmp_path):
+    """`python bench.py --gpus 4` -- the self-launch the driver's N > 1 command line goes through when no launcher set
+    WORLD_SIZE -- with its two testing aids: RM_BENCH_SHARE_GPU=1 (every rank renders on GPU 0: this box has one) and
+    RM_BENCH_BACKEND=gloo (RCCL refuses two ranks on one device; the gathered rows travel through host memory instead).
+    Everything else is the N > 1 path as it runs on a node: four processes, the rendezvous, each rank's stripes, sample
+    batches, a present and a gather per yield, the assembly on rank 0, the barrier and the max over ranks, the
+    present-every-sample leg, one JSON line from rank 0."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RM_BENCH_SHARE_GPU="1", RM_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "16", "--warmup", "8", "--no-cpu-baseline"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=500, env=env)
+    except subprocess.TimeoutExpired:
+        pytest.skip("four torch processes did not start within 500 s on this box; steady state is ~20 s")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["steps"] == 16 and out["value"] > 50.0 and out["config"]["sample_yield_interval"] == 8
+    assert out["config"]["rows_per_gpu"] in (536, 544) and out["present_every_sample"]["value"] > 10.0
