@@ -188,6 +188,9 @@ def main():
                          "sharded, gathered -- every this many samples; the samples in between go to the library in one "
                          "rm_render_samples call.  Default: 1 on one GPU (the live loop's value, index.tsx:166), 8 when the "
                          "frame is sharded")
+    ap.add_argument("--check-frame", action="store_true",
+                    help="sharded runs: after the timed legs rank 0 renders the same samples on ONE framebuffer, presents it and compares "
+                         "the bytes with the frame it assembled from the gathered rows (reported as `frame_check`)")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -355,6 +358,26 @@ def main():
         every_sample = {"sample_yield_interval": 1, "samples_in_flight": 4, "value": px_frame * args.steps / e1 / 1e6,
                         "ms_per_step": e1 / args.steps * 1e3}
 
+    # --check-frame: the frame rank 0 assembled from the gathered rows against the same samples rendered and presented on
+    # ONE framebuffer here (the accumulation per pixel is in sample order either way: the bytes must be identical)
+    frame_check = None
+    if args.check_frame and sharded and rank == 0 and payload == "rgba8":
+        torch.cuda.synchronize()
+        whole = ctx.create_framebuffer(W, H)
+        g2, g3 = J.halton(2), J.halton(3)
+        pairs = [(next(g2), next(g3)) for _ in range(samples[0])]
+        ctx.set_sample_batch(1)
+        ctx.set_samples_in_flight(1)
+        ctx.render_samples(scene, whole, u_step, pairs, None, flags)
+        expect = whole.present(samples[0])
+        whole.destroy()
+        ctx.set_sample_batch(0)
+        ctx.set_samples_in_flight(in_flight)
+        got = gatherer.frame.cpu().numpy()
+        frame_check = bool(np.array_equal(got, expect))
+        if not frame_check:
+            sys.exit(f"bench.py --check-frame: the assembled frame differs from the single-framebuffer render in {int((got != expect).sum())} bytes")
+
     overlap = None
     if world == 1 and not force_dist and in_flight == 1 and args.overlap_leg:
         # for information: the same K steps with consecutive samples overlapping on the device (what a sharded run uses)
@@ -432,7 +455,7 @@ def main():
                        if sharded else "none",
                        "planes": "color+normal_dof+albedo_depth fp32, accumulated in place", "samples_in_flight": in_flight,
                        "sample_yield_interval": yield_interval},
-            "roofline": roof, "cpu_baseline": cpu, "overlap": overlap, "present_every_sample": every_sample,
+            "roofline": roof, "cpu_baseline": cpu, "overlap": overlap, "present_every_sample": every_sample, "frame_check": frame_check,
         }
     fb.destroy()
     scene.destroy()

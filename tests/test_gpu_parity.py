@@ -1493,14 +1493,15 @@ def test_bench_with_four_ranks_sharing_this_gpu(tmp_path):
     RM_BENCH_BACKEND=gloo (RCCL refuses two ranks on one device; the gathered rows travel through host memory instead).
     Everything else is the N > 1 path as it runs on a node: four processes, the rendezvous, each rank's stripes, sample
     batches, a present and a gather per yield, the assembly on rank 0, the barrier and the max over ranks, the
-    present-every-sample leg, one JSON line from rank 0."""
+    present-every-sample leg, one JSON line from rank 0 -- and the assembled frame is checked against a one-framebuffer
+    render of the same samples (--check-frame)."""
     import json
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, RM_BENCH_SHARE_GPU="1", RM_BENCH_BACKEND="gloo")
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "16", "--warmup", "8", "--no-cpu-baseline"]
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "16", "--warmup", "8", "--no-cpu-baseline", "--check-frame"]
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=500, env=env)
     except subprocess.TimeoutExpired:
@@ -1511,3 +1512,6 @@ def test_bench_with_four_ranks_sharing_this_gpu(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 4 and out["steps"] == 16 and out["value"] > 50.0 and out["config"]["sample_yield_interval"] == 8
     assert out["config"]["rows_per_gpu"] in (536, 544) and out["present_every_sample"]["value"] > 10.0
+    # --check-frame: the frame rank 0 assembled from the four ranks' gathered rows is, byte for byte, the present of the same
+    # 48 samples rendered on one framebuffer
+    assert out["frame_check"] is True
