@@ -21,6 +21,7 @@
 #ifndef HIP_RAYMARCH_H
 #define HIP_RAYMARCH_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus

@@ -466,3 +466,15 @@ def test_framebuffer_cache_replays_the_reference_cache_operation_by_operation():
             c.fbo_delete(w, h, f)
         got.append((uid, list(log)))
     fbo_events_equal(fx["results"], got)
+
+
+def test_public_header_is_self_contained_c_and_cxx(tmp_path):
+    """include/hip_raymarch.h compiles on its own as C99 (-pedantic) and as C++11: the boundary is a C ABI."""
+    import subprocess
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "include/hip_raymarch.h"\nint main(void) { return RM_ABI_VERSION > 0 ? 0 : 1; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", str(root), str(src)], check=True)
+    subprocess.run(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c++", "-I", str(root), str(src)], check=True)
