@@ -18,7 +18,7 @@ import glref  # noqa: E402
 from gen_golden import FETCH, pack  # noqa: E402
 from raymarching_engine_amd import abi, scene as S  # noqa: E402
 
-N_SCENES = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+N_SCENES = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 32
 W = H = 16  # 256 points / rays per scene
 STEPS = 24.0
 
@@ -87,5 +87,59 @@ def main():
     print("wrote", dest, dest.stat().st_size, "B")
 
 
+MAT_FIELDS = ("diffuse", "diffuse_cutoff", "specular", "specular_cutoff", "roughness", "subsurface", "subsurface_color", "ior", "sky_color", "sky_floor", "sky_scale",
+              "sky_radius", "sky_axis")
+
+
+def images(n_cases: int = 12):
+    """tests/golden/random_images.npz: the reference's unmodified main() (tan routed to the portable tangent, as for every
+    whole-image golden) on random tables with RANDOM MATERIALS -- colours, roughness, ior, subsurface on and off, sky
+    colours -- under 1-3 random lights, two bounces of 128 and 64 steps, 64 x 32 pixels, 2 samples: three planes each."""
+    import dataclasses
+
+    import golden_cases as GC
+    from raymarching_engine_amd import job as J
+
+    rng = np.random.default_rng(777)
+
+    def f32(v):
+        v = np.float32(v)
+        while not survives_translation(v):
+            v = np.nextafter(v, np.float32(0.0))
+        return float(v)
+
+    out = {"count": np.int32(n_cases)}
+    for i in range(n_cases):
+        sc = random_table(rng)
+        sc.material = S.Material(diffuse=tuple(f32(v) for v in rng.uniform(0.1, 0.9, 3)), specular=tuple(f32(v) for v in rng.uniform(0.1, 0.9, 3)),
+                                 roughness=f32(rng.uniform(0.05, 0.8)), ior=f32(rng.choice([1.3, 1.5, 2.4, 100.0])), subsurface=f32(rng.choice([11111115.0, 4.0, 0.75])),
+                                 subsurface_color=tuple(f32(v) for v in rng.uniform(0.3, 1.0, 3)), sky_color=tuple(f32(v) for v in rng.uniform(0.3, 1.0, 3)),
+                                 sky_floor=f32(rng.uniform(0.05, 0.4)), sky_scale=f32(rng.uniform(0.5, 2.5)))
+        lights = [J.point_light(tuple(f32(v) for v in rng.uniform(-4, 4, 3)), color=tuple(f32(v) for v in rng.uniform(0.3, 1, 3)), strength=f32(rng.uniform(1, 4)),
+                                size=f32(rng.choice([0.0, 0.0, 0.3]))) for _ in range(int(rng.integers(1, 4)))]
+        pos = tuple(f32(v) for v in (0.2 + rng.uniform(-0.3, 0.3), 0.1 + rng.uniform(-0.3, 0.3), -4.0))
+        schema = J.make_schema(sc, 64, 32, counts=(128, 64), render_mode="full", position=pos, lights=lights, fov=f32(rng.uniform(0.9, 1.6)))
+        schema["sdfShaderSource"] = sc.glsl()
+        noise = GC.halton_pairs(2)
+        base = glref.uniforms_from_schema(schema, noise[0])
+        draws = [{"randNoise": glref.u_float(*x)} for x in noise]
+        r = glref.run_gl(glref.with_portable_tan(glref.splice(sc.glsl())), 64, 32, base, draws=draws, read=(0, 1, 2))
+        pl = r["planes"]
+        m = dataclasses.asdict(sc.material)
+        out[f"rows_{i}"] = rows_of(sc)
+        out[f"material_{i}"] = np.array([x for k in MAT_FIELDS for x in (m[k] if isinstance(m[k], (tuple, list)) else [m[k]])], np.float64)
+        out[f"lights_{i}"] = np.array([[*l["position"], *l["color"], l["size"]] for l in lights], np.float64)
+        out[f"camera_{i}"] = np.array([*pos, schema["camera"]["mode"]["fov"]], np.float64)
+        out[f"color_{i}"], out[f"normal_dof_{i}"], out[f"albedo_depth_{i}"] = pl[0], pl[1], pl[2]
+        print(f"image {i}: {len(out[f'rows_{i}'])} rows, {len(lights)} lights, subsurface {sc.material.subsurface}, finite {np.isfinite(pl[0]).all(-1).mean():.2f}")
+    out["rand_noise"] = np.array(noise, np.float64)
+    dest = ROOT / "tests" / "golden" / "random_images.npz"
+    np.savez_compressed(dest, **out)
+    print("wrote", dest, dest.stat().st_size, "B")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "images":
+        images()
+    else:
+        main()

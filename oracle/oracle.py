@@ -54,6 +54,7 @@ def _lib(count: bool = False):
         lib.or_set_nan_mode.argtypes = [C.c_int]
         lib.or_set_tan_mode.argtypes = [C.c_int]
         lib.or_set_math_mode.argtypes = [C.c_int]
+        lib.or_set_math_round_bits.argtypes = [C.c_int]
         _libs[key] = lib
     return _libs[key]
 
@@ -77,6 +78,12 @@ def set_math_mode(mode: int) -> None:
     """MATH_PORTABLE (default: oracle/pm_math.h, the same text the HIP kernels compile) or MATH_LIBM, for both variants."""
     _lib(False).or_set_math_mode(mode)
     _lib(True).or_set_math_mode(mode)
+
+
+def set_math_round_bits(bits: int) -> None:
+    """Sensitivity probe (0 = off): sin / cos / log / exp / pow / acos results rounded to `bits` significant bits."""
+    _lib(False).or_set_math_round_bits(bits)
+    _lib(True).or_set_math_round_bits(bits)
 
 
 class Frame:

@@ -73,6 +73,17 @@ void or_set_tan_mode(int mode) { or_tan_mode = mode; }
 enum { OR_MATH_LIBM = 0, OR_MATH_PORTABLE = 1 };
 static int or_math_mode = OR_MATH_PORTABLE;
 void or_set_math_mode(int mode) { or_math_mode = mode; }
+/* Sensitivity probe for the tests (0 = off, the default): round every sin / cos / log / exp / pow / acos result to `bits`
+ * significant bits.  tests/test_oracle_golden.py uses it to show that what separates this file from the reference's GLSL
+ * under SwiftShader on glossy random materials is what ~20-bit transcendentals alone produce, case by case. */
+static int or_math_round_bits = 0;
+void or_set_math_round_bits(int bits) { or_math_round_bits = bits; }
+static inline float o_rounded(float v) {
+  if (or_math_round_bits <= 0 || or_math_round_bits >= 24 || !(v == v) || isinf(v)) return v;
+  int e;
+  float m = frexpf(v, &e), sc = ldexpf(1.0f, or_math_round_bits);
+  return ldexpf(rintf(m * sc) / sc, e);
+}
 
 #define PM_FN static inline
 static inline unsigned long long PM_D2U(double x) { unsigned long long u; memcpy(&u, &x, 8); return u; }
@@ -80,12 +91,15 @@ static inline double PM_U2D(unsigned long long u) { double x; memcpy(&x, &u, 8);
 static inline unsigned int PM_F2U(float x) { unsigned int u; memcpy(&u, &x, 4); return u; }
 #include "pm_math.h"
 
-static inline float o_sin(float x) { return or_math_mode == OR_MATH_LIBM ? sinf(x) : pm_sin(x); }
-static inline float o_cos(float x) { return or_math_mode == OR_MATH_LIBM ? cosf(x) : pm_cos(x); }
-static inline float o_log(float x) { return or_math_mode == OR_MATH_LIBM ? logf(x) : pm_log(x); }
-static inline float o_exp(float x) { return or_math_mode == OR_MATH_LIBM ? expf(x) : pm_exp(x); }
-static inline float o_pow(float x, float y) { return or_math_mode == OR_MATH_LIBM ? powf(x, y) : pm_pow(x, y); }
-static inline float o_acos(float x) { return or_math_mode == OR_MATH_LIBM ? acosf(x) : pm_acos(x); }
+static inline float o_sin(float x) { return o_rounded(or_math_mode == OR_MATH_LIBM ? sinf(x) : pm_sin(x)); }
+static inline float o_cos(float x) { return o_rounded(or_math_mode == OR_MATH_LIBM ? cosf(x) : pm_cos(x)); }
+static inline float o_log(float x) { return o_rounded(or_math_mode == OR_MATH_LIBM ? logf(x) : pm_log(x)); }
+static inline float o_exp(float x) { return o_rounded(or_math_mode == OR_MATH_LIBM ? expf(x) : pm_exp(x)); }
+static inline float o_pow(float x, float y) {
+  float v = or_math_mode == OR_MATH_LIBM ? powf(x, y) : pm_pow(x, y);
+  return y == 2.0f ? v : o_rounded(v); /* pow(x, 2.0) is a product in every implementation met so far */
+}
+static inline float o_acos(float x) { return o_rounded(or_math_mode == OR_MATH_LIBM ? acosf(x) : pm_acos(x)); }
 static inline float o_atan2(float y, float x) { return or_math_mode == OR_MATH_LIBM ? atan2f(y, x) : pm_atan2(y, x); }
 
 static float or_tan(float x) {
