@@ -971,7 +971,8 @@ def test_random_materials_whole_main_strict_build_is_the_oracle_and_tracks_the_r
     and cameras (two bounces, 2 samples).  The strict build's three planes are the oracle's bits; against the REFERENCE's
     image the first hit is held to 1 % of the pixels at 1e-5 and the colour to the bound tests/test_oracle_golden.py
     derives case by case (SwiftShader's own transcendentals in the bounce; there with the x86 NaN conventions, here with
-    the IEEE ones of the hardware, hence the comparison over the pixels that are finite on both sides)."""
+    the IEEE ones of the hardware, hence the comparison over the pixels that are finite on both sides, where there are at
+    least 64 of them)."""
     z = load("random_images")
     for i in range(int(z["count"])):
         sc, schema, noises = GC.random_image_case(z, i)
@@ -990,7 +991,7 @@ def test_random_materials_whole_main_strict_build_is_the_oracle_and_tracks_the_r
             both = np.isfinite(ref).all(-1) & np.isfinite(planes[k]).all(-1)
             with np.errstate(invalid="ignore"):
                 d = (np.abs(ref - planes[k]) / np.maximum(1.0, np.abs(ref))).max(-1)[both]
-            assert d.size == 0 or float(np.mean(d > 1e-5)) <= bar, f"case {i}: {name} against the reference {float(np.mean(d > 1e-5)):.4f}"
+            assert d.size < 64 or float(np.mean(d > 1e-5)) <= bar, f"case {i}: {name} against the reference {float(np.mean(d > 1e-5)):.4f}"
         fb.destroy()
         h.destroy()
 
