@@ -3,7 +3,7 @@ on RANDOM scenes of the composition API -- primitive tables of 1..10 spheres / b
 them behind a repeat and / or an unrotated fold row -- at random points and along random rays.  These scenes are
 + - * / sqrt floor abs min max only, so the reference's bits are the bar: the oracle (CPU tests) and the HIP strict build
 (GPU tests) must reproduce them exactly.  Build-container only (needs /root/reference and the kaleido wheel):
-    python oracle/gl/gen_random_golden.py [scenes]
+    python oracle/gl/gen_random_golden.py [scenes | images | kinds]
 The file holds numbers only: per scene the table rows, the points / rays, and the reference's outputs."""
 from __future__ import annotations
 
@@ -138,8 +138,60 @@ def images(n_cases: int = 12):
     print("wrote", dest, dest.stat().st_size, "B")
 
 
+def random_kind(rng, k: int):
+    """One of the reference's example scenes with RANDOM values of its annotated uniforms (within their //@min ... //@max),
+    and a camera position for its rays."""
+    f = lambda lo, hi: float(np.float32(rng.uniform(lo, hi)))
+    if k == 0:
+        return S.SphereGridFractal(big_sphere_size=f(2.0, 6.0), iterations=float(rng.integers(1, 9)), grid_scale=f(0.2, 0.6),
+                                   big_sphere_center=(f(-1, 1), f(-1, 1), f(6.0, 12.0))), (0.0, 0.0, 0.0)
+    if k == 1:
+        return S.MengerSponge(iterations=float(rng.integers(1, 9))), (0.5, 0.5, -2.0)
+    if k == 2:
+        return S.KifsTree(iterations=float(rng.integers(1, 11)), scale=f(0.5, 0.85), angles=(f(-3, 3), f(-3, 3), f(-3, 3)), offset=f(0.7, 1.6), smoothen=False), (0.0, 0.3, -3.5)
+    if k == 3:
+        return S.KifsTree(iterations=float(rng.integers(1, 11)), scale=f(0.5, 0.85), angles=(f(-3, 3), f(-3, 3), f(-3, 3)), offset=f(0.7, 1.6), smoothen=True), (0.0, 0.3, -3.5)
+    return S.KifsBox(iterations=float(rng.integers(1, 17)), scale=f(0.35, 0.7), angles=(f(-1.5, 1.5), f(-1.5, 1.5), f(-1.5, 1.5)), offset=f(0.7, 1.6)), (0.2, 0.1, -3.0)
+
+
+def kinds(per_kind: int = 5):
+    """tests/golden/random_kinds.npz: the reference's own example scenes (fractal1, menger-sponge, tree, smooth-tree,
+    rotation-fractal; their text read from /root/reference at run time) with random values of their annotated uniforms:
+    sdf() at 256 random points and castRay() along 256 random rays each.  The file holds the parameter values, the
+    points / rays and the reference's outputs."""
+    rng = np.random.default_rng(4242)
+    out, n = {}, 0
+    for k in range(5):
+        for _ in range(per_kind):
+            sc, pos = random_kind(rng, k)
+            text, uni = glref.example_scene_text(sc.example), dict(sc.custom_shader_parameters())
+            pts = rng.normal(scale=float(rng.choice([0.7, 2.0, 6.0])), size=(W * H, 3)).astype(np.float32)
+            frag = glref.splice(text, "void main(void){ " + FETCH + " fragColor = vec4(sdf(t.xyz), 0.0, 0.0, 0.0); }")
+            g = glref.run_gl(frag, W, H, uni, init_prev0=pack(pts, W, H))["planes"][0]
+            org = np.array(pos, np.float32)
+            dirs = rng.normal(size=(W * H, 3)).astype(np.float32); dirs[:, 2] = np.abs(dirs[:, 2]) + np.float32(1.5)
+            dirs = (dirs / np.linalg.norm(dirs, axis=1, keepdims=True)).astype(np.float32)
+            u2 = dict(uni); u2["position"] = glref.u_float(*[float(v) for v in org]); u2["hsteps"] = glref.u_float(STEPS)
+            harness = "uniform float hsteps;\nvoid main(void){ " + FETCH + " vec3 e = castRay(position, t.xyz, hsteps); fragColor = vec4(e, sdf(e)); }"
+            e = glref.run_gl(glref.splice(text, harness), W, H, u2, init_prev0=pack(dirs, W, H))["planes"][0].reshape(-1, 4)
+            out[f"kind_{n}"] = np.int32(k)
+            out[f"params_{n}"] = np.array(sc.params(), np.float64)
+            out[f"points_{n}"] = pts
+            out[f"sdf_{n}"] = g[..., 0].reshape(-1).astype(np.float32)
+            out[f"rays_{n}"] = np.concatenate([np.tile(org, (W * H, 1)), dirs], 1).astype(np.float32)
+            out[f"end_{n}"] = e[:, :3].astype(np.float32)
+            print(f"scene {n}: {type(sc).__name__} {sc.params()}, finite ends {np.isfinite(e[:, :3]).all(1).mean():.2f}")
+            n += 1
+    out["count"] = np.int32(n); out["steps"] = np.float32(STEPS)
+    dest = ROOT / "tests" / "golden" / "random_kinds.npz"
+    np.savez_compressed(dest, **out)
+    print("wrote", dest, dest.stat().st_size, "B")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "images":
         images()
+    elif len(sys.argv) > 1 and sys.argv[1] == "kinds":
+        kinds()
     else:
         main()

@@ -880,11 +880,14 @@ def _random_scene(rng):
         mat = S.Material(diffuse=tuple(rng.uniform(0.1, 0.9, 3)), specular=tuple(rng.uniform(0.1, 0.9, 3)), roughness=float(rng.uniform(0.05, 0.8)),
                          ior=float(rng.choice([1.3, 1.5, 100.0])), subsurface=float(rng.choice([11111115.0, 4.0, 0.7])),
                          subsurface_color=tuple(rng.uniform(0.3, 1.0, 3)))
-    kind = rng.integers(0, 7)
+    kind = rng.integers(0, 8)
     if kind == 0:
         return S.Mandelbulb(power=float(rng.choice([2.0, 3.0, 5.0, 8.0, 8.0, 9.0])), iterations=int(rng.integers(1, 9)), material=mat), (0.1, 0.2, -2.6)
     if kind == 1:
-        return S.SphereGridFractal(iterations=float(rng.integers(1, 7)), material=mat), (0.0, 0.0, 0.0)
+        if rng.random() < 0.5:
+            return S.SphereGridFractal(iterations=float(rng.integers(1, 7)), material=mat), (0.0, 0.0, 0.0)
+        return S.SphereGridFractal(big_sphere_size=float(rng.uniform(2.0, 6.0)), iterations=float(rng.integers(1, 9)), grid_scale=float(rng.uniform(0.2, 0.6)),
+                                   big_sphere_center=(float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1)), float(rng.uniform(6.0, 12.0))), material=mat), (0.0, 0.0, 0.0)
     if kind == 2:
         return S.MengerSponge(iterations=float(rng.integers(1, 6)), material=mat), (0.2, 0.3, -3.0)
     if kind == 3:
@@ -892,6 +895,9 @@ def _random_scene(rng):
                           offset=float(rng.uniform(0.8, 1.5)), smoothen=bool(rng.random() < 0.5), material=mat), (0.0, 0.3, -3.5)
     if kind == 4:
         return S.SphereLattice(period=float(rng.uniform(1.5, 3.0)), radius=float(rng.uniform(0.2, 0.6)), material=mat), (0.3, 0.2, -0.1)
+    if kind == 5:
+        return S.KifsBox(iterations=float(rng.integers(1, 17)), scale=float(rng.uniform(0.35, 0.7)), angles=tuple(rng.uniform(-1.5, 1.5, 3)),
+                         offset=float(rng.uniform(0.7, 1.6)), material=mat), (0.2, 0.1, -3.0)
     sc = S.CsgScene(material=mat)
     if rng.random() < 0.3:
         sc.repeat(tuple(rng.uniform(2.5, 4.0, 3)))
@@ -964,6 +970,30 @@ def test_random_tables_match_the_reference_glsl_bit_for_bit(ctx):
         assert same_bits(ctx.probe(h, abi.RM_PROBE_SDF, z[f"points_{i}"]), z[f"sdf_{i}"]).all(), f"scene {i}: sdf"
         assert same_bits(ctx.probe(h, abi.RM_PROBE_CAST_RAY, z[f"rays_{i}"], float(z["steps"])), z[f"end_{i}"]).all(), f"scene {i}: castRay"
         h.destroy()
+
+
+def test_reference_example_scenes_with_random_parameter_values(ctx):
+    """tests/golden/random_kinds.npz: the reference's example scenes under software GL with 25 random settings of their
+    annotated uniforms.  The strict build's sdf and castRay are the oracle's bits, and within the tolerance
+    tests/test_oracle_golden.py states of the REFERENCE's values (SwiftShader's pow / sin / cos in the scale tables and
+    rotations); the fast build within 1e-4 of the strict one on the distances."""
+    z = load("random_kinds")
+    worst_fast = 0.0
+    for n in range(int(z["count"])):
+        sc = GC.random_kind_case(z, n)
+        h = ctx.create_scene(sc)
+        got = ctx.probe(h, abi.RM_PROBE_SDF, z[f"points_{n}"])
+        end = ctx.probe(h, abi.RM_PROBE_CAST_RAY, z[f"rays_{n}"], float(z["steps"]))
+        assert same_bits(got, O.eval_sdf(sc, z[f"points_{n}"])).all(), f"scene {n}: sdf against the oracle"
+        assert same_bits(end, O.cast_ray(sc, z[f"rays_{n}"], float(z["steps"]))).all(), f"scene {n}: castRay against the oracle"
+        assert rel_diff(z[f"sdf_{n}"], got).max() <= 5e-6, f"scene {n} {type(sc).__name__}: sdf against the reference"
+        e = rel_diff(z[f"end_{n}"], end).max(1)
+        assert e.max() <= 1e-3 and np.percentile(e, 99) <= 2e-4, f"scene {n} {type(sc).__name__}: castRay against the reference {e.max():.2e}"
+        fast = rel_diff(got, ctx.probe(h, abi.RM_PROBE_SDF, z[f"points_{n}"], flags=abi.RM_RENDER_FAST))
+        worst_fast = max(worst_fast, float(fast.max()))
+        assert fast.max() <= 1e-4, f"scene {n} {type(sc).__name__}: fast build sdf {fast.max():.2e}"
+        h.destroy()
+    print(f"\nfast build against the strict one on the distances: worst {worst_fast:.2e}")
 
 
 def test_random_materials_whole_main_strict_build_is_the_oracle_and_tracks_the_reference(ctx):
