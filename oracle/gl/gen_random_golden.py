@@ -3,7 +3,7 @@ on RANDOM scenes of the composition API -- primitive tables of 1..10 spheres / b
 them behind a repeat and / or an unrotated fold row -- at random points and along random rays.  These scenes are
 + - * / sqrt floor abs min max only, so the reference's bits are the bar: the oracle (CPU tests) and the HIP strict build
 (GPU tests) must reproduce them exactly.  Build-container only (needs /root/reference and the kaleido wheel):
-    python oracle/gl/gen_random_golden.py [scenes | images | kinds]
+    python oracle/gl/gen_random_golden.py [scenes | images | kinds | jobs]
 The file holds numbers only: per scene the table rows, the points / rays, and the reference's outputs."""
 from __future__ import annotations
 
@@ -188,10 +188,82 @@ def kinds(per_kind: int = 5):
     print("wrote", dest, dest.stat().st_size, "B")
 
 
+def jobs(n_cases: int = 24):
+    """tests/golden/random_jobs.npz: the reference's unmodified main() (tan routed to the portable tangent) on RANDOM render
+    jobs -- a random table with a random material or one of the reference's example scenes with random parameter values;
+    the three cameras, with and without rotation; depth of field, fog, 0-3 lights (points, soft points, a sun), 1-3
+    bounces, both blend modes, preview (with the focal-plane overlay now and then) and full, 1-3 samples; 64 x 32.
+    Per case the file holds the scene (rows + material, or kind + parameters), the job's settings as JSON (numbers and
+    option names) and the reference's planes."""
+    import dataclasses
+    import json
+
+    import golden_cases as GC
+    from raymarching_engine_amd import job as J
+
+    rng = np.random.default_rng(90210)
+
+    def f32(v):
+        v = np.float32(v)
+        while not survives_translation(v):
+            v = np.nextafter(v, np.float32(0.0))
+        return float(v)
+
+    out = {"count": np.int32(n_cases)}
+    for i in range(n_cases):
+        spec = {}
+        if rng.random() < 0.5:
+            sc = random_table(rng)
+            sc.material = S.Material(diffuse=tuple(f32(v) for v in rng.uniform(0.1, 0.9, 3)), specular=tuple(f32(v) for v in rng.uniform(0.1, 0.9, 3)),
+                                     roughness=f32(rng.uniform(0.05, 0.8)), ior=f32(rng.choice([1.3, 1.5, 2.4, 100.0])), subsurface=f32(rng.choice([11111115.0, 4.0, 0.75])),
+                                     subsurface_color=tuple(f32(v) for v in rng.uniform(0.3, 1.0, 3)), sky_color=tuple(f32(v) for v in rng.uniform(0.3, 1.0, 3)),
+                                     sky_floor=f32(rng.uniform(0.05, 0.4)), sky_scale=f32(rng.uniform(0.5, 2.5)))
+            m = dataclasses.asdict(sc.material)
+            spec["scene"] = {"rows": rows_of(sc).astype(np.float64).tolist(),
+                             "material": [float(x) for k in MAT_FIELDS for x in (m[k] if isinstance(m[k], (tuple, list)) else [m[k]])]}
+            text, pos = sc.glsl(), (0.2, 0.1, -4.0)
+        else:
+            k = int(rng.integers(0, 5))
+            sc, pos = random_kind(rng, k)
+            spec["scene"] = {"kind": k, "params": [float(v) for v in sc.params()]}
+            text = glref.example_scene_text(sc.example)
+        mode = "preview" if rng.random() < 0.25 else "full"
+        lights = []
+        for _ in range(int(rng.integers(0, 4))):
+            if rng.random() < 0.25:
+                lights.append(["sun", [f32(v) for v in rng.uniform(-4, 4, 3)], [f32(v) for v in rng.uniform(0.3, 1, 3)], f32(rng.uniform(1, 4)), 0.0])
+            else:
+                lights.append(["point", [f32(v) for v in rng.uniform(-4, 4, 3)], [f32(v) for v in rng.uniform(0.3, 1, 3)], f32(rng.uniform(1, 4)), f32(rng.choice([0.0, 0.0, 0.3, 1.0]))])
+        cam = ("perspective", "perspective", "orthographic", "panoramic")[rng.integers(0, 4)]
+        kw = dict(counts=[int(c) for c in rng.integers(16, 96, size=rng.integers(1, 4))], render_mode=mode,
+                  position=[f32(pos[j] + rng.uniform(-0.2, 0.2)) for j in range(3)], rotate=bool(rng.random() < 0.5), camera=cam,
+                  fov=f32(rng.uniform(0.8, 1.8)) if cam != "orthographic" else f32(rng.uniform(2.0, 5.0)), lights=lights,
+                  blend_mode="mix" if rng.random() < 0.25 else "additive", fog_density=f32(rng.choice([0.0, 0.0, 0.05, 0.3])),
+                  dof_amount=f32(rng.choice([0.0, 0.0, 0.05])), dof_distance=f32(rng.uniform(1.0, 4.0)),
+                  show_focused_area=bool(mode == "preview" and rng.random() < 0.4), samples=int(rng.integers(1, 4)))
+        spec["job"] = kw
+        out[f"spec_{i}"] = np.array(json.dumps(spec))
+        sc2, schema, noise = GC.random_job_case(out, i)
+        schema = dict(schema); schema["sdfShaderSource"] = text
+        base = glref.uniforms_from_schema(schema, noise[0])
+        draws = [{"randNoise": glref.u_float(*x)} for x in noise]
+        r = glref.run_gl(glref.with_portable_tan(glref.splice(text)), 64, 32, base, draws=draws, read=(0, 1, 2))
+        pl = r["planes"]
+        out[f"color_{i}"] = pl[0]
+        if mode == "full":
+            out[f"normal_dof_{i}"], out[f"albedo_depth_{i}"] = pl[1], pl[2]
+        print(f"job {i}: {type(sc).__name__} {mode} {cam} counts {kw['counts']} lights {len(lights)} samples {kw['samples']} finite {np.isfinite(pl[0]).all(-1).mean():.2f}")
+    dest = ROOT / "tests" / "golden" / "random_jobs.npz"
+    np.savez_compressed(dest, **out)
+    print("wrote", dest, dest.stat().st_size, "B")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "images":
         images()
     elif len(sys.argv) > 1 and sys.argv[1] == "kinds":
         kinds()
+    elif len(sys.argv) > 1 and sys.argv[1] == "jobs":
+        jobs()
     else:
         main()

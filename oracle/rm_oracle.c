@@ -24,6 +24,7 @@
  * decides real pixels.  Two are implemented:
  *   OR_NAN_X86  : max(x,y) = x > y ? x : y, min(x,y) = x < y ? x : y -- what
  *                 SwiftShader does (probed); used against the GL goldens.
+ *                 (With it goes SwiftShader's finite log(0): see o_log.)
  *   OR_NAN_IEEE : maxNum/minNum (the non-NaN operand wins) -- what gfx950's
  *                 v_max_f32/v_min_f32 and desktop GPUs do; used as the checker
  *                 for the HIP path.
@@ -93,7 +94,15 @@ static inline unsigned int PM_F2U(float x) { unsigned int u; memcpy(&u, &x, 4); 
 
 static inline float o_sin(float x) { return o_rounded(or_math_mode == OR_MATH_LIBM ? sinf(x) : pm_sin(x)); }
 static inline float o_cos(float x) { return o_rounded(or_math_mode == OR_MATH_LIBM ? cosf(x) : pm_cos(x)); }
-static inline float o_log(float x) { return o_rounded(or_math_mode == OR_MATH_LIBM ? logf(x) : pm_log(x)); }
+/* log(0): GLSL leaves it undefined.  IEEE (and gfx950's v_log_f32, and desktop GPUs) give -Inf; SwiftShader gives
+ * -127 ln 2 (probed: log(+-0) = log(1e-45) = 0xc2b00f34), a FINITE number -- and the reference's Box-Muller draw takes
+ * log(u1) of a gold_noise value that is exactly 0 about once in a thousand draws (the noise is fract() of a huge product:
+ * coarse dyadic values), so under SwiftShader such a sample continues in a finite direction where IEEE arithmetic makes
+ * the direction NaN.  Like the min / max forms this belongs to the convention the GL goldens were rendered under. */
+static inline float o_log(float x) {
+  if (or_nan_mode == OR_NAN_X86 && x == 0.0f) return -88.02969360351562f;
+  return o_rounded(or_math_mode == OR_MATH_LIBM ? logf(x) : pm_log(x));
+}
 static inline float o_exp(float x) { return o_rounded(or_math_mode == OR_MATH_LIBM ? expf(x) : pm_exp(x)); }
 static inline float o_pow(float x, float y) {
   float v = or_math_mode == OR_MATH_LIBM ? powf(x, y) : pm_pow(x, y);

@@ -996,6 +996,21 @@ def test_reference_example_scenes_with_random_parameter_values(ctx):
     print(f"\nfast build against the strict one on the distances: worst {worst_fast:.2e}")
 
 
+def test_random_jobs_of_the_reference_golden_strict_build_is_the_oracle(ctx):
+    """tests/golden/random_jobs.npz: the 24 random jobs the reference's GLSL was rendered on (every camera, depth of field,
+    fog, lights, bounces, blend modes, preview and full; tables and the example scenes with random parameters).  The
+    oracle is held to the reference's planes on them (tests/test_oracle_golden.py); here both implementations of the
+    strict build give the oracle's bits on every plane, so the kernels stand where the oracle stands."""
+    z = load("random_jobs")
+    for i in range(int(z["count"])):
+        sc, schema, noises = GC.random_job_case(z, i)
+        want = render_oracle(sc, schema, noises, nan_mode=O.NAN_IEEE)
+        for pipeline in (MK, WF):
+            got = render_gpu(ctx, sc, schema, noises, STRICT | pipeline)
+            for k in range(3 if schema["render"]["renderMode"] == "full" else 1):
+                assert same_bits(want[k], got[k]).all(), f"job {i} pipeline {pipeline} plane {k}"
+
+
 def test_random_materials_whole_main_strict_build_is_the_oracle_and_tracks_the_reference(ctx):
     """tests/golden/random_images.npz: the reference's unmodified main() on 12 random tables with random materials, lights
     and cameras (two bounces, 2 samples).  The strict build's three planes are the oracle's bits; against the REFERENCE's
