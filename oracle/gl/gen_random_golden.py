@@ -194,7 +194,7 @@ def jobs(n_cases: int = 24):
     the three cameras, with and without rotation; depth of field, fog, 0-3 lights (points, soft points, a sun), 1-3
     bounces, both blend modes, preview (with the focal-plane overlay now and then) and full, 1-3 samples; 64 x 32.
     Per case the file holds the scene (rows + material, or kind + parameters), the job's settings as JSON (numbers and
-    option names) and the reference's planes."""
+    option names), the reference's planes, and the RGBA8 canvas its present pass (display.frag) makes of them."""
     import dataclasses
     import json
 
@@ -247,11 +247,12 @@ def jobs(n_cases: int = 24):
         schema = dict(schema); schema["sdfShaderSource"] = text
         base = glref.uniforms_from_schema(schema, noise[0])
         draws = [{"randNoise": glref.u_float(*x)} for x in noise]
-        r = glref.run_gl(glref.with_portable_tan(glref.splice(text)), 64, 32, base, draws=draws, read=(0, 1, 2))
+        r = glref.run_gl(glref.with_portable_tan(glref.splice(text)), 64, 32, base, draws=draws, read=(0, 1, 2), display_brightness=1.0 / kw["samples"])
         pl = r["planes"]
         out[f"color_{i}"] = pl[0]
         if mode == "full":
             out[f"normal_dof_{i}"], out[f"albedo_depth_{i}"] = pl[1], pl[2]
+        out[f"rgba8_{i}"] = r["display"]  # the reference's present pass (display.frag) over these planes, brightness 1 / samples
         print(f"job {i}: {type(sc).__name__} {mode} {cam} counts {kw['counts']} lights {len(lights)} samples {kw['samples']} finite {np.isfinite(pl[0]).all(-1).mean():.2f}")
     dest = ROOT / "tests" / "golden" / "random_jobs.npz"
     np.savez_compressed(dest, **out)

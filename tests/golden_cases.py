@@ -227,3 +227,19 @@ def random_job_case(z, i):
     samples, rotate = kw.pop("samples"), kw.pop("rotate")
     schema = J.make_schema(sc, IMG_W, IMG_H, counts=tuple(kw.pop("counts")), position=tuple(kw.pop("position")), rotation=ROT if rotate else None, lights=lights, **kw)
     return sc, schema, halton_pairs(samples)
+
+
+def random_job_present_case(z, i):
+    """Inputs and reference output of the present pass of case i of random_jobs.npz: (colour plane, normal / DoF plane,
+    samples, the reference's RGBA8 canvas, mask of the pixels to compare).  A non-finite colour is presented white by
+    SwiftShader (its log(NaN) is a large finite number, so pow() overflows into the clamp) and black here and on GPUs that
+    flush NaN to 0 in the unorm conversion -- GLSL leaves both undefined; those pixels, and with depth of field every
+    frame that has any (the blur spreads them), are left out of the comparison."""
+    import json
+
+    kw = json.loads(str(z[f"spec_{i}"]))["job"]
+    color = z[f"color_{i}"]
+    ndof = z[f"normal_dof_{i}"] if f"normal_dof_{i}" in z else np.zeros_like(color)
+    finite = np.isfinite(color).all(-1)
+    mask = finite if not ndof[..., 3].any() else np.full(finite.shape, bool(finite.all()))
+    return color, ndof, int(kw["samples"]), z[f"rgba8_{i}"], mask

@@ -564,6 +564,23 @@ def test_present_pass(ctx, name):
     win.destroy()
 
 
+def test_present_pass_on_the_random_jobs_of_the_reference(ctx):
+    """rm_present on the planes of the 24 random jobs the reference's own present pass was run on under software GL: the
+    oracle's bytes exactly, and within one code value of the reference's canvas wherever the colour is finite."""
+    z = load("random_jobs")
+    for i in range(int(z["count"])):
+        color, ndof, n, ref, mask = GC.random_job_present_case(z, i)
+        fb = ctx.create_framebuffer(color.shape[1], color.shape[0])
+        fb.upload(0, color)
+        fb.upload(1, ndof)
+        got = fb.present(n)
+        fb.destroy()
+        assert np.array_equal(got, O.present(color, ndof, n)), f"job {i}: against the oracle"
+        if mask.any():
+            d = np.abs(got.astype(int) - ref.astype(int))[mask]
+            assert d.max() <= 1 and np.mean(d == 0) >= 0.99, f"job {i}: against the reference, max {d.max()}, equal {np.mean(d == 0):.4f}"
+
+
 def test_present_pass_blur_radii_and_wrap(ctx):
     """The LDS-staged blur on a frame whose DoF radius runs from 0 to the 16-pixel cap across the image, borders
     included (REPEAT taps wrap): the same RGBA8 as the oracle's display.frag, byte for byte, and tiles
