@@ -44,6 +44,10 @@ def load(name):
     return np.load(GOLD + name + ".npz")
 
 
+# the randomised tests draw from fixed streams; RM_RANDOM_SEED=n shifts every one of them (tools/r02_fuzz.sh runs other seeds)
+SEED_OFFSET = int(os.environ.get("RM_RANDOM_SEED", "0"))
+
+
 def same_bits(a, b):
     a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
     return (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
@@ -750,7 +754,7 @@ def test_random_present_passes_equal_the_oracle_byte_for_byte(ctx):
     """60 random accumulated frames -- sizes that are no multiple of the 16x16 present tile, radiances over six decades
     with zeros, negative and non-finite values, depth-of-field radii from 0 through the 16-pixel cap in patches and
     ramps, 1..500 samples, with and without the DoF plane -- through rm_present: the oracle's display.frag, byte for byte."""
-    rng = np.random.default_rng(99)
+    rng = np.random.default_rng(99 + SEED_OFFSET)
     for it in range(60):
         w, h = int(rng.integers(5, 150)), int(rng.integers(5, 120))
         n = int(rng.choice([1, 2, 7, 64, 500]))
@@ -808,7 +812,7 @@ def test_random_striped_assemblies_equal_numpy(ctx):
     """rm_assemble_striped_bytes on 80 random layouts -- frame height 1..300, rows of 4..6000 bytes (multiples of 4, so both
     the 16-byte and the 4-byte copy kernels run), 1..9 parts, stripes of 1..16 rows, windows padded to the largest part --
     puts every row where shard.assemble puts it."""
-    rng = np.random.default_rng(808)
+    rng = np.random.default_rng(808 + SEED_OFFSET)
     for it in range(80):
         H, parts, stripe = int(rng.integers(1, 301)), int(rng.integers(1, 10)), int(rng.integers(1, 17))
         row_bytes = 4 * int(rng.integers(1, 1501)) if rng.random() < 0.5 else 16 * int(rng.integers(1, 376))
@@ -940,7 +944,7 @@ def test_random_jobs_strict_build_equals_the_oracle_bit_for_bit(ctx):
     implementations -- rendered by the strict build and by the oracle: every plane bit-identical.  (These jobs found
     the one defect of round 2 that no written case had: the wavefront pipeline left the shadow-ray slots of the lanes
     beyond a tile uninitialised, harmless until a re-allocated workspace handed a march 1e8 as its step budget.)"""
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(77 + SEED_OFFSET)
     hits, distinct = [], []
     for it in range(int(os.environ.get("RM_RANDOM_JOBS", "300"))):
         sc, pos = _random_scene(rng)
@@ -1062,7 +1066,7 @@ def test_random_scenes_probes_equal_the_oracle_bit_for_bit(ctx):
     """200 random scenes (as above): sdf on 300 points -- near, far, on the axes, huge, non-finite --, castRay from 120
     random rays for a random step count, forward-difference normals and the material functions: the strict build's bits
     are the oracle's; and the camera block and the random stream for random uniforms."""
-    rng = np.random.default_rng(31337)
+    rng = np.random.default_rng(31337 + SEED_OFFSET)
     special = np.array([0.0, -0.0, 1.0, -1.0, 1e-20, 1e20, 3e38, np.inf, -np.inf, np.nan], np.float32)
     for it in range(int(os.environ.get("RM_RANDOM_SCENES", "200"))):
         sc, pos = _random_scene(rng)
@@ -1095,7 +1099,7 @@ def test_random_jobs_fast_build_estimates_what_the_strict_build_estimates(ctx):
     stream differs by no more than four times what 32 strict samples with ANOTHER stream differ by (the Monte-Carlo
     yardstick), plus 1 % of the mean, and the two builds agree on which pixels are finite.  (tools/dbg/
     fast_vs_strict_fuzz.py is the study this comes from.)"""
-    rng = np.random.default_rng(2026)
+    rng = np.random.default_rng(2026 + SEED_OFFSET)
     spp = 32
     noise = GC.halton_pairs(2 * spp)
     worst = 0.0
@@ -1127,7 +1131,7 @@ def test_random_jobs_partitions_and_implementations_leave_the_same_bits(ctx):
     the reference; the same frame through the OTHER implementation, and cut up at random -- two row windows, striped
     parts as the ranks of a sharded run hold them, a grid of tiles -- through a random implementation, gives the same
     bits in every plane."""
-    rng = np.random.default_rng(4242)
+    rng = np.random.default_rng(4242 + SEED_OFFSET)
     scale = int(os.environ.get("RM_RANDOM_SCALE", "1"))  # larger frames: the wavefront pipeline's bands, cost-ordered tiles
     for it in range(int(os.environ.get("RM_RANDOM_JOBS2", "150"))):
         sc, pos = _random_scene(rng)
@@ -1202,7 +1206,7 @@ def test_random_jobs_through_the_staged_paths_leave_the_same_bits(ctx):
     """Thirty random jobs -- scene, frame size, tile, a striped window or not, both builds, additive or mix blend, with
     or without the G-buffer, 1..12 samples, batch size 0..8, 1..4 launches in flight, cost order on or off -- through
     rm_render_samples: every plane equals one NO_OVERLAP rm_render_sample call per sample, bit for bit."""
-    rng = np.random.default_rng(2024)
+    rng = np.random.default_rng(2024 + SEED_OFFSET)
     scenes = [("sphere", S.single_sphere(), (0, 0, -3.0)), ("csg_mixed", GC.build_scene("csg_mixed"), (0.3, 0.2, -4.0)), ("bulb", S.Mandelbulb(), (0, 0, -2.5))]
     NO = abi.RM_RENDER_NO_OVERLAP
     try:

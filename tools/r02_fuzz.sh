@@ -9,3 +9,7 @@ RM_RANDOM_JOBS2=20000 timeout 900 python -m pytest tests/test_gpu_parity.py -m g
 for s in 11 12 13; do SEED=$s timeout 300 python3 tools/dbg/abuse_fuzz.py 10000 2>&1 | tail -1; done
 date
 } | tee gpurun_out/r2fuzz/log.txt
+# other streams: every randomised test of the suite under three more seeds, at 10x the default counts
+for seed in 1 2 3; do
+  RM_RANDOM_SEED=$seed RM_RANDOM_JOBS=3000 RM_RANDOM_SCENES=2000 RM_RANDOM_JOBS2=1500 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "random" 2>&1 | tail -2
+done | tee gpurun_out/r2fuzz/log_seeds.txt
