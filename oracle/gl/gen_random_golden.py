@@ -193,8 +193,8 @@ def jobs(n_cases: int = 24):
     jobs -- a random table with a random material or one of the reference's example scenes with random parameter values;
     the three cameras, with and without rotation; depth of field, fog, 0-3 lights (points, soft points, a sun), 1-3
     bounces, both blend modes, preview (with the focal-plane overlay now and then) and full, 1-3 samples; 64 x 32.
-    Per case the file holds the scene (rows + material, or kind + parameters), the job's settings as JSON (numbers and
-    option names), the reference's planes, and the RGBA8 canvas its present pass (display.frag) makes of them."""
+    random_jobs.json holds, per case, the scene (rows + material, or kind + parameters) and the job's settings (numbers and
+    option names); the .npz the reference's planes and the RGBA8 canvas its present pass (display.frag) makes of them."""
     import dataclasses
     import json
 
@@ -209,7 +209,7 @@ def jobs(n_cases: int = 24):
             v = np.nextafter(v, np.float32(0.0))
         return float(v)
 
-    out = {"count": np.int32(n_cases)}
+    out, specs = {"count": np.int32(n_cases)}, []
     for i in range(n_cases):
         spec = {}
         if rng.random() < 0.5:
@@ -242,8 +242,8 @@ def jobs(n_cases: int = 24):
                   dof_amount=f32(rng.choice([0.0, 0.0, 0.05])), dof_distance=f32(rng.uniform(1.0, 4.0)),
                   show_focused_area=bool(mode == "preview" and rng.random() < 0.4), samples=int(rng.integers(1, 4)))
         spec["job"] = kw
-        out[f"spec_{i}"] = np.array(json.dumps(spec))
-        sc2, schema, noise = GC.random_job_case(out, i)
+        specs.append(json.loads(json.dumps(spec)))
+        sc2, schema, noise = GC.random_job_from_spec(specs[-1])
         schema = dict(schema); schema["sdfShaderSource"] = text
         base = glref.uniforms_from_schema(schema, noise[0])
         draws = [{"randNoise": glref.u_float(*x)} for x in noise]
@@ -256,6 +256,7 @@ def jobs(n_cases: int = 24):
         print(f"job {i}: {type(sc).__name__} {mode} {cam} counts {kw['counts']} lights {len(lights)} samples {kw['samples']} finite {np.isfinite(pl[0]).all(-1).mean():.2f}")
     dest = ROOT / "tests" / "golden" / "random_jobs.npz"
     np.savez_compressed(dest, **out)
+    (ROOT / "tests" / "golden" / "random_jobs.json").write_text(json.dumps(specs, separators=(",", ":")))
     print("wrote", dest, dest.stat().st_size, "B")
 
 

@@ -205,13 +205,19 @@ def random_kind_case(z, n):
     return S.KifsBox(iterations=p[0], scale=p[1], angles=tuple(p[2:5]), offset=p[5])
 
 
-def random_job_case(z, i):
-    """Case i of tests/golden/random_jobs.npz: (scene, RenderJobSchema, randNoise pairs)."""
+def random_job_specs():
+    """tests/golden/random_jobs.json: scene and job settings of the cases of random_jobs.npz (numbers and option names)."""
     import json
+    import os
 
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "random_jobs.json")) as f:
+        return json.load(f)
+
+
+def random_job_from_spec(spec):
+    """(scene, RenderJobSchema, randNoise pairs) of one entry of random_jobs.json."""
     from raymarching_engine_amd import scene as S
 
-    spec = json.loads(str(z[f"spec_{i}"]))
     sd, kw = spec["scene"], dict(spec["job"])
     if "rows" in sd:
         sc = table_from_rows(np.array(sd["rows"], np.float32))
@@ -229,15 +235,18 @@ def random_job_case(z, i):
     return sc, schema, halton_pairs(samples)
 
 
+def random_job_case(z, i):
+    """Case i of tests/golden/random_jobs.npz (+ its settings in random_jobs.json): (scene, RenderJobSchema, randNoise pairs)."""
+    return random_job_from_spec(random_job_specs()[i])
+
+
 def random_job_present_case(z, i):
     """Inputs and reference output of the present pass of case i of random_jobs.npz: (colour plane, normal / DoF plane,
     samples, the reference's RGBA8 canvas, mask of the pixels to compare).  A non-finite colour is presented white by
     SwiftShader (its log(NaN) is a large finite number, so pow() overflows into the clamp) and black here and on GPUs that
     flush NaN to 0 in the unorm conversion -- GLSL leaves both undefined; those pixels, and with depth of field every
     frame that has any (the blur spreads them), are left out of the comparison."""
-    import json
-
-    kw = json.loads(str(z[f"spec_{i}"]))["job"]
+    kw = random_job_specs()[i]["job"]
     color = z[f"color_{i}"]
     ndof = z[f"normal_dof_{i}"] if f"normal_dof_{i}" in z else np.zeros_like(color)
     finite = np.isfinite(color).all(-1)
