@@ -62,15 +62,16 @@ def _worker(rank, world, port, width, height, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("height", [64, 52])  # 52 = ragged: the ranks hold different numbers of rows
-def test_two_rank_striped_render_gather_assemble(tmp_path, height):
+# 52 rows = ragged: the ranks hold different numbers of rows; 3 ranks: an odd world, rank 2 holds two stripes of 52 rows' seven
+@pytest.mark.parametrize("world,height", [(2, 64), (2, 52), (3, 52)])
+def test_two_rank_striped_render_gather_assemble(tmp_path, world, height):
     import torch.multiprocessing as mp
 
     import golden_cases as GC
     from oracle import oracle as O
     from raymarching_engine_amd import job as J
 
-    width, world = 48, 2
+    width = 48
     out = str(tmp_path / "frame.npy")
     mp.spawn(_worker, args=(world, _free_port(), width, height, out), nprocs=world, join=True)
     got = np.load(out)
