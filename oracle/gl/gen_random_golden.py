@@ -3,7 +3,7 @@ on RANDOM scenes of the composition API -- primitive tables of 1..10 spheres / b
 them behind a repeat and / or an unrotated fold row -- at random points and along random rays.  These scenes are
 + - * / sqrt floor abs min max only, so the reference's bits are the bar: the oracle (CPU tests) and the HIP strict build
 (GPU tests) must reproduce them exactly.  Build-container only (needs /root/reference and the kaleido wheel):
-    python oracle/gl/gen_random_golden.py [scenes | images | kinds | jobs]
+    python oracle/gl/gen_random_golden.py [scenes | images | kinds | jobs | math]
 The file holds numbers only: per scene the table rows, the points / rays, and the reference's outputs."""
 from __future__ import annotations
 
@@ -253,10 +253,55 @@ def jobs(n_cases: int = 24):
         if mode == "full":
             out[f"normal_dof_{i}"], out[f"albedo_depth_{i}"] = pl[1], pl[2]
         out[f"rgba8_{i}"] = r["display"]  # the reference's present pass (display.frag) over these planes, brightness 1 / samples
+        if i < 8:  # the same job from the UNMODIFIED text: the GL stack's own tan in the random stream and the camera
+            rn = glref.run_gl(glref.splice(text), 64, 32, base, draws=draws, read=(0, 1, 2))["planes"]
+            out[f"color_native_{i}"] = rn[0]
+            if mode == "full":
+                out[f"normal_dof_native_{i}"], out[f"albedo_depth_native_{i}"] = rn[1], rn[2]
         print(f"job {i}: {type(sc).__name__} {mode} {cam} counts {kw['counts']} lights {len(lights)} samples {kw['samples']} finite {np.isfinite(pl[0]).all(-1).mean():.2f}")
     dest = ROOT / "tests" / "golden" / "random_jobs.npz"
     np.savez_compressed(dest, **out)
     (ROOT / "tests" / "golden" / "random_jobs.json").write_text(json.dumps(specs, separators=(",", ":")))
+    print("wrote", dest, dest.stat().st_size, "B")
+
+
+def math(n_side: int = 128):
+    """tests/golden/swiftshader_math.npz: the GL stack's own log2 / log / exp2 / exp / pow / sin / cos / tan / asin / acos /
+    atan / atan(y, x) on 16 384 arguments each -- random over the ranges the shaders use and far beyond, both signs, zeros,
+    denormals, infinities, NaN -- for oracle/ss_math.h, which has to reproduce every one of them bit for bit."""
+    w = h = n_side
+    n = w * h
+    rng = np.random.default_rng(5)
+    edge = np.array([0.0, -0.0, 1.0, -1.0, 2.0, 0.5, 1e-45, 1e-40, 1.1754944e-38, 3e38, -3e38, np.inf, -np.inf, np.nan, 1e-20, 1e20], np.float32)
+    x = (np.exp(rng.uniform(-20, 20, n)) * rng.choice([1.0, 1.0, 1.0, -1.0], n)).astype(np.float32)
+    x[:2048] = rng.uniform(0, 2, 2048); x[2048:4096] = rng.uniform(0.9, 1.1, 2048); x[4096:4096 + 16] = edge
+    y = rng.uniform(-8, 8, n).astype(np.float32)
+    y[:512] = rng.uniform(-160, 160, 512); y[4096:4096 + 16] = edge[::-1]; y[5000:5016] = edge; x[5000:5016] = edge[::-1]
+    ang = rng.uniform(-10, 10, n).astype(np.float32); ang[:4096] = rng.uniform(-900, 900, 4096); ang[4096:4096 + 16] = edge
+    a = rng.uniform(-1, 1, n).astype(np.float32); a[:256] = rng.uniform(-1.3, 1.3, 256); a[4096:4096 + 16] = edge
+    # arguments at which the restated sine of x or of x + pi/2 leaves [-1, 1] (the stack clamps its cosine, not its sine), tiny
+    # angles (rodrigues' cos(theta) near 1), and arguments where x / 2pi is exactly k + 1/2 (the reduction's rounding)
+    from oracle import oracle as O
+    dense = np.linspace(-10, 10, 4000001).astype(np.float32)
+    over = dense[(np.abs(O.ss_math("sin", dense)) > 1) | (np.abs(O.ss_math("sin", dense + np.float32(1.57079632))) > 1)][:64]
+    ang[8192:8192 + len(over)] = over
+    ang[8300:8556] = (10.0 ** rng.uniform(-7, -2, 256) * rng.choice([1.0, -1.0], 256)).astype(np.float32)
+    c = np.float32(1.59154943e-1)
+    ties = [v for k in range(-140, 140) for v in [np.float32(np.float32(k + 0.5) / c)] if np.float32(v * c) == np.float32(k + 0.5)]
+    ang[8600:8600 + len(ties)] = ties
+    pts = np.stack([x, y, ang, a], 1).astype(np.float32)
+    text = S.single_sphere().glsl()
+
+    def run(expr):
+        frag = glref.splice(text, "void main(void){ " + FETCH + " fragColor = " + expr + "; }")
+        return glref.run_gl(frag, w, h, {}, init_prev0=pts.reshape(h, w, 4))["planes"][0].reshape(-1, 4)
+
+    r1 = run("vec4(log2(t.x), log(t.x), exp2(t.y), exp(t.y))")
+    r2 = run("vec4(sin(t.z), cos(t.z), pow(t.x, t.y), acos(t.w))")
+    r3 = run("vec4(atan(t.y, t.x), atan(t.y), asin(t.w), tan(t.z))")
+    dest = ROOT / "tests" / "golden" / "swiftshader_math.npz"
+    np.savez_compressed(dest, x=x, y=y, angle=ang, a=a, log2=r1[:, 0], log=r1[:, 1], exp2=r1[:, 2], exp=r1[:, 3], sin=r2[:, 0], cos=r2[:, 1],
+                        pow=r2[:, 2], acos=r2[:, 3], atan2=r3[:, 0], atan=r3[:, 1], asin=r3[:, 2], tan=r3[:, 3])
     print("wrote", dest, dest.stat().st_size, "B")
 
 
@@ -267,5 +312,7 @@ if __name__ == "__main__":
         kinds()
     elif len(sys.argv) > 1 and sys.argv[1] == "jobs":
         jobs()
+    elif len(sys.argv) > 1 and sys.argv[1] == "math":
+        math()
     else:
         main()

@@ -13,15 +13,15 @@ import raymarching_engine_amd.abi as abi
 _HERE = Path(__file__).resolve().parent
 _BUILD = _HERE / "_build"
 NAN_X86, NAN_IEEE = 0, 1
-TAN_LIBM, TAN_PORTABLE = 0, 1
-MATH_LIBM, MATH_PORTABLE = 0, 1
+TAN_LIBM, TAN_PORTABLE, TAN_SWIFTSHADER = 0, 1, 2
+MATH_LIBM, MATH_PORTABLE, MATH_SWIFTSHADER = 0, 1, 2
 
 _libs = {}
 
 
 def build(force: bool = False) -> None:
     """gcc the restatement into oracle/_build (both the plain and the flop-counting variant)."""
-    srcs = [_HERE / "rm_oracle.c", _HERE / "pm_math.h"]
+    srcs = [_HERE / "rm_oracle.c", _HERE / "pm_math.h", _HERE / "ss_math.h"]
     outs = [_BUILD / "librm_oracle.so", _BUILD / "librm_oracle_count.so"]
     if not force and all(o.exists() and all(o.stat().st_mtime >= src.stat().st_mtime for src in srcs) for o in outs):
         return
@@ -55,6 +55,7 @@ def _lib(count: bool = False):
         lib.or_set_tan_mode.argtypes = [C.c_int]
         lib.or_set_math_mode.argtypes = [C.c_int]
         lib.or_set_math_round_bits.argtypes = [C.c_int]
+        lib.or_ss_math.argtypes = [C.c_int, fp, fp, C.c_int, fp]
         _libs[key] = lib
     return _libs[key]
 
@@ -69,15 +70,28 @@ def set_nan_mode(mode: int, count: bool = False) -> None:
 
 
 def set_tan_mode(mode: int) -> None:
-    """TAN_PORTABLE (default) or TAN_LIBM, for both library variants."""
+    """TAN_PORTABLE (default), TAN_LIBM or TAN_SWIFTSHADER (the GL stack's own tan: oracle/ss_math.h), for both library variants."""
     _lib(False).or_set_tan_mode(mode)
     _lib(True).or_set_tan_mode(mode)
 
 
 def set_math_mode(mode: int) -> None:
-    """MATH_PORTABLE (default: oracle/pm_math.h, the same text the HIP kernels compile) or MATH_LIBM, for both variants."""
+    """MATH_PORTABLE (default: oracle/pm_math.h, the same text the HIP kernels compile), MATH_LIBM, or MATH_SWIFTSHADER
+    (oracle/ss_math.h: the GL stack the goldens were rendered with), for both variants."""
     _lib(False).or_set_math_mode(mode)
     _lib(True).or_set_math_mode(mode)
+
+
+SS_FUNCTIONS = ("log2", "log", "exp2", "exp", "sin", "cos", "pow", "acos", "atan2", "atan", "asin", "tan")
+
+
+def ss_math(name: str, a: np.ndarray, b: np.ndarray = None) -> np.ndarray:
+    """One function of oracle/ss_math.h (the GL stack's transcendentals, restated) on an array."""
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32) if b is not None else None
+    out = np.empty_like(a)
+    _lib().or_ss_math(SS_FUNCTIONS.index(name), _fp(a), _fp(b) if b is not None else None, a.size, _fp(out))
+    return out
 
 
 def set_math_round_bits(bits: int) -> None:

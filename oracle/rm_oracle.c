@@ -61,7 +61,7 @@ void or_set_nan_mode(int mode) { or_nan_mode = mode; }
  * [0, 870]) that SwiftShader, this file and the HIP kernel evaluate to the
  * same bits; the whole-image goldens are rendered from the reference's text
  * with its tan() routed to the same sequence (oracle/gl/glref.py). */
-enum { OR_TAN_LIBM = 0, OR_TAN_PORTABLE = 1 };
+enum { OR_TAN_LIBM = 0, OR_TAN_PORTABLE = 1, OR_TAN_SWIFTSHADER = 2 }; /* 2: sin / cos of oracle/ss_math.h -- the GL stack's OWN tan, for goldens rendered from the unmodified text */
 static int or_tan_mode = OR_TAN_PORTABLE;
 void or_set_tan_mode(int mode) { or_tan_mode = mode; }
 
@@ -70,8 +70,11 @@ void or_set_tan_mode(int mode) { or_tan_mode = mode; }
  * OR_MATH_PORTABLE (default): oracle/pm_math.h -- double-precision series from IEEE basic operations, correctly rounded
  * to float for all but ~1e-5 of the arguments, the same text the HIP kernels compile: bit-identical on both sides.
  * OR_MATH_LIBM: the C library's float functions, as this file used them until round 2 (kept to show that nothing hangs
- * on the choice: tests/test_oracle_golden.py renders the goldens' cases both ways). */
-enum { OR_MATH_LIBM = 0, OR_MATH_PORTABLE = 1 };
+ * on the choice: tests/test_oracle_golden.py renders the goldens' cases both ways).
+ * OR_MATH_SWIFTSHADER: oracle/ss_math.h -- the approximations of the GL stack the goldens were rendered with, bit for bit
+ * (pinned by tests/golden/swiftshader_math.npz).  With it "the reference under software GL" has ONE value on every scene,
+ * transcendental or not, and the goldens are compared without a tolerance for the functions' last bits. */
+enum { OR_MATH_LIBM = 0, OR_MATH_PORTABLE = 1, OR_MATH_SWIFTSHADER = 2 };
 static int or_math_mode = OR_MATH_PORTABLE;
 void or_set_math_mode(int mode) { or_math_mode = mode; }
 /* Sensitivity probe for the tests (0 = off, the default): round every sin / cos / log / exp / pow / acos result to `bits`
@@ -91,28 +94,44 @@ static inline unsigned long long PM_D2U(double x) { unsigned long long u; memcpy
 static inline double PM_U2D(unsigned long long u) { double x; memcpy(&x, &u, 8); return x; }
 static inline unsigned int PM_F2U(float x) { unsigned int u; memcpy(&u, &x, 4); return u; }
 #include "pm_math.h"
+#include "ss_math.h"
 
-static inline float o_sin(float x) { return o_rounded(or_math_mode == OR_MATH_LIBM ? sinf(x) : pm_sin(x)); }
-static inline float o_cos(float x) { return o_rounded(or_math_mode == OR_MATH_LIBM ? cosf(x) : pm_cos(x)); }
+static inline float o_sin(float x) { return or_math_mode == OR_MATH_SWIFTSHADER ? ss_sin(x) : o_rounded(or_math_mode == OR_MATH_LIBM ? sinf(x) : pm_sin(x)); }
+static inline float o_cos(float x) { return or_math_mode == OR_MATH_SWIFTSHADER ? ss_cos(x) : o_rounded(or_math_mode == OR_MATH_LIBM ? cosf(x) : pm_cos(x)); }
 /* log(0): GLSL leaves it undefined.  IEEE (and gfx950's v_log_f32, and desktop GPUs) give -Inf; SwiftShader gives
  * -127 ln 2 (probed: log(+-0) = log(1e-45) = 0xc2b00f34), a FINITE number -- and the reference's Box-Muller draw takes
  * log(u1) of a gold_noise value that is exactly 0 about once in a thousand draws (the noise is fract() of a huge product:
  * coarse dyadic values), so under SwiftShader such a sample continues in a finite direction where IEEE arithmetic makes
  * the direction NaN.  Like the min / max forms this belongs to the convention the GL goldens were rendered under. */
 static inline float o_log(float x) {
+  if (or_math_mode == OR_MATH_SWIFTSHADER) return ss_log(x);
   if (or_nan_mode == OR_NAN_X86 && x == 0.0f) return -88.02969360351562f;
   return o_rounded(or_math_mode == OR_MATH_LIBM ? logf(x) : pm_log(x));
 }
-static inline float o_exp(float x) { return o_rounded(or_math_mode == OR_MATH_LIBM ? expf(x) : pm_exp(x)); }
+static inline float o_exp(float x) { return or_math_mode == OR_MATH_SWIFTSHADER ? ss_exp(x) : o_rounded(or_math_mode == OR_MATH_LIBM ? expf(x) : pm_exp(x)); }
 static inline float o_pow(float x, float y) {
+  if (or_math_mode == OR_MATH_SWIFTSHADER) return ss_pow(x, y); /* also for y = 2: exp2(2 log2 x), not a product (misc_schlick golden) */
   float v = or_math_mode == OR_MATH_LIBM ? powf(x, y) : pm_pow(x, y);
   return y == 2.0f ? v : o_rounded(v); /* pow(x, 2.0) is a product in every implementation met so far */
 }
-static inline float o_acos(float x) { return o_rounded(or_math_mode == OR_MATH_LIBM ? acosf(x) : pm_acos(x)); }
-static inline float o_atan2(float y, float x) { return or_math_mode == OR_MATH_LIBM ? atan2f(y, x) : pm_atan2(y, x); }
+static inline float o_acos(float x) { return or_math_mode == OR_MATH_SWIFTSHADER ? ss_acos(x) : o_rounded(or_math_mode == OR_MATH_LIBM ? acosf(x) : pm_acos(x)); }
+static inline float o_atan2(float y, float x) {
+  return or_math_mode == OR_MATH_SWIFTSHADER ? ss_atan2(y, x) : or_math_mode == OR_MATH_LIBM ? atan2f(y, x) : pm_atan2(y, x);
+}
+/* the functions of ss_math.h on arrays, for the test that pins them: which = 0 log2, 1 log, 2 exp2, 3 exp, 4 sin, 5 cos,
+ * 6 pow(a, b), 7 acos, 8 atan(a, b), 9 atan, 10 asin, 11 tan */
+void or_ss_math(int which, const float* a, const float* b, int n, float* out) {
+  for (int i = 0; i < n; i++) {
+    const float x = a[i], y = b ? b[i] : 0.0f;
+    out[i] = which == 0 ? ss_log2(x) : which == 1 ? ss_log(x) : which == 2 ? ss_exp2(x) : which == 3 ? ss_exp(x) : which == 4 ? ss_sin(x)
+           : which == 5 ? ss_cos(x) : which == 6 ? ss_pow(x, y) : which == 7 ? ss_acos(x) : which == 8 ? ss_atan2(x, y) : which == 9 ? ss_atan(x)
+           : which == 10 ? ss_asin(x) : ss_tan(x);
+  }
+}
 
 static float or_tan(float x) {
   if (or_tan_mode == OR_TAN_LIBM) return tanf(x);
+  if (or_tan_mode == OR_TAN_SWIFTSHADER) return ss_tan(x);
   float k = floorf(x * 0.636619772f + 0.5f);
   float r = x - k * 1.5703125f;
   r = r - k * 4.83751296997e-4f;
@@ -156,7 +175,16 @@ static inline float gl_min(float x, float y) {
   return x < y ? x : y;
 }
 static inline float gl_clamp(float x, float lo, float hi) { return gl_min(gl_max(x, lo), hi); }
-static inline float gl_fract(float x) { FL(2); return x - floorf(x); }
+/* fract(x) = x - floor(x) (GLSL); SwiftShader clamps the difference below 1 with an x86 min -- min(x - floor(x), 0x3F7FFFFF),
+ * second operand for a NaN -- so fract(+-Inf) = fract(NaN) = 0.99999994 there (probed) where IEEE arithmetic gives NaN, and a
+ * tiny negative x gives 0.99999994 instead of 1.  Part of the GL comparison convention like the min / max forms; it shows
+ * once the random stream runs on the GL stack's own tan, whose cosine can be exactly 0. */
+static inline float gl_fract(float x) {
+  FL(2);
+  const float r = x - floorf(x);
+  if (or_nan_mode == OR_NAN_X86) return r < 0.99999994f ? r : 0.99999994f;
+  return r;
+}
 static inline float gl_mod(float x, float y) { FL(4); return x - y * floorf(x / y); }
 static inline float gl_sign(float x) { FL(1); return (float)((x > 0.0f) - (x < 0.0f)); }
 /* the specification writes x*(1-a)+y*a; implementations evaluate the lerp form
@@ -877,6 +905,13 @@ void or_present(const float* color, const float* normal_dof, int W, int H, int s
       for (int k = 0; k < 3; k++) {
         float v = gl_pow(acc[k] / count * brightness, 1.0f / 2.2f);
         v = v != v ? 0.0f : (v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v)); /* UNORM8 conversion of the canvas */
+        if (or_math_mode == OR_MATH_SWIFTSHADER) {
+          /* the GL stack the goldens come from goes through 16 bits: c16 = trunc(v * 65535), c8 = (c16 - (c16 >> 8) + 128) >> 8
+           * (fitted to its canvases: e.g. v * 255 = 201.5017 is presented as 201) */
+          const int c16 = (int)(v * 65535.0f);
+          o[k] = (uint8_t)((c16 - (c16 >> 8) + 128) >> 8);
+          continue;
+        }
         o[k] = (uint8_t)floorf(v * 255.0f + 0.5f);
       }
       o[3] = 255; /* pow(1.0, 1/2.2) */
