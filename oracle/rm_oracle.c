@@ -12,7 +12,8 @@
  * Every function cites the lines it follows.  GLSL built-ins are restated
  * from the GLSL ES 3.00 specification.
  *
- * Parity pin: the reference has no tests or golden vectors of its own
+ * Parity pin (bit for bit on every golden: tests/test_reference_bits.py, with the GL stack's own transcendentals restated
+ * in oracle/ss_math.h): the reference has no tests or golden vectors of its own
  * (SURVEY.md section 4).  This restatement is pinned against outputs of the
  * reference's own GLSL run in this container under software GL (SwiftShader
  * in Kaleido's HeadlessChrome 88; oracle/gl/), committed as tests/golden/
