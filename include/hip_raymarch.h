@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RM_ABI_VERSION 3 /* 3: rm_ctx_set_sample_batch, rm_buffer_* (additions only) */
+#define RM_ABI_VERSION 4 /* 3: rm_ctx_set_sample_batch, rm_buffer_*; 4: rm_ctx_set_gl_stack (additions only) */
 
 #define RM_MAX_BOUNCES 10 /* raymarchingStepCountsArray[10], raymarcher.frag:31 */
 #define RM_MAX_LIGHTS 10  /* lightPositions[10],             raymarcher.frag:37-39 */
@@ -243,6 +243,15 @@ int rm_ctx_set_cost_order(rm_ctx* ctx, int on);
  * eps 2^-25 +0.7 %, 2^-24 +2.9 %, 2^-23 +4.7 %, 2^-21 +6.8 %, 1e-5 +14 %, for
  * 1 %, 3 %, 8 %, 12 % and 28 % less time (tools/eps_study.py). */
 int rm_ctx_set_retire_eps(rm_ctx* ctx, float eps);
+/* Parity mode of the strict build: on != 0 makes everything this context does WITHOUT RM_RENDER_FAST -- rm_render_sample(s),
+ * rm_probe*, rm_present* -- compute in the arithmetic of the GL stack the reference's golden images were rendered under
+ * (SwiftShader as shipped in HeadlessChrome 88): its sin / cos / log / exp / pow / acos / atan as IEEE operation sequences,
+ * min / max as x86 computes them, fract clamped below 1, the canvas's unorm conversion through 16 bits.  GLSL leaves all of
+ * these to the implementation (raymarcher.frag has one value only together with a GL stack); with this switch the GPU
+ * reproduces tests/golden/ -- distances, marches, whole main() images, the present pass -- bit for bit.  The pixel kernel
+ * only (the wavefront pipeline is not built in this arithmetic); slower than the default strict arithmetic's IEEE-derived
+ * shortcuts allow.  Off by default. */
+int rm_ctx_set_gl_stack(rm_ctx* ctx, int on);
 /* Diagnostics of the wavefront march, filled only by builds compiled with
  * -DRM_WF_STATS (zeros otherwise): out16[8*shadow + 4*pass2 + {0,1,2}] =
  * rays marched, lane-steps, wave-steps since the last reset. */

@@ -95,6 +95,9 @@ static inline unsigned long long PM_D2U(double x) { unsigned long long u; memcpy
 static inline double PM_U2D(unsigned long long u) { double x; memcpy(&x, &u, 8); return x; }
 static inline unsigned int PM_F2U(float x) { unsigned int u; memcpy(&u, &x, 4); return u; }
 #include "pm_math.h"
+#define SS_FN static inline
+#define SS_F2U(x) PM_F2U(x)
+static inline float SS_U2F(unsigned int u) { float x; memcpy(&x, &u, 4); return x; }
 #include "ss_math.h"
 
 static inline float o_sin(float x) { return or_math_mode == OR_MATH_SWIFTSHADER ? ss_sin(x) : o_rounded(or_math_mode == OR_MATH_LIBM ? sinf(x) : pm_sin(x)); }

@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-RM_ABI_VERSION = 3
+RM_ABI_VERSION = 4
 RM_MAX_BOUNCES = 10
 RM_MAX_LIGHTS = 10
 RM_MAX_PRIMS = 256

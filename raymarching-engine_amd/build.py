@@ -23,6 +23,7 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno
 UNITS = {
     "rm_strict": ["-ffp-contract=off"],
     "rm_fast": ["-ffp-contract=off"],
+    "rm_glstack": ["-ffp-contract=off"],
     "rm_api": [],
 }
 
@@ -55,7 +56,7 @@ def build_native(force: bool = False, verbose: bool = False, extra=(), out: Path
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
 
-    with ThreadPoolExecutor(max_workers=3) as ex:
+    with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(compile_unit, UNITS))
     cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", str(lib)] + [str(obj / f"{n}.o") for n in UNITS]
     if verbose:

@@ -19,12 +19,22 @@
 
 #define RM_SP_MAX 8
 
+// rm_glstack.hip: the parity build in the GL stack's arithmetic, behind C entry points (its types live in another namespace)
+extern "C" {
+hipError_t rm_gl_launch_pixels(const void* kparams, hipStream_t stream);
+hipError_t rm_gl_launch_probe(const void* probe_params, hipStream_t stream);
+hipError_t rm_gl_launch_camera_rng(const RmUniforms* u, int W, int H, int what, int count, float* out, hipStream_t stream);
+hipError_t rm_gl_launch_present(const float4* color, const float4* normal_dof, int W, int H, float brightness, uchar4* out, hipStream_t stream);
+hipError_t rm_gl_launch_present_rows(const float4* color, long long pixels, float brightness, uchar4* out, hipStream_t stream);
+}
+
 struct rm_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float retire_eps = 0.0f;  // opt-in (rm_ctx_set_retire_eps): any tolerance brightens lit pixels, see the header
+  bool gl_stack = false;    // rm_ctx_set_gl_stack: strict-flag work runs in the GL stack's arithmetic (rm_glstack.hip)
   int cu_count = 256;
   // persistent-grid sizes in workgroups per CU, from a sweep on the headline frame (tools/sweep.sh):
   // the Mandelbulb passes want FEW waves (every wave ends in a tail of a few long rays), the table march wants all slots
@@ -248,6 +258,13 @@ int rm_ctx_set_retire_eps(rm_ctx* ctx, float eps) {
   if (!ctx) return RM_ERR_INVALID;
   if (!(eps >= 0.0f && eps <= 1e-3f)) return fail(ctx, RM_ERR_INVALID, "rm_ctx_set_retire_eps: eps must be in [0, 1e-3]");
   ctx->retire_eps = eps;
+  return RM_OK;
+}
+
+int rm_ctx_set_gl_stack(rm_ctx* ctx, int on) {
+  if (!ctx) return RM_ERR_INVALID;
+  if (ctx->sp_ready) RM_HIP(ctx, hipStreamSynchronize(ctx->stream));  // samples in flight finish in the arithmetic they started in
+  ctx->gl_stack = on != 0;
   return RM_OK;
 }
 
@@ -872,7 +889,7 @@ static hipError_t launch_pixels_ordered(rm_ctx* ctx, const KParams& P, int flags
   rm::pixel_grid(P, &gx, &gy);
   const long long tiles = (long long)gx * gy;
   if (!ctx->lpt_enabled || tiles < 512 || tiles > (1ll << 22))  // small jobs end on launch latency, not on a tail
-    return fast ? rm::launch_pixels_fast(P, stream) : rm::launch_pixels_strict(P, stream);
+    return fast ? rm::launch_pixels_fast(P, stream) : ctx->gl_stack ? rm_gl_launch_pixels(&P, stream) : rm::launch_pixels_strict(P, stream);
   rm_ctx::Lpt& L = ctx->lpt[slot];
   hipError_t e;
   const long long key[8] = {P.W, P.H, ((long long)P.tx << 32) | (unsigned int)P.ty, ((long long)P.tw << 32) | (unsigned int)P.th,
@@ -911,7 +928,7 @@ static hipError_t launch_pixels_ordered(rm_ctx* ctx, const KParams& P, int flags
     else if ((e = hipMemsetAsync(L.cost, 0, sizeof(unsigned int) * (size_t)tiles, stream)) != hipSuccess) return e;
     L.have_cost = true;
     L.launches = (unsigned long long)tiles;  // what sort_slot_costs has to sort
-    return fast ? rm::launch_pixels_fast(Q, stream) : rm::launch_pixels_strict(Q, stream);
+    return fast ? rm::launch_pixels_fast(Q, stream) : ctx->gl_stack ? rm_gl_launch_pixels(&Q, stream) : rm::launch_pixels_strict(Q, stream);
   }
   if (!ctx->lpt_stream) {
     if ((e = hipStreamCreateWithFlags(&ctx->lpt_stream, hipStreamNonBlocking)) != hipSuccess) return e;
@@ -938,7 +955,7 @@ static hipError_t launch_pixels_ordered(rm_ctx* ctx, const KParams& P, int flags
   }
   Q.block_cost = cost_cur;
   (void)prev;
-  if ((e = fast ? rm::launch_pixels_fast(Q, stream) : rm::launch_pixels_strict(Q, stream)) != hipSuccess) return e;
+  if ((e = fast ? rm::launch_pixels_fast(Q, stream) : ctx->gl_stack ? rm_gl_launch_pixels(&Q, stream) : rm::launch_pixels_strict(Q, stream)) != hipSuccess) return e;
   if ((e = hipEventRecord(L.rendered[cur], stream)) != hipSuccess) return e;
   if ((e = hipStreamWaitEvent(ctx->lpt_stream, L.rendered[cur], 0)) != hipSuccess) return e;
   if ((e = rm::launch_order(cost_cur, order_cur, (int)tiles, ctx->lpt_stream)) != hipSuccess) return e;  // sorts and zeroes the costs
@@ -948,7 +965,8 @@ static hipError_t launch_pixels_ordered(rm_ctx* ctx, const KParams& P, int flags
 }
 
 static hipError_t launch(rm_ctx* ctx, const KParams& P, int flags) {
-  const bool wavefront = (flags & RM_RENDER_WAVEFRONT) ? true : (flags & RM_RENDER_MEGAKERNEL) ? false : prefer_wavefront(P, flags);
+  const bool gl = ctx->gl_stack && !(flags & RM_RENDER_FAST);  // the GL-stack arithmetic exists as the pixel kernel only
+  const bool wavefront = gl ? false : (flags & RM_RENDER_WAVEFRONT) ? true : (flags & RM_RENDER_MEGAKERNEL) ? false : prefer_wavefront(P, flags);
   if (wavefront) return launch_wavefront(ctx, P, flags);
   // full mode with at least one bounce: the kernel's only use of the planes is the final blend, which can be split off
   if (ctx->samples_in_flight > 1 && !(flags & RM_RENDER_NO_OVERLAP) && P.u.renderMode == 0 && P.u.reflections > 0.0f)
@@ -975,7 +993,8 @@ int rm_render_samples(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms*
   if (empty) return RM_OK;
   RM_HIP(ctx, hipSetDevice(ctx->device));
   // Samples the pixel kernel can stage (the conditions of launch()) go out in batches: one launch per batch.
-  const bool wavefront = (flags & RM_RENDER_WAVEFRONT) ? true : (flags & RM_RENDER_MEGAKERNEL) ? false : prefer_wavefront(P, flags);
+  const bool gl = ctx->gl_stack && !(flags & RM_RENDER_FAST);  // the GL-stack arithmetic exists as the pixel kernel only
+  const bool wavefront = gl ? false : (flags & RM_RENDER_WAVEFRONT) ? true : (flags & RM_RENDER_MEGAKERNEL) ? false : prefer_wavefront(P, flags);
   const bool stageable = !wavefront && !(flags & RM_RENDER_NO_OVERLAP) && P.u.renderMode == 0 && P.u.reflections > 0.0f;
   int per_launch = 1;
   if (stageable && ctx->sample_batch != 1) {
@@ -1055,8 +1074,8 @@ int rm_present_device(rm_ctx* ctx, const void* color, const void* normal_dof, in
   if (!ctx || !color || !out_rgba8_device) return fail(ctx, RM_ERR_INVALID, "rm_present_device: NULL argument");
   if (width < 1 || height < 1 || samples < 1) return fail(ctx, RM_ERR_INVALID, "rm_present_device: width, height and samples must be >= 1");
   RM_HIP(ctx, hipSetDevice(ctx->device));
-  RM_HIP(ctx, rm::launch_present(static_cast<const float4*>(color), static_cast<const float4*>(normal_dof), width, height, 1.0f / (float)samples,
-                                 static_cast<uchar4*>(out_rgba8_device), hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream));
+  RM_HIP(ctx, (ctx->gl_stack ? rm_gl_launch_present : rm::launch_present)(static_cast<const float4*>(color), static_cast<const float4*>(normal_dof), width, height,
+                                 1.0f / (float)samples, static_cast<uchar4*>(out_rgba8_device), hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream));
   return RM_OK;
 }
 
@@ -1065,7 +1084,7 @@ int rm_present_rows(rm_ctx* ctx, rm_fb* fb, int samples, void* out_rgba8_device,
   if (fb->ctx != ctx) return fail(ctx, RM_ERR_INVALID, "rm_present_rows: framebuffer belongs to another context");
   if (samples < 1) return fail(ctx, RM_ERR_INVALID, "rm_present_rows: samples must be >= 1");
   RM_HIP(ctx, hipSetDevice(ctx->device));
-  RM_HIP(ctx, rm::launch_present_rows(fb->plane[0], (long long)fb->width * (long long)fb->row_count, 1.0f / (float)samples,
+  RM_HIP(ctx, (ctx->gl_stack ? rm_gl_launch_present_rows : rm::launch_present_rows)(fb->plane[0], (long long)fb->width * (long long)fb->row_count, 1.0f / (float)samples,
                                       static_cast<uchar4*>(out_rgba8_device), hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream));
   return RM_OK;
 }
@@ -1113,7 +1132,7 @@ int rm_probe(rm_ctx* ctx, rm_scene* scene, int what, const float* in, int n, flo
   if (e == hipSuccess) e = hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
     ProbeParams P{scene->dev, d_in, d_out, n, what, param, (flags & RM_RENDER_FAST) ? ctx->retire_eps : 0.0f};
-    e = (flags & RM_RENDER_FAST) ? rm::launch_probe_fast(P, ctx->stream) : rm::launch_probe_strict(P, ctx->stream);
+    e = (flags & RM_RENDER_FAST) ? rm::launch_probe_fast(P, ctx->stream) : ctx->gl_stack ? rm_gl_launch_probe(&P, ctx->stream) : rm::launch_probe_strict(P, ctx->stream);
   }
   if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1129,7 +1148,7 @@ static int camera_rng(rm_ctx* ctx, const RmUniforms* u, int width, int height, i
   float* d_out = nullptr;
   const size_t bytes = sizeof(float) * (size_t)width * (size_t)height * (size_t)(what == 1 ? count : 8);
   RM_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&d_out), bytes));
-  hipError_t e = rm::launch_camera_rng(*u, width, height, what, count, d_out, ctx->stream);
+  hipError_t e = ctx->gl_stack ? rm_gl_launch_camera_rng(u, width, height, what, count, d_out, ctx->stream) : rm::launch_camera_rng(*u, width, height, what, count, d_out, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   (void)hipFree(d_out);

@@ -48,8 +48,40 @@ RM_DEV v3 vabs(v3 a) { return V(fabsf(a.x), fabsf(a.y), fabsf(a.z)); }
 
 #include "rm_pm_math.hpp"
 
+// RM_GL_STACK (rm_glstack.hip only): the parity build in the arithmetic of the GL stack the reference's golden images were
+// rendered under -- its twelve transcendental functions (rm_ss_math.hpp) and its conventions: min / max as x86 computes
+// them, fract clamped below 1 -- and WITHOUT the exact shortcuts of this file and rm_kernels.inc that were derived for
+// IEEE semantics (log 0 = -Inf, min / max dropping a NaN).  With it the kernels reproduce tests/golden/ bit for bit.
+#ifndef RM_GL_STACK
+#define RM_GL_STACK 0
+#endif
+#if RM_GL_STACK
+#define SS_FN RM_DEV
+#define SS_F2U(x) __float_as_uint(x)
+#define SS_U2F(u) __uint_as_float(u)
+#include "rm_ss_math.hpp"
+#endif
+
 // ---- math policies --------------------------------------------------------------
 
+#if RM_GL_STACK
+struct PM {
+  static constexpr bool fast = false;
+  static RM_DEV float fma(float a, float b, float c) { return a * b + c; }
+  static RM_DEV float rcp(float x) { return 1.0f / x; }
+  static RM_DEV float div(float a, float b) { return a / b; }
+  static RM_DEV float sqrt(float x) { return sqrtf(x); }
+  static RM_DEV float pow(float x, float y) { return ss_pow(x, y); }  // exp2(y log2 |x|), also for y = 2
+  static RM_DEV float log(float x) { return ss_log(x); }
+  static RM_DEV float exp(float x) { return ss_exp(x); }
+  static RM_DEV float sin(float x) { return ss_sin(x); }
+  static RM_DEV float cos(float x) { return ss_cos(x); }
+  static RM_DEV float acos(float x) { return ss_acos(x); }
+  static RM_DEV float atan2(float y, float x) { return ss_atan2(y, x); }
+  static RM_DEV void sincos(float x, float& s, float& c) { s = ss_sin(x); c = ss_cos(x); }
+  static RM_DEV void pow_pair(float r, float n, float& r_nm1, float& r_n) { r_nm1 = pow(r, n - 1.0f); r_n = pow(r, n); }
+};
+#else
 struct PM {
   static constexpr bool fast = false;
   static RM_DEV float fma(float a, float b, float c) { return a * b + c; }  // two roundings, like GLSL/C
@@ -69,6 +101,7 @@ struct PM {
   static RM_DEV void sincos(float x, float& s, float& c) { pm_sincos(x, &s, &c); }  // one reduction, the bits of sin and cos
   static RM_DEV void pow_pair(float r, float n, float& r_nm1, float& r_n) { r_nm1 = pow(r, n - 1.0f); r_n = pow(r, n); }
 };
+#endif
 
 struct FM {
   static constexpr bool fast = true;
@@ -112,9 +145,27 @@ RM_DEV v3 cross(v3 a, v3 b) { return V(a.y * b.z - b.y * a.z, a.z * b.x - b.z * 
 template <class M> RM_DEV v3 reflect(v3 i, v3 n) { return i - n * (2.0f * dot<M>(n, i)); }
 
 // min/max are IEEE minNum/maxNum = v_min_f32/v_max_f32 (NaN convention OR_NAN_IEEE)
+#if RM_GL_STACK  // x > y ? x : y and x < y ? x : y: the second operand when either is a NaN (OR_NAN_X86)
+RM_DEV float gmax(float x, float y) { return x > y ? x : y; }
+RM_DEV float gmin(float x, float y) { return x < y ? x : y; }
+RM_DEV float gfract(float x) { const float r = x - floorf(x); return r < 0.99999994f ? r : 0.99999994f; }
+#else
 RM_DEV float gmax(float x, float y) { return fmaxf(x, y); }
 RM_DEV float gmin(float x, float y) { return fminf(x, y); }
+RM_DEV float gfract(float x) { return x - floorf(x); }
+#endif
 RM_DEV float gclamp(float x, float lo, float hi) { return gmin(gmax(x, lo), hi); }
+// UNORM8 conversion of the canvas (display.frag's output): NaN and negatives to 0, round to nearest; the GL stack of the
+// goldens goes through 16 bits (oracle/rm_oracle.c or_present)
+RM_DEV unsigned char unorm8(float g) {
+  g = g != g ? 0.0f : (g < 0.0f ? 0.0f : (g > 1.0f ? 1.0f : g));
+#if RM_GL_STACK
+  const int c16 = (int)(g * 65535.0f);
+  return (unsigned char)((c16 - (c16 >> 8) + 128) >> 8);
+#else
+  return (unsigned char)floorf(g * 255.0f + 0.5f);
+#endif
+}
 template <class M> RM_DEV float gmod(float x, float y) { return x - y * floorf(M::div(x, y)); }
 RM_DEV float gsign(float x) { return (float)((x > 0.0f) - (x < 0.0f)); }
 template <class M> RM_DEV float gmix(float x, float y, float a) { return M::fma(a, y - x, x); }  // x + a*(y-x)
@@ -183,25 +234,21 @@ RM_DEV Rng rng_init(float tcx, float tcy, float n0, float n1) {
 
 // :46-49
 RM_DEV float gold_noise(const Rng& r, float seed) {
-  float t = rm_tan(r.dist * seed) * r.x1000;
-  return t - floorf(t);
+  return gfract(rm_tan(r.dist * seed) * r.x1000);
 }
 
 // :91-94
 RM_DEV float uniform_sample(Rng& r) {
   r.seed += 0.131223f;
-  float a = r.n0 + r.seed;
-  return gold_noise(r, a - floorf(a));
+  return gold_noise(r, gfract(r.n0 + r.seed));
 }
 
 // :80-89 (PI is 3.141592 there)
 RM_DEV void box_muller(Rng& r, float& ox, float& oy) {
   r.seed += 0.123123213f;
-  float a = r.n0 + r.seed;
-  const float u1 = gold_noise(r, a - floorf(a));
+  const float u1 = gold_noise(r, gfract(r.n0 + r.seed));
   r.seed += 0.123123213f;
-  float b = r.n1 + r.seed;
-  const float u2 = gold_noise(r, b - floorf(b));
+  const float u2 = gold_noise(r, gfract(r.n1 + r.seed));
   const float two_pi_u2 = 2.0f * 3.141592f * u2;
   const float rad = sqrtf(-2.0f * PM::log(u1));
   float sn, cs;
@@ -234,14 +281,14 @@ RM_DEV void rng_skip_sphere(Rng& r) {
 // reproduced (+0 is returned): the callers add the product to, or subtract it from, a value, where the sign of a zero
 // addend shows only if that value is itself -0 -- `zero_sign_matters` says so, and then the full sample is taken.
 RM_DEV v3 sphere_sample_times(Rng& r, float scale, bool zero_sign_matters) {
-  if (scale != 0.0f || scale != scale) return sphere_sample(r) * scale;
+  if (RM_GL_STACK || scale != 0.0f || scale != scale) return sphere_sample(r) * scale;  // (the shortcut below is IEEE's: log 0 = -Inf)
   const float seed0 = r.seed;
   const float s1 = seed0 + 0.123123213f;   // first pair: log argument
   const float s2 = s1 + 0.123123213f;      //             angle (value not needed)
   const float s3 = s2 + 0.123123213f;      // second pair: log argument
   const float s4 = s3 + 0.123123213f;
   const float a = r.n0 + s1, b = r.n0 + s3;
-  const float u1a = gold_noise(r, a - floorf(a)), u1b = gold_noise(r, b - floorf(b));
+  const float u1a = gold_noise(r, gfract(a)), u1b = gold_noise(r, gfract(b));
   r.seed = s4;
   // (a value of exactly 1 -- fract() of a tiny negative number -- makes a radius 0, two of them a 0/0: also the slow way)
   const bool ordinary = u1a > 0.0f && u1a < 1.0f && u1b > 0.0f && u1b < 1.0f;
@@ -757,7 +804,7 @@ RM_DEV v3 scene_emission(const DevScene& sc, v3 p) {
 // :148-150.  Without fog (lambda = +0, the default) -log(1 - x) / 0 is +Inf, or NaN when 1 - x rounds to 1
 // (-0 / 0): the same values without the logarithm and the division.
 RM_DEV float inv_exp_dist(float x, float lambda) {
-  if (__float_as_uint(lambda) == 0u) return (1.0f - x == 1.0f) ? __builtin_nanf("") : __builtin_inff();
+  if (!RM_GL_STACK && __float_as_uint(lambda) == 0u) return (1.0f - x == 1.0f) ? __builtin_nanf("") : __builtin_inff();
   return -PM::log(1.0f - x) / lambda;
 }
 

@@ -1,25 +1,7 @@
-/* Test infrastructure (part of the oracle, see rm_oracle.c): the transcendental functions of the GL implementation the
- * goldens of tests/golden/ were rendered with -- SwiftShader's shader core as shipped in the HeadlessChrome 88 of the
- * kaleido wheel (Google, Apache-2.0; not part of /root/reference and not in this repository).  GLSL leaves the precision
- * of sin / cos / log / exp / pow / asin / acos / atan to the implementation, so "what the reference computes" on a
- * transcendental scene is defined only together with its GL stack; this file restates that stack's published
- * approximations as sequences of IEEE fp32 operations:
- *   log2   exponent extraction + a (2,3) rational in the mantissa        (the sign bit is ignored: log2(-x) = log2(x),
- *          log2(+-0) = -127, log2(NaN) ~ 128.6; +Inf stays +Inf)
- *   exp2   2^i by exponent construction (i = round(x - 0.5)) times a degree-5 polynomial in x - i, x clamped to [-127, 129]
- *   log x = log2 x * ln 2,  exp x = exp2(x * log2 e),  pow(x, y) = exp2(y * log2 x)
- *   sin    x / 2pi reduced to [-0.5, 0.5] by round-to-nearest; sine-cosine pair of a quarter of the angle (degree 7 / 6),
- *          two angle doublings, the result normalised by s^2 + c^2      (no range reduction beyond fp32: 8e-5 off at |x| ~ 900)
- *   cos x = sin(x + pi/2) clamped to [-1, 1],  tan x = sin x / cos x
- *   asin   Abramowitz & Stegun 4.4.45 (4 coefficients, 7e-5),  acos x = pi/2 - asin x
- *   atan   A&S 4.4.49 on [0, 1] (1 / |x| above 1); atan(y, x) by octant reduction
- * Pinned: tests/golden/swiftshader_math.npz holds that GL stack's own outputs on ~10^5 arguments per function (random over
- * the ranges the shaders use, edge values, both signs; oracle/gl/gen_random_golden.py math), and every function here
- * reproduces every one of them bit for bit (tests/test_oracle_golden.py).  Used by the oracle's OR_MATH_SWIFTSHADER mode
- * only, i.e. when the oracle is compared with the GL goldens; the HIP kernels and their checker (OR_MATH_PORTABLE) never
- * see it -- except in the library's GL-stack arithmetic (rm_ctx_set_gl_stack), a parity mode of the strict build that
- * compiles the same text (csrc/rm_ss_math.hpp, identical from the marker line on) so that the GPU reproduces the goldens
- * themselves.  The includer defines SS_FN (function qualifiers), SS_F2U / SS_U2F (bit casts). */
+// The GL stack's transcendentals (SwiftShader's shader core as shipped in HeadlessChrome 88), restated: see oracle/ss_math.h
+// for what, why and how it is pinned (tests/golden/swiftshader_math.npz).  Compiled only into the GL-stack arithmetic of the
+// parity build (rm_glstack.hip, rm_ctx_set_gl_stack): with it the kernels reproduce the reference's golden images -- rendered
+// under that stack -- bit for bit on the GPU.  Same text as oracle/ss_math.h from the marker line on (tests/test_host_cpu.py).
 /* ---- shared text: identical in oracle/ss_math.h and raymarching-engine_amd/csrc/rm_ss_math.hpp from here on ---- */
 SS_FN float ss_log2(float x) {
   const unsigned int xi = SS_F2U(x);

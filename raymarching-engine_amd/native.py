@@ -27,7 +27,7 @@ LIB_PATH = Path(os.environ.get("RM_LIB") or Path(__file__).resolve().parent / "l
 EXPORTS = [
     "rm_abi_version", "rm_material_default", "rm_ctx_create", "rm_ctx_destroy", "rm_last_error", "rm_ctx_set_stream",
     "rm_ctx_set_retire_eps", "rm_ctx_set_samples_in_flight", "rm_ctx_set_cost_order", "rm_debug_counters", "rm_device_memory", "rm_sync", "rm_scene_create", "rm_scene_destroy", "rm_fb_create", "rm_fb_create_striped", "rm_fb_rows", "rm_fb_width", "rm_fb_height", "rm_fb_wrap", "rm_fb_clear", "rm_fb_destroy",
-    "rm_fb_download", "rm_fb_upload", "rm_fb_device_ptr", "rm_buffer_create", "rm_buffer_destroy", "rm_buffer_download", "rm_buffer_upload", "rm_render_sample", "rm_render_samples", "rm_ctx_set_sample_batch", "rm_render_timed",
+    "rm_fb_download", "rm_fb_upload", "rm_fb_device_ptr", "rm_buffer_create", "rm_buffer_destroy", "rm_buffer_download", "rm_buffer_upload", "rm_render_sample", "rm_render_samples", "rm_ctx_set_sample_batch", "rm_ctx_set_gl_stack", "rm_render_timed",
     "rm_probe", "rm_probe_camera", "rm_probe_rng", "rm_assemble_striped", "rm_assemble_striped_bytes", "rm_present", "rm_present_planes", "rm_present_device", "rm_present_rows",
 ]
 
@@ -89,6 +89,7 @@ def load_library():
         "rm_ctx_set_retire_eps": (ip, [vp, C.c_float]),
         "rm_ctx_set_samples_in_flight": (ip, [vp, C.c_int]),
         "rm_ctx_set_sample_batch": (ip, [vp, C.c_int]),
+        "rm_ctx_set_gl_stack": (ip, [vp, C.c_int]),
         "rm_device_memory": (ip, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
         "rm_buffer_create": (ip, [vp, C.c_size_t, C.POINTER(C.c_void_p)]),
         "rm_buffer_destroy": (ip, [vp, vp]),
@@ -210,6 +211,11 @@ class Context:
     def buffer(self, nbytes: int) -> "DeviceBuffer":
         """Zero-filled raw device memory (for rm_present_rows / rm_assemble_striped_bytes on hosts without torch)."""
         return DeviceBuffer(self, nbytes)
+
+    def set_gl_stack(self, on: bool):
+        """Parity mode: strict-flag renders, probes and presents in the arithmetic of the GL stack the goldens were
+        rendered under (include/hip_raymarch.h rm_ctx_set_gl_stack)."""
+        self._check(self.lib.rm_ctx_set_gl_stack(self.h, 1 if on else 0))
 
     def set_sample_batch(self, n: int):
         """Samples per launch of render_samples (0 = automatic, 1 = one launch per sample, up to 8); same bits."""

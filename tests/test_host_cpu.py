@@ -229,6 +229,20 @@ def test_portable_math_text_is_shared_by_oracle_and_kernels():
     assert "PM_FN" in a and "__device__" in b[:b.index(mark)]
 
 
+
+def test_gl_stack_math_text_is_shared_by_oracle_and_kernels():
+    """The GL stack's transcendentals exist twice as well -- oracle/ss_math.h (the oracle's OR_MATH_SWIFTSHADER mode, pinned
+    by tests/golden/swiftshader_math.npz) and csrc/rm_ss_math.hpp (the kernels' rm_ctx_set_gl_stack arithmetic): the same
+    text from the marker line on."""
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    a = (root / "oracle" / "ss_math.h").read_text()
+    b = (root / "raymarching-engine_amd" / "csrc" / "rm_ss_math.hpp").read_text()
+    mark = "/* ---- shared text:"
+    assert mark in a and mark in b
+    assert a[a.index(mark):] == b[b.index(mark):] and "SS_FN float ss_atan2" in a
+
 def test_portable_math_is_correctly_rounded_on_samples():
     """oracle/pm_math.h against numpy's double-precision functions rounded to float: equal on every sample of the
     ranges the path uses (the double series are good to ~1e-14; a float disagrees only when the true value is
