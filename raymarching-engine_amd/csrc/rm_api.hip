@@ -26,6 +26,7 @@ hipError_t rm_gl_launch_probe(const void* probe_params, hipStream_t stream);
 hipError_t rm_gl_launch_camera_rng(const RmUniforms* u, int W, int H, int what, int count, float* out, hipStream_t stream);
 hipError_t rm_gl_launch_present(const float4* color, const float4* normal_dof, int W, int H, float brightness, uchar4* out, hipStream_t stream);
 hipError_t rm_gl_launch_present_rows(const float4* color, long long pixels, float brightness, uchar4* out, hipStream_t stream);
+hipError_t rm_gl_set_native_tan(int on, hipStream_t stream);
 }
 
 struct rm_ctx {
@@ -264,6 +265,16 @@ int rm_ctx_set_retire_eps(rm_ctx* ctx, float eps) {
 int rm_ctx_set_gl_stack(rm_ctx* ctx, int on) {
   if (!ctx) return RM_ERR_INVALID;
   if (ctx->sp_ready) RM_HIP(ctx, hipStreamSynchronize(ctx->stream));  // samples in flight finish in the arithmetic they started in
+  if (on != 0 && on != 1 && on != 2) return fail(ctx, RM_ERR_INVALID, "rm_ctx_set_gl_stack: 0 (off), 1 (on) or 2 (on, with the stack's own tan)");
+  RM_HIP(ctx, hipSetDevice(ctx->device));
+  RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  static int native_tan = 0;  // the kernels read one device-wide switch: the stack's own tan is a property of the process
+  if (on != 0 && (on == 2) != (native_tan != 0)) {
+    int v = on == 2;
+    RM_HIP(ctx, rm_gl_set_native_tan(v, ctx->stream));
+    RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    native_tan = v;
+  }
   ctx->gl_stack = on != 0;
   return RM_OK;
 }

@@ -191,7 +191,15 @@ RM_DEV v3 mat_rotate(const float* m, v3 v) {
 // ---- the portable tangent (oracle/rm_oracle.c or_tan, oracle/gl/glref.py):
 // one fixed sequence of IEEE operations (no FMA: the TU is contract-off; plain
 // '/' and sqrtf are correctly rounded), the same bits in every build.
+#if RM_GL_STACK
+// rm_ctx_set_gl_stack(ctx, 2): the GL stack's OWN tan (sin / cos of rm_ss_math.hpp) instead of the portable tangent -- what the
+// reference's unmodified text computes under that stack (random stream and camera); process-wide, set by rm_gl_set_native_tan
+static __device__ int g_native_tan = 0;
+#endif
 RM_DEV float rm_tan(float x) {
+#if RM_GL_STACK
+  if (g_native_tan) return ss_tan(x);
+#endif
   float k = floorf(x * 0.636619772f + 0.5f);
   float r = x - k * 1.5703125f;
   r = r - k * 4.83751296997e-4f;

@@ -215,7 +215,7 @@ class Context:
     def set_gl_stack(self, on: bool):
         """Parity mode: strict-flag renders, probes and presents in the arithmetic of the GL stack the goldens were
         rendered under (include/hip_raymarch.h rm_ctx_set_gl_stack)."""
-        self._check(self.lib.rm_ctx_set_gl_stack(self.h, 1 if on else 0))
+        self._check(self.lib.rm_ctx_set_gl_stack(self.h, int(on)))  # True / 1: on; 2: on, with the stack's own tan
 
     def set_sample_batch(self, n: int):
         """Samples per launch of render_samples (0 = automatic, 1 = one launch per sample, up to 8); same bits."""

@@ -136,3 +136,28 @@ def test_random_jobs_equal_the_oracle_in_the_gl_stacks_arithmetic(glctx):
                 assert eq.all(), f"job {it}: {type(sc).__name__} {w}x{h} {mode} counts {counts} camera {cam} lights {len(lights)}: plane {k}, {int((~eq).sum())} values differ"
     finally:
         O.set_math_mode(O.MATH_PORTABLE)
+
+
+def test_the_unmodified_shader_text_bit_for_bit(glctx):
+    """rm_ctx_set_gl_stack(ctx, 2): the GL stack's own tan() in the random stream and the camera, i.e. the reference's text as
+    it stands.  The two 256-sample goldens (sphere 32 x 16, Mandelbulb with its light 64 x 32: every pixel's sum) and the 8
+    random jobs rendered from the unmodified text: every value."""
+    glctx.set_gl_stack(2)
+    try:
+        for name, scene, kw in (("stat_sphere_full_native_tan", "sphere", dict(render_mode="full", counts=(64, 32), exposure=1.0)),
+                                ("stat_mandelbulb_full_native_tan", "mandelbulb", dict(render_mode="full", counts=(64,), position=(0, 0, -2.5), lights=GC.LIGHT, exposure=1.0))):
+            z = load(name)
+            h, w = z["color_sum"].shape[:2]
+            sc = GC.build_scene(scene)
+            got = render_gpu(glctx, sc, J.make_schema(sc, w, h, **kw), GC.halton_pairs(int(z["samples"])), STRICT | MK)
+            assert same_bits(got[0], z["color_sum"]).all(), name
+        z = load("random_jobs")
+        for i in range(int(z["count"])):
+            if f"color_native_{i}" not in z:
+                continue
+            sc, schema, noises = GC.random_job_case(z, i)
+            got = render_gpu(glctx, sc, schema, noises, STRICT | MK)
+            for k, name in enumerate(("color", "normal_dof", "albedo_depth") if schema["render"]["renderMode"] == "full" else ("color",)):
+                assert same_bits(got[k], z[f"{name}_native_{i}"]).all(), f"job {i} {name}"
+    finally:
+        glctx.set_gl_stack(1)
