@@ -3,7 +3,7 @@ on RANDOM scenes of the composition API -- primitive tables of 1..10 spheres / b
 them behind a repeat and / or an unrotated fold row -- at random points and along random rays.  These scenes are
 + - * / sqrt floor abs min max only, so the reference's bits are the bar: the oracle (CPU tests) and the HIP strict build
 (GPU tests) must reproduce them exactly.  Build-container only (needs /root/reference and the kaleido wheel):
-    python oracle/gl/gen_random_golden.py [scenes | images | kinds | jobs | math]
+    python oracle/gl/gen_random_golden.py [scenes | images | kinds | jobs | math | configs]
 The file holds numbers only: per scene the table rows, the points / rays, and the reference's outputs."""
 from __future__ import annotations
 
@@ -305,6 +305,27 @@ def math(n_side: int = 128):
     print("wrote", dest, dest.stat().st_size, "B")
 
 
+def configs():
+    """tests/golden/config_<name>.npz: BASELINE.json's configurations -- the headline C3b (Mandelbulb, full, [256], the point
+    light), C3a, C2, C4 and C5 with their own scenes, step counts, lights and cameras (tests/golden_cases.py CONFIGS) -- through
+    the reference's main() under software GL at 256 x 128 / 128 x 128, tan routed to the portable tangent."""
+    import golden_cases as GC
+
+    for name in GC.CONFIGS:
+        sc, schema, noise = GC.config_case(name)
+        w, h = schema["render"]["width"], schema["render"]["height"]
+        schema = dict(schema); schema["sdfShaderSource"] = sc.glsl()
+        base = glref.uniforms_from_schema(schema, noise[0])
+        draws = [{"randNoise": glref.u_float(*x)} for x in noise]
+        pl = glref.run_gl(glref.with_portable_tan(glref.splice(sc.glsl())), w, h, base, draws=draws, read=(0, 1, 2))["planes"]
+        arrays = dict(color=pl[0])
+        if schema["render"]["renderMode"] == "full":
+            arrays.update(normal_dof=pl[1], albedo_depth=pl[2])
+        dest = ROOT / "tests" / "golden" / f"config_{name}.npz"
+        np.savez_compressed(dest, **arrays)
+        print("wrote", dest, dest.stat().st_size, "B, finite", float(np.isfinite(pl[0]).all(-1).mean()))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "images":
         images()
@@ -314,5 +335,7 @@ if __name__ == "__main__":
         jobs()
     elif len(sys.argv) > 1 and sys.argv[1] == "math":
         math()
+    elif len(sys.argv) > 1 and sys.argv[1] == "configs":
+        configs()
     else:
         main()

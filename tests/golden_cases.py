@@ -252,3 +252,21 @@ def random_job_present_case(z, i):
     finite = np.isfinite(color).all(-1)
     mask = finite if not ndof[..., 3].any() else np.full(finite.shape, bool(finite.all()))
     return color, ndof, int(kw["samples"]), z[f"rgba8_{i}"], mask
+
+
+# BASELINE.json's configurations (bench.py WORKLOADS) with their own scenes, step counts, lights and cameras,
+# at a power-of-two size the reference's GLSL renders in seconds under software GL: name -> (scene, W, H, samples, make_schema kwargs)
+CONFIGS = {
+    "c2_preview": ("sphere", 256, 128, 1, dict(counts=(128,), render_mode="preview", position=(0.0, 0.0, -3.0))),
+    "c2_full_light": ("sphere", 256, 128, 1, dict(counts=(128,), render_mode="full", position=(0.0, 0.0, -3.0), lights=LIGHT)),
+    "c3a": ("mandelbulb", 256, 128, 1, dict(counts=(256,), render_mode="preview", position=(0.0, 0.0, -2.5))),
+    "c3b": ("mandelbulb", 256, 128, 2, dict(counts=(256,), render_mode="full", position=(0.0, 0.0, -2.5), lights=LIGHT)),
+    "c4": ("csg64", 128, 128, 1, dict(counts=(128,), render_mode="full", position=(0.0, 0.0, -5.0), lights=LIGHT)),
+    "c5": ("csg64", 128, 128, 1, dict(counts=(128, 64, 64), render_mode="full", position=(0.0, 0.0, -5.0), lights=SOFT_LIGHT)),
+}
+
+
+def config_case(name):
+    scene, w, h, samples, kw = CONFIGS[name]
+    sc = build_scene(scene)
+    return sc, J.make_schema(sc, w, h, **kw), halton_pairs(samples)

@@ -68,6 +68,15 @@ def test_whole_main_image_is_the_reference_bit_for_bit(glctx, case):
     _planes_equal(z, render_gpu(glctx, sc, schema, z["rand_noise"], STRICT | MK), full="normal_dof" in z)
 
 
+@pytest.mark.parametrize("name", list(GC.CONFIGS))
+def test_baseline_configurations_are_the_reference_bit_for_bit(glctx, name):
+    """BASELINE.json's configurations (the headline C3b, C3a, C2, C4, C5: their own scenes, step counts, lights, cameras) at
+    256 x 128 / 128 x 128: the GPU reproduces what the reference's main() rendered of them under its GL stack."""
+    sc, schema, noises = GC.config_case(name)
+    z = load("config_" + name)
+    _planes_equal(z, render_gpu(glctx, sc, schema, noises, STRICT | MK), full="normal_dof" in z)
+
+
 def test_random_goldens_are_reproduced_bit_for_bit(glctx):
     """Random tables (sdf, castRay), the example scenes with random parameters, random-material images, random jobs."""
     z = load("random_tables")

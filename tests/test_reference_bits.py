@@ -161,3 +161,14 @@ def test_helper_functions_bit_for_bit():
     r = load("rng_32x32")
     u = J.uniforms_from_schema(J.make_schema(GC.build_scene("sphere"), 32, 32), tuple(r["rand_noise"]))
     assert same_bits(O.rng(u, 32, 32, 4), r["uniform4"]).all()
+
+
+@pytest.mark.parametrize("name", list(GC.CONFIGS))
+def test_baseline_configurations_bit_for_bit(name):
+    """BASELINE.json's configurations with their own scenes, step counts, lights and cameras -- the headline C3b (Mandelbulb,
+    full mode, 256 steps, the point light; 2 samples), C3a, C2 (preview and lit), C4 (CSG-64, 128 steps), C5 (three bounces,
+    the soft light) -- through the reference's main() at 256 x 128 / 128 x 128: every value of every plane."""
+    sc, schema, noises = GC.config_case(name)
+    z = load("config_" + name)
+    r = schema["render"]
+    _planes_equal(z, _render(sc, schema, noises, r["width"], r["height"], threads=min(8, O.host_cores())), full="normal_dof" in z)
