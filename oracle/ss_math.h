@@ -15,7 +15,7 @@
  *   atan   A&S 4.4.49 on [0, 1] (1 / |x| above 1); atan(y, x) by octant reduction
  * Pinned: tests/golden/swiftshader_math.npz holds that GL stack's own outputs on ~10^5 arguments per function (random over
  * the ranges the shaders use, edge values, both signs; oracle/gl/gen_random_golden.py math), and every function here
- * reproduces every one of them bit for bit (tests/test_oracle_golden.py).  Used by the oracle's OR_MATH_SWIFTSHADER mode
+ * reproduces every one of them bit for bit (tests/test_reference_bits.py).  Used by the oracle's OR_MATH_SWIFTSHADER mode
  * only, i.e. when the oracle is compared with the GL goldens; the HIP kernels and their checker (OR_MATH_PORTABLE) never
  * see it -- except in the library's GL-stack arithmetic (rm_ctx_set_gl_stack), a parity mode of the strict build that
  * compiles the same text (csrc/rm_ss_math.hpp, identical from the marker line on) so that the GPU reproduces the goldens
