@@ -3,7 +3,7 @@ on RANDOM scenes of the composition API -- primitive tables of 1..10 spheres / b
 them behind a repeat and / or an unrotated fold row -- at random points and along random rays.  These scenes are
 + - * / sqrt floor abs min max only, so the reference's bits are the bar: the oracle (CPU tests) and the HIP strict build
 (GPU tests) must reproduce them exactly.  Build-container only (needs /root/reference and the kaleido wheel):
-    python oracle/gl/gen_random_golden.py [scenes | images | kinds | jobs | math | configs]
+    python oracle/gl/gen_random_golden.py [scenes | images | kinds | jobs | math | configs | fullsize]
 The file holds numbers only: per scene the table rows, the points / rays, and the reference's outputs."""
 from __future__ import annotations
 
@@ -326,6 +326,32 @@ def configs():
         print("wrote", dest, dest.stat().st_size, "B, finite", float(np.isfinite(pl[0]).all(-1).mean()))
 
 
+def fullsize():
+    """tests/golden/rows_<name>.npz: BASELINE configurations at megapixel size -- the headline C3b at 2048 x 1024, C4 at
+    1024 x 1024 -- through the reference's main() under software GL (portable tangent); the planes stay here, the fixture is a
+    CRC-32 per row and plane (tests/golden_cases.py row_checksums) plus the share of finite pixels per row."""
+    import time
+
+    import golden_cases as GC
+
+    for name in GC.ROW_CHECKSUM_CASES:
+        sc, schema, noise = GC.row_checksum_case(name)
+        w, h = schema["render"]["width"], schema["render"]["height"]
+        schema = dict(schema); schema["sdfShaderSource"] = sc.glsl()
+        base = glref.uniforms_from_schema(schema, noise[0])
+        t0 = time.time()
+        out = {}
+        for k, plane in enumerate(("color", "normal_dof", "albedo_depth")):  # one plane per run: the read-back travels as text
+            pl = glref.run_gl(glref.with_portable_tan(glref.splice(sc.glsl())), w, h, base, draws=[{"randNoise": glref.u_float(*noise[0])}], read=(k,))["planes"][k]
+            out[plane] = GC.row_checksums(pl)
+            if k == 0:
+                out["finite_share"] = np.isfinite(pl).all(-1).mean(1).astype(np.float32)
+            del pl
+        dest = ROOT / "tests" / "golden" / f"rows_{name}.npz"
+        np.savez_compressed(dest, **out)
+        print("wrote", dest, dest.stat().st_size, "B in", round(time.time() - t0), "s")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "images":
         images()
@@ -337,5 +363,7 @@ if __name__ == "__main__":
         math()
     elif len(sys.argv) > 1 and sys.argv[1] == "configs":
         configs()
+    elif len(sys.argv) > 1 and sys.argv[1] == "fullsize":
+        fullsize()
     else:
         main()

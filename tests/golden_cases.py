@@ -270,3 +270,28 @@ def config_case(name):
     scene, w, h, samples, kw = CONFIGS[name]
     sc = build_scene(scene)
     return sc, J.make_schema(sc, w, h, **kw), halton_pairs(samples)
+
+
+# BASELINE configurations at megapixel size: the reference's planes are too large to keep, so the fixtures hold a CRC-32 per
+# image row and plane (tests/golden/rows_<name>.npz): name -> (scene, W, H, make_schema kwargs); 1 sample, randNoise (0.5, 1/3)
+ROW_CHECKSUM_CASES = {
+    "c3b_2048x1024": ("mandelbulb", 2048, 1024, dict(counts=(256,), render_mode="full", position=(0.0, 0.0, -2.5), lights=LIGHT)),
+    "c4_1024x1024": ("csg64", 1024, 1024, dict(counts=(128,), render_mode="full", position=(0.0, 0.0, -5.0), lights=LIGHT)),
+}
+
+
+def row_checksums(plane: np.ndarray) -> np.ndarray:
+    """CRC-32 of every row of a float32 plane [H, W, 4]; every NaN counts as one value (its payload is the platform's)."""
+    import zlib
+
+    a = np.ascontiguousarray(plane, np.float32).copy()
+    a[np.isnan(a)] = np.float32(np.nan)
+    bits = a.view(np.uint32)
+    bits[np.isnan(a)] = 0x7FC00000
+    return np.array([zlib.crc32(bits[y].tobytes()) for y in range(bits.shape[0])], np.uint32)
+
+
+def row_checksum_case(name):
+    scene, w, h, kw = ROW_CHECKSUM_CASES[name]
+    sc = build_scene(scene)
+    return sc, J.make_schema(sc, w, h, **kw), [(0.5, 1.0 / 3.0)]

@@ -77,6 +77,18 @@ def test_baseline_configurations_are_the_reference_bit_for_bit(glctx, name):
     _planes_equal(z, render_gpu(glctx, sc, schema, noises, STRICT | MK), full="normal_dof" in z)
 
 
+@pytest.mark.parametrize("name", list(GC.ROW_CHECKSUM_CASES))
+def test_megapixel_configurations_every_row_checksum(glctx, name):
+    """The headline C3b at 2048 x 1024 and C4 at 1024 x 1024 as the reference's GLSL rendered them under software GL (a
+    CRC-32 per row and plane in the fixture): the GPU reproduces every row of the three planes."""
+    sc, schema, noises = GC.row_checksum_case(name)
+    z = load("rows_" + name)
+    got = render_gpu(glctx, sc, schema, noises, STRICT | MK)
+    for k, plane in enumerate(("color", "normal_dof", "albedo_depth")):
+        crc = GC.row_checksums(got[k])
+        assert (crc == z[plane]).all(), f"{plane}: {int((crc != z[plane]).sum())} of {len(crc)} rows differ"
+
+
 def test_random_goldens_are_reproduced_bit_for_bit(glctx):
     """Random tables (sdf, castRay), the example scenes with random parameters, random-material images, random jobs."""
     z = load("random_tables")

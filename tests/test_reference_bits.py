@@ -172,3 +172,19 @@ def test_baseline_configurations_bit_for_bit(name):
     z = load("config_" + name)
     r = schema["render"]
     _planes_equal(z, _render(sc, schema, noises, r["width"], r["height"], threads=min(8, O.host_cores())), full="normal_dof" in z)
+
+
+@pytest.mark.parametrize("name", list(GC.ROW_CHECKSUM_CASES))
+def test_megapixel_configurations_row_checksums(name):
+    """BASELINE configurations at megapixel size -- the headline C3b (Mandelbulb, full, 256 steps, the light) at 2048 x 1024
+    and C4 (CSG-64, 128 steps) at 1024 x 1024 -- rendered by the reference's GLSL under software GL; the fixture holds a
+    CRC-32 per image row.  Here: 24 rows spread over the frame (the colour plane; the GPU test checks every row of every
+    plane), each row's checksum."""
+    sc, schema, noises = GC.row_checksum_case(name)
+    z = load("rows_" + name)
+    w, h = schema["render"]["width"], schema["render"]["height"]
+    rows = list(range(h // 48, h, h // 24))
+    _, got = O.render_rows(sc, J.uniforms_from_schema(schema, noises[0]), w, h, rows, threads=min(8, O.host_cores()), **X86)
+    crc = GC.row_checksums(got)
+    assert (crc == z["color"][rows]).all(), f"rows {[r for r, a, b in zip(rows, crc, z['color'][rows]) if a != b]} differ"
+    assert 0.0 < float(z["finite_share"].mean()) <= 1.0
