@@ -335,6 +335,8 @@ def fullsize():
     import golden_cases as GC
 
     for name in GC.ROW_CHECKSUM_CASES:
+        if len(sys.argv) > 2 and name not in sys.argv[2:]:
+            continue
         sc, schema, noise = GC.row_checksum_case(name)
         w, h = schema["render"]["width"], schema["render"]["height"]
         schema = dict(schema); schema["sdfShaderSource"] = sc.glsl()
