@@ -277,6 +277,9 @@ def config_case(name):
 ROW_CHECKSUM_CASES = {
     "c3b_2048x1024": ("mandelbulb", 2048, 1024, dict(counts=(256,), render_mode="full", position=(0.0, 0.0, -2.5), lights=LIGHT)),
     "c4_1024x1024": ("csg64", 1024, 1024, dict(counts=(128,), render_mode="full", position=(0.0, 0.0, -5.0), lights=LIGHT)),
+    "c5_1024x1024": ("csg64", 1024, 1024, dict(counts=(128, 64, 64), render_mode="full", position=(0.0, 0.0, -5.0), lights=SOFT_LIGHT)),
+    "c3a_2048x1024": ("mandelbulb", 2048, 1024, dict(counts=(256,), render_mode="preview", position=(0.0, 0.0, -2.5))),
+    "c2_2048x1024": ("sphere", 2048, 1024, dict(counts=(128,), render_mode="preview", position=(0.0, 0.0, -3.0))),
     # the headline at the pixel count of its own frame (8.39 M against the 8.29 M of 3840 x 2160)
     "c3b_4096x2048": ("mandelbulb", 4096, 2048, dict(counts=(256,), render_mode="full", position=(0.0, 0.0, -2.5), lights=LIGHT)),
 }

@@ -177,8 +177,8 @@ def test_baseline_configurations_bit_for_bit(name):
 @pytest.mark.parametrize("name", list(GC.ROW_CHECKSUM_CASES))
 def test_megapixel_configurations_row_checksums(name):
     """BASELINE configurations at megapixel size -- the headline C3b (Mandelbulb, full, 256 steps, the light) at 2048 x 1024
-    and C4 (CSG-64, 128 steps) at 1024 x 1024 -- rendered by the reference's GLSL under software GL; the fixture holds a
-    CRC-32 per image row.  Here: 24 rows spread over the frame (the colour plane; the GPU test checks every row of every
+    and 4096 x 2048, C3a and C2 at 2048 x 1024, C4 (CSG-64, 128 steps) and C5 (three bounces, the soft light) at 1024 x 1024 --
+    rendered by the reference's GLSL under software GL; the fixture holds a CRC-32 per image row.  Here: 24 rows spread over the frame (the colour plane; the GPU test checks every row of every
     plane), each row's checksum."""
     sc, schema, noises = GC.row_checksum_case(name)
     z = load("rows_" + name)
