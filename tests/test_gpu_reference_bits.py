@@ -183,3 +183,21 @@ def test_the_unmodified_shader_text_bit_for_bit(glctx):
                 assert same_bits(got[k], z[f"{name}_native_{i}"]).all(), f"job {i} {name}"
     finally:
         glctx.set_gl_stack(1)
+
+
+def test_gl_stack_arithmetic_is_partition_and_batch_invariant(glctx):
+    """The GL-stack arithmetic goes through the same launch machinery as the default one: a row window, a tile, and three
+    samples in one launch (rm_render_samples) give the bits of the whole-frame, sample-by-sample render."""
+    sc, schema, noises = GC.random_job_case(load("random_jobs"), 6)
+    noises = GC.halton_pairs(3)
+    whole = render_gpu(glctx, sc, schema, noises, STRICT | MK)
+    part = render_gpu(glctx, sc, schema, noises, STRICT | MK, rows=(8, 16))
+    for k in range(3):
+        assert same_bits(part[k], whole[k][8:24]).all(), f"row window, plane {k}"
+    h = glctx.create_scene(sc)
+    fb = glctx.create_framebuffer(GC.IMG_W, GC.IMG_H)
+    glctx.render_samples(h, fb, J.uniforms_from_schema(schema, noises[0]), noises, None, STRICT | MK)
+    for k in range(3):
+        assert same_bits(fb.download(k), whole[k]).all(), f"three samples in one launch, plane {k}"
+    fb.destroy()
+    h.destroy()
