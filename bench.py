@@ -136,6 +136,41 @@ def cpu_baseline(sc, schema, target_seconds=12.0):
                       "oracle/rm_oracle.c with OpenMP over the rows, libm transcendentals"}
 
 
+def reference_gl(key):
+    """The reference's own GLSL under software GL, as measured in the BUILD container (oracle/gl/time_reference.py): it cannot
+    run on the GPU box (only this repository travels), so it is quoted with its hardware and stack, never re-timed here."""
+    try:
+        rows = json.load(open(os.path.join(ROOT, "profiles", "r01_b1_swiftshader_reference.json")))
+    except Exception:
+        return None
+    tag = {"c3b": "C3b", "c3a": "C3a", "c2": "C2", "c4": "C4", "c5": "C5"}[key]
+    hits = [r for r in rows if r["case"].startswith(tag + " ")]
+    if not hits:
+        return None
+    r = hits[-1]  # the largest size timed for that configuration (cost per pixel does not depend on the size)
+    return {"value": r["Mpix_per_s"], "unit": "Mpixels/s", "cores": r["cores"], "kind": "reference",
+            "stack": "the reference's raymarcher.frag under SwiftShader (HeadlessChrome 88, WebGL2) standing in for llvmpipe, 8 cores of the build container",
+            "sample": r["case"], "source": "profiles/r01_b1_swiftshader_reference.json"}
+
+
+def counters_entry(key, strict, pipeline, windowed):
+    """This workload's entry of profiles/r03_counters.json (separate rocprofv3 --pmc passes of this command, tools/profile_gpu.sh
+    + tools/update_counters.py): HBM bytes and executed lane-flops per frame.  The counters belong to the kernel sources they
+    were measured on (their hash is recorded): after a source change they are withheld until re-measured."""
+    try:
+        cj = json.load(open(os.path.join(ROOT, "profiles", "r03_counters.json")))
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("update_counters", os.path.join(ROOT, "tools", "update_counters.py"))
+        uc = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(uc)
+        ent = cj.get(key + ("_shard" if windowed else "") + ("_strict" if strict else "_fast"))
+        if not ent or ent.get("kernel_source_sha256") != uc.kernel_source_hash() or ent.get("pipeline") != pipeline:
+            return None
+        return ent
+    except Exception:
+        return None
+
+
 def self_launch(args):
     """--gpus N > 1 with no launcher: start N fresh ranks before this process touches a GPU."""
     import socket
@@ -176,7 +211,6 @@ def main():
     ap.add_argument("--megakernel", action="store_true", help="force the one-thread-one-pixel kernel (default: the library picks per job)")
     ap.add_argument("--wavefront", action="store_true", help="force the wavefront pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--payload", default="rgba8", choices=["rgba8", "f32"], help="what a sharded run gathers: the tone-mapped rows or the fp32 colour plane")
     ap.add_argument("--overlap-leg", action="store_true",
                     help="also time the same K steps with 3 samples in flight on this one GPU (reported as `overlap`, never as `value`)")
     ap.add_argument("--in-flight", type=int, default=0,
@@ -188,6 +222,10 @@ def main():
                          "sharded, gathered -- every this many samples; the samples in between go to the library in one "
                          "rm_render_samples call.  Default: 1 on one GPU (the live loop's value, index.tsx:166), 8 when the "
                          "frame is sharded")
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions of exactly --steps steps each; `value` is their median, `spread` their range")
+    ap.add_argument("--dof", action="store_true", help="give the job the live default depth of field (dof.amount 0.01 at 1.5): a sharded present then "
+                                                       "gathers the packed (colour, DoF radius) rows and rank 0 runs the blur")
+    ap.add_argument("--no-far-jump", action="store_true", help="RM_RENDER_NO_FAR_JUMP: march escaping rays step by step (measurement switch, same bits)")
     ap.add_argument("--check-frame", action="store_true",
                     help="sharded runs: after the timed legs rank 0 renders the same samples on ONE framebuffer, presents it and compares "
                          "the bytes with the frame it assembled from the gathered rows (reported as `frame_check`)")
@@ -237,196 +275,177 @@ def main():
 
     wl, sc, schema = make_workload(args.workload)
     W, H = wl["width"], wl["height"]
+    if args.dof:  # the live default (index.tsx:309-310): the job has depth of field, so a sharded present gathers the packed rows
+        schema["dof"]["amount"], schema["dof"]["distance"] = 0.01, 1.5
     flags = abi.RM_RENDER_STRICT if args.strict else abi.RM_RENDER_FAST
     if args.megakernel:
         flags |= abi.RM_RENDER_MEGAKERNEL
     if args.wavefront:
         flags |= abi.RM_RENDER_WAVEFRONT
+    if args.no_far_jump:
+        flags |= abi.RM_RENDER_NO_FAR_JUMP
 
-    ctx = native.Context(local_rank)
-    # One stream for the renders, the torch ops on the planes and the point RCCL orders its collectives after.  Not torch's
-    # default stream: its handle is NULL, which rm_ctx_set_stream reads as "the context's own stream" -- and that one is
-    # non-blocking, i.e. NOT ordered with the NULL stream.
-    render_stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(render_stream)
-    ctx.set_stream(render_stream.cuda_stream)
-    # measured on one GPU standing in for a rank (tools/dbg/depth_sweep.py, ms per sample of a rank's stripes, depth 1/2/3/4/6):
-    # whole frame 2.48/2.57/2.55/2.51/2.51, 1/2 of it 1.45/1.32/1.31/1.29/1.28, 1/4 0.88/0.70/0.70/0.68/0.66, 1/8 0.58/0.41/0.46/0.37/0.36
-    # sharded, the job yields every 8 samples: a rank's 8 samples go out as ONE launch of a full frame's worth of workgroups
-    # (rm_render_samples, rm_ctx_set_sample_batch), two such launches in flight, one present + gather per yield
-    yield_interval = args.yield_interval if args.yield_interval > 0 else (1 if world == 1 else 8)
-    in_flight = args.in_flight if args.in_flight > 0 else (1 if world == 1 else 4 if yield_interval == 1 else 3)
-    ctx.set_samples_in_flight(in_flight)
-    tile = None
+    # The job runs through the render-job API (job.do_render_job on a job.RenderJobContext): sharded, the context owns this
+    # rank's striped framebuffer and the gatherers, and makes a torch stream of its own current for renders, snapshots, the
+    # collective and the assembly (not torch's default stream: its NULL handle is not ordered with the context's stream).
     rows_window = None
-    if args.rows:
+    if args.rows:  # one shard of a frame on one GPU: the context holds that window of rows (global pixel coordinates)
         if sharded:
             sys.exit("bench.py: --rows is a one-GPU option")
         a, b = (int(v) for v in args.rows.split(":"))
         rows_window = (a, b)
-        tile = abi.RmRect(0, a, W, b - a)
-    # the tone-mapped rows can only be gathered when depth of field is off (the blur of display.frag reads neighbour rows)
-    payload = args.payload if schema["dof"]["amount"] == 0.0 else "f32"
-    gatherer = rmdist.FrameGatherer(H, W, world, rank, dev, force=force_dist, ctx=ctx, payload=payload)
-    row_count = gatherer.rows
-    # planes live in torch memory (padded to the largest shard so that the gather is regular)
-    planes = [torch.zeros((gatherer.max_rows, W, 4), dtype=torch.float32, device=dev) for _ in range(3)]
-    fb = ctx.create_striped_framebuffer(W, H, shard.STRIPE_ROWS, world, rank, *(p.data_ptr() for p in planes))
-    assert fb.row_count == row_count
-    scene = ctx.create_scene(sc)
-
-    h2, h3 = J.halton(2), J.halton(3)
-    u_step = J.uniforms_from_schema(schema, (0.5, 1.0 / 3.0))  # only randNoise changes from sample to sample
+    group = rmdist.ShardGroup(dist, dev, force=force_dist) if sharded else None
+    jctx = J.RenderJobContext(local_rank, flags=flags, group=group, rows=(rows_window[0], rows_window[1] - rows_window[0]) if rows_window else None)
+    ctx = jctx.native
+    if not sharded:
+        render_stream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(render_stream)
+        ctx.set_stream(render_stream.cuda_stream)
+    # measured on one GPU standing in for a rank (tools/dbg/depth_sweep.py, ms per sample of a rank's stripes, depth 1/2/3/4/6):
+    # whole frame 2.48/2.57/2.55/2.51/2.51, 1/2 of it 1.45/1.32/1.31/1.29/1.28, 1/4 0.88/0.70/0.70/0.68/0.66, 1/8 0.58/0.41/0.46/0.37/0.36
+    # sharded, the job yields every 8 samples: a rank's 8 samples go out as ONE launch of a full frame's worth of workgroups
+    # (rm_render_samples, rm_ctx_set_sample_batch), three such launches in flight, one present + gather per yield
+    yield_interval = args.yield_interval if args.yield_interval > 0 else (1 if world == 1 else 8)
+    in_flight = args.in_flight if args.in_flight > 0 else (1 if world == 1 else 4 if yield_interval == 1 else 3)
+    ctx.set_samples_in_flight(in_flight)
+    payload = "f32dof" if schema["dof"]["amount"] != 0.0 else "rgba8"
+    schema["render"]["frameid"] = 7
+    fb = jctx.fbo_create(W, H, 7)  # (the job finds it in the context's cache: same size, same frameid -> it keeps accumulating)
+    row_count = fb.row_count
+    scene = jctx.get_scene(sc)
     samples = [0]
 
-    yi = [yield_interval]
+    def run(n, interval):
+        """n samples of the job through do_render_job: `interval` of them between two yields (one rm_render_samples call);
+        sharded, every yield starts the gather of what is shown -- it travels while the next samples render -- and the
+        previous frame is assembled on rank 0 first (at most one gather is outstanding)."""
+        r = schema["render"]
+        r["samplesPerPixel"], r["sampleYieldInterval"] = n, interval
+        base = samples[0]
 
-    def run(n):
-        yield_interval = yi[0]
-        # n samples of the job: `yield_interval` of them at a time (one rm_render_samples call), then -- sharded -- the
-        # gather of the presented rows (a snapshot) is started; it runs over RCCL while the next samples render, and
-        # the frame is assembled on rank 0 before the next gather starts
-        done = 0
-        while done < n:
-            k = min(yield_interval, n - done)
-            if k == 1:
-                u_step.randNoise[0], u_step.randNoise[1] = next(h2), next(h3)
-                ctx.render_sample(scene, fb, u_step, tile, flags)
-            else:
-                ctx.render_samples(scene, fb, u_step, [(next(h2), next(h3)) for _ in range(k)], tile, flags)
-            done += k
-            samples[0] += k
-            if sharded:
-                if gatherer.pending is not None:
-                    gatherer.finish()
-                gatherer.start(planes[0], dist, fb=fb, samples=samples[0])
+        def present(schema_, context_, fb_, k):
+            if k == 0 or not sharded:  # (nothing to show yet; unsharded, `value` is the render alone: planes resident, nothing presented)
+                return
+            if fb_._pending is not None:
+                fb_.finish_present()
+            fb_.start_present(base + k)
 
-    def step():
-        run(1)
+        res = J.drain(J.do_render_job(schema, jctx)(present))
+        if not res.get("success"):
+            sys.exit(f"bench.py: the render job failed: {res}")
+        samples[0] += n
 
     def drain():
-        if sharded and gatherer.pending is not None:
-            gatherer.finish()
-        if sharded and gatherer.aux is not None:
-            torch.cuda.current_stream().wait_stream(gatherer.aux)  # the last frame is assembled before the clock stops (side-stream mode)
+        if sharded and fb._pending is not None:
+            fb.finish_present()
 
-    run(args.warmup)
+    def timed(n, interval):
+        """n steps between barriers + device synchronisation on both sides; the MAX over ranks."""
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(n, interval)
+        drain()  # the last frame is assembled inside the timed region: n samples rendered, ceil(n / interval) frames assembled
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        e = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([e], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e = float(t.item())
+        return e
+
+    run(args.warmup, yield_interval)
     drain()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(args.steps)
-    drain()  # the last frame is assembled inside the timed region: K samples rendered, ceil(K / yield_interval) frames assembled
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # EXACTLY K steps per timed region; three regions, `value` from the median (the spread says what one region is worth)
+    regions = sorted(timed(args.steps, yield_interval) for _ in range(max(1, args.repeats)))
+    elapsed = regions[len(regions) // 2]
 
     px_frame = W * H if rows_window is None else W * (rows_window[1] - rows_window[0])
     ms_per_step = elapsed / args.steps * 1e3
     value = px_frame * args.steps / elapsed / 1e6
+    spread = {"regions": len(regions), "steps_each": args.steps, "ms_per_step_min": regions[0] / args.steps * 1e3,
+              "ms_per_step_max": regions[-1] / args.steps * 1e3, "value_min": px_frame * args.steps / regions[-1] / 1e6,
+              "value_max": px_frame * args.steps / regions[0] / 1e6}
 
     # for information, never `value`: the same K steps with a present + gather after EVERY sample (the live loop's
     # sampleYieldInterval = 1), four single-sample launches in flight
     every_sample = None
     if sharded and yield_interval > 1:
-        yi[0] = 1
         ctx.set_samples_in_flight(4)
-        run(min(args.warmup, 8) or 1)
+        run(min(args.warmup, 8) or 1, 1)
         drain()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        run(args.steps)
-        drain()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        e1 = time.perf_counter() - t1
-        if world > 1:
-            t = torch.tensor([e1], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            e1 = float(t.item())
-        yi[0] = yield_interval
+        e1 = timed(args.steps, 1)
         ctx.set_samples_in_flight(in_flight)
         every_sample = {"sample_yield_interval": 1, "samples_in_flight": 4, "value": px_frame * args.steps / e1 / 1e6,
                         "ms_per_step": e1 / args.steps * 1e3}
 
-    # --check-frame: the frame rank 0 assembled from the gathered rows against the same samples rendered and presented on
-    # ONE framebuffer here (the accumulation per pixel is in sample order either way: the bytes must be identical)
+    # --check-frame: the canvas rank 0 was last presented against the same samples rendered and presented on ONE framebuffer
+    # here (the accumulation per pixel is in sample order either way: the bytes must be identical)
     frame_check = None
-    if args.check_frame and sharded and rank == 0 and payload == "rgba8":
+    if args.check_frame and sharded:
+        fb.start_present(samples[0])
+        canvas = fb.finish_present()
         torch.cuda.synchronize()
-        whole = ctx.create_framebuffer(W, H)
-        g2, g3 = J.halton(2), J.halton(3)
-        pairs = [(next(g2), next(g3)) for _ in range(samples[0])]
-        ctx.set_sample_batch(1)
-        ctx.set_samples_in_flight(1)
-        ctx.render_samples(scene, whole, u_step, pairs, None, flags)
-        expect = whole.present(samples[0])
-        whole.destroy()
-        ctx.set_sample_batch(0)
-        ctx.set_samples_in_flight(in_flight)
-        got = gatherer.frame.cpu().numpy()
-        frame_check = bool(np.array_equal(got, expect))
-        if not frame_check:
-            sys.exit(f"bench.py --check-frame: the assembled frame differs from the single-framebuffer render in {int((got != expect).sum())} bytes")
+        if rank == 0:
+            whole = ctx.create_framebuffer(W, H)
+            J.reset_halton()
+            pairs = [J.next_rand_noise() for _ in range(samples[0])]
+            ctx.set_sample_batch(1)
+            ctx.set_samples_in_flight(1)
+            ctx.render_samples(scene, whole, J.uniforms_from_schema(schema, pairs[0]), pairs, None, flags)
+            expect = whole.present(samples[0])
+            whole.destroy()
+            ctx.set_sample_batch(0)
+            ctx.set_samples_in_flight(in_flight)
+            got = canvas.cpu().numpy()
+            frame_check = bool(np.array_equal(got, expect))
+            if not frame_check:
+                sys.exit(f"bench.py --check-frame: the assembled frame differs from the single-framebuffer render in {int((got != expect).sum())} bytes")
 
     overlap = None
     if world == 1 and not force_dist and in_flight == 1 and args.overlap_leg:
         # for information: the same K steps with consecutive samples overlapping on the device (what a sharded run uses)
         ctx.set_samples_in_flight(3)
-        for _ in range(3):
-            step()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        e1 = time.perf_counter() - t1
+        run(3, 1)
+        e1 = timed(args.steps, 1)
         ctx.set_samples_in_flight(in_flight)
         overlap = {"samples_in_flight": 3, "value": px_frame * args.steps / e1 / 1e6, "ms_per_step": e1 / args.steps * 1e3}
 
+    # kernel time of every rank's launch: HIP events on the launch stream
+    tile = None  # the whole window this rank's framebuffer holds
+    u = J.uniforms_from_schema(schema, (0.5, 1.0 / 3.0))
+    n_timed = max(3, min(args.steps, 20))
+    ctx.render_timed(scene, fb, u, 2, tile, flags | abi.RM_RENDER_NO_OVERLAP)  # let the cost order of this job settle
+    kernel_ms = ctx.render_timed(scene, fb, u, n_timed, tile, flags | abi.RM_RENDER_NO_OVERLAP)
+    pipeline = ctx.last_pipeline()  # what the library dispatched for this job (rm_ctx_last_pipeline), not a re-derivation of its rule
+    kernel_ms_per_rank = [kernel_ms]
+    if world > 1:
+        t = torch.zeros(world, dtype=torch.float64, device=dev)
+        t[rank] = kernel_ms
+        dist.all_reduce(t)
+        kernel_ms_per_rank = [float(v) for v in t.tolist()]
+
     out = None
     if rank == 0:
-        # kernel time of this rank's launch, HIP events on the launch stream
-        u = J.uniforms_from_schema(schema, (0.5, 1.0 / 3.0))
-        n_timed = max(3, min(args.steps, 20))
-        ctx.render_timed(scene, fb, u, 2, tile, flags | abi.RM_RENDER_NO_OVERLAP)  # let the cost order of this job settle
-        kernel_ms = ctx.render_timed(scene, fb, u, n_timed, tile, flags | abi.RM_RENDER_NO_OVERLAP)
         rows_held = shard.owned_rows(H, world, rank) if rows_window is None else np.arange(rows_window[0], rows_window[1])
         px_launch = len(rows_held) * W
         flops_launch, flops_px, fixture = instrumented_flops(args.workload, rows_held)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(sc, schema)
+            cpu["reference_gl"] = reference_gl(args.workload)
         nominal_px = NOMINAL_FLOPS_PX[args.workload]
         roof = None
-        # measured in separate rocprofv3 --pmc runs of this command (profiles/*_counters.json says how and from which file)
+        # measured in separate rocprofv3 --pmc runs of this command (profiles/r03_counters.json says how and from which file)
         traffic = executed = counters_file = None
-        try:
-            cj = json.load(open(os.path.join(ROOT, "profiles", "r02_counters.json")))
-            ent = cj.get(args.workload + ("_strict" if args.strict else "_fast"))
-            # the counters belong to the kernel sources they were measured on (tools/update_counters.py records their hash):
-            # after a source change they are withheld until re-measured
-            import importlib.util
-            spec = importlib.util.spec_from_file_location("update_counters", os.path.join(ROOT, "tools", "update_counters.py"))
-            uc = importlib.util.module_from_spec(spec)
-            spec.loader.exec_module(uc)
-            if ent and ent.get("kernel_source_sha256") != uc.kernel_source_hash():
-                ent = None
-            if ent and not args.wavefront and rows_window is None:
-                traffic = ent["hbm_bytes_per_frame"] * px_launch / (W * H)
-                executed = ent["executed_lane_flops_per_frame"] * px_launch / (W * H)
-                counters_file = ent["profile"]
-        except Exception:
-            pass
+        ent = counters_entry(args.workload, args.strict, pipeline, rows_window is not None)
+        if ent:
+            traffic = ent["hbm_bytes_per_frame"] * px_launch / ent["pixels_per_frame"]
+            executed = ent["executed_lane_flops_per_frame"] * px_launch / ent["pixels_per_frame"]
+            counters_file = ent["profile"]
         if flops_launch is not None:
             sec = kernel_ms * 1e-3
             achieved = flops_launch / sec / 1e12
@@ -438,25 +457,27 @@ def main():
                     "flops_per_launch_instrumented": flops_launch,
                     "flops_source": f"profiles/flops_per_pixel.json[{args.workload}] (every {fixture['row_stride']} row(s) of the whole frame; tools/count_flops.py)",
                     "executed_source": counters_file,
-                    "kernel_ms": kernel_ms, "kernel_launches_timed": n_timed, "pixels_per_launch": px_launch,
+                    "kernel_ms": kernel_ms, "kernel_ms_per_rank": kernel_ms_per_rank, "kernel_launches_timed": n_timed, "pixels_per_launch": px_launch,
                     "hbm_algorithmic_GBs": 96.0 * px_launch / sec / 1e9, "hbm_peak_GBs": PEAK_HBM_GBS}
-        # rm_api.hip prefer_wavefront: full-mode tiles of >= 2^23 pixels over a primitive table of >= 16 rows
-        auto = "auto (wavefront)" if (args.workload in ("c4", "c5") and wl["mode"] == "full" and px_launch >= (1 << 23)) else "auto (megakernel)"
         out = {
             "metric": "Mpixels/sec at 3840x2160 Mandelbulb" if args.workload in ("c3b", "c3a") else "Mpixels/sec",
             "value": value, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl["name"], "build": "strict" if args.strict else "fast",
+            "dtype": "f32", "data": "synthetic", "spread": spread,
+            "config": {"workload": wl["name"] + (" + depth of field 0.01 @ 1.5" if args.dof else ""), "build": "strict" if args.strict else "fast",
                        "rows_per_gpu": row_count if rows_window is None else rows_window[1] - rows_window[0],
-                       "pipeline": "megakernel" if args.megakernel else "wavefront" if args.wavefront else auto,
-                       "sharding": (f"{shard.STRIPE_ROWS}-row stripes round-robin over ranks; every {yield_interval} sample(s) (render.sampleYieldInterval) each rank "
-                                    f"tone-maps its rows and the {payload} rows are gathered to rank 0 over RCCL (overlapped with the next samples' render) and put back in image order")
+                       "pipeline": pipeline + ("" if (args.megakernel or args.wavefront) else " (the library's choice)"),
+                       "host": "job.do_render_job on a job.RenderJobContext" + (" (sharded: dist.ShardGroup)" if sharded else ""),
+                       "sharding": (f"{shard.STRIPE_ROWS}-row stripes round-robin over ranks; a step = one sample of every pixel, plus -- every {yield_interval} sample(s) "
+                                    f"(render.sampleYieldInterval) -- one present: each rank {'packs (colour, DoF radius) of' if payload == 'f32dof' else 'tone-maps'} its rows, the {payload} "
+                                    f"rows are gathered to rank 0 over RCCL (overlapped with the next samples' render) and put back in image order"
+                                    + (", and rank 0 runs the present pass with its blur on the assembled frame" if payload == "f32dof" else ""))
                        if sharded else "none",
                        "planes": "color+normal_dof+albedo_depth fp32, accumulated in place", "samples_in_flight": in_flight,
                        "sample_yield_interval": yield_interval},
             "roofline": roof, "cpu_baseline": cpu, "overlap": overlap, "present_every_sample": every_sample, "frame_check": frame_check,
         }
+    jctx.fbo_delete(W, H, 7)
     fb.destroy()
     scene.destroy()
     ctx.close()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RM_ABI_VERSION 4 /* 3: rm_ctx_set_sample_batch, rm_buffer_*; 4: rm_ctx_set_gl_stack (additions only) */
+#define RM_ABI_VERSION 5 /* 3: rm_ctx_set_sample_batch, rm_buffer_*; 4: rm_ctx_set_gl_stack; 5: rm_pack_present_rows, rm_ctx_last_pipeline, RM_RENDER_NO_FAR_JUMP (additions only) */
 
 #define RM_MAX_BOUNCES 10 /* raymarchingStepCountsArray[10], raymarcher.frag:31 */
 #define RM_MAX_LIGHTS 10  /* lightPositions[10],             raymarcher.frag:37-39 */
@@ -189,8 +189,12 @@ enum {
                                 full-mode tiles of >= 8 M pixels over primitive tables of >= 16 rows.  Same results either way. */
   RM_RENDER_NO_COST_CLASSES = 8, /* wavefront march in one pass even for scene kinds whose sdf cost depends on the
                                    point (Mandelbulb); a measurement switch, same results */
-  RM_RENDER_NO_OVERLAP = 32  /* this sample runs alone on the context's stream and blends in its own kernel (see
+  RM_RENDER_NO_OVERLAP = 32, /* this sample runs alone on the context's stream and blends in its own kernel (see
                                 rm_ctx_set_samples_in_flight); for timing one launch.  Same results. */
+  RM_RENDER_NO_FAR_JUMP = 64 /* RM_RENDER_FAST, power-8 Mandelbulb: march an escaping ray step by step instead of setting
+                                it to the end state its remaining steps are known to reach (castRay, raymarcher.frag:163-170,
+                                has no distance bound: such a ray overflows to a fixed +-Inf / NaN pattern).  A measurement
+                                and test switch: the same bits either way. */
 };
 
 enum { RM_PLANE_COLOR = 0, RM_PLANE_NORMAL_DOF = 1, RM_PLANE_ALBEDO_DEPTH = 2 };
@@ -225,8 +229,9 @@ int rm_ctx_set_samples_in_flight(rm_ctx* ctx, int n);
  * (a ray is a serial chain of ~1 ms); rm_render_samples therefore renders up to 8 consecutive samples of the job in
  * ONE launch, a workgroup per (tile, sample), each sample staged separately and blended into the planes in sample
  * order by one small kernel -- the same bits as one launch per sample.  Automatic = as many as bring the launch to
- * about 16 384 workgroups (a whole 3840x2160 frame has 16 320, so whole frames are not batched).  Costs 3 planes of
- * staging per sample of a batch (times the samples in flight). */
+ * about 16 384 workgroups (a whole 3840x2160 frame has 16 320, so whole frames are not batched), within a staging
+ * budget of a quarter of the device's free memory.  Staging costs 48 bytes per pixel of the TILE a launch renders, per
+ * sample of a batch and per launch in flight; a launch whose staging cannot be allocated renders unstaged (same bits). */
 int rm_ctx_set_sample_batch(rm_ctx* ctx, int n);
 /* Cost-ordered dispatch (default on; environment RM_COST_ORDER=0 turns it off).  From the second sample of a job on
  * (same framebuffer window, tile and scene kind, >= 512 workgroups), the pixel kernel starts its tiles in the order of
@@ -259,6 +264,11 @@ int rm_ctx_set_gl_stack(rm_ctx* ctx, int on);
  * -DRM_WF_STATS (zeros otherwise): out16[8*shadow + 4*pass2 + {0,1,2}] =
  * rays marched, lane-steps, wave-steps since the last reset. */
 int rm_debug_counters(rm_ctx* ctx, unsigned long long* out16, int reset);
+/* Which implementation of the per-pixel program the LAST rm_render_sample(s) / rm_render_timed call on this context
+ * dispatched (the library picks per job unless a flag forces one; same results either way): what a host reports next to a
+ * timing instead of re-deriving the library's rule. */
+enum { RM_PIPELINE_NONE = 0, RM_PIPELINE_PIXEL_KERNEL = 1, RM_PIPELINE_WAVEFRONT = 2 };
+int rm_ctx_last_pipeline(const rm_ctx* ctx);
 /* Free and total memory of the context's GPU (hipMemGetInfo): what a host sizes its frames against -- the planes of
  * a W x H frame take 48 W H bytes, staging 48 W H per sample in flight or in a batch, the wavefront pipeline 240 bytes
  * per pixel of a launch (the reference asks MAX_TEXTURE_SIZE instead). */
@@ -418,6 +428,16 @@ int rm_present_device(rm_ctx* ctx, const void* color, const void* normal_dof, in
  * window's own row order.  This is what a sharded run gathers instead of the fp32 colour plane: a quarter of the
  * bytes (raymarching_engine_amd/dist.py); rm_assemble_striped_bytes puts the stripes in image order. */
 int rm_present_rows(rm_ctx* ctx, rm_fb* fb, int samples, void* out_rgba8_device, void* hip_stream);
+/* What a sharded job WITH depth of field gathers instead: the blur of display.frag:44-55 reads up to 16 rows either
+ * side of a pixel, rows that other GPUs hold, so the present pass has to run where the whole frame is.  It reads two
+ * things per pixel -- the accumulated colour (display.frag:19,53) and the accumulated DoF radius, normalAndDofRadius.w
+ * (:21-23) -- and this call packs exactly those for the rows `fb` holds: out_float4_device = rm_fb_rows(fb)*width
+ * float4 (colour.r, colour.g, colour.b, normal_dof.w) of DEVICE memory, in the window's own row order, asynchronous on
+ * hip_stream (NULL = the context's stream).  Gathered and put in image order (rm_assemble_striped) the buffer is
+ * passed to rm_present_device / rm_present_planes as BOTH `color` and `normal_dof` (they read .rgb of the one and .w of
+ * the other): the bytes are those rm_present gives for the unsharded frame (raymarching_engine_amd/dist.py,
+ * index.tsx:25-59 is the caller this serves). */
+int rm_pack_present_rows(rm_ctx* ctx, rm_fb* fb, void* out_float4_device, void* hip_stream);
 
 #ifdef __cplusplus
 }

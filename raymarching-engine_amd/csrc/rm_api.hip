@@ -64,8 +64,8 @@ struct rm_ctx {
   hipStream_t sp_stream[RM_SP_MAX] = {};
   hipEvent_t sp_done[RM_SP_MAX] = {}, sp_free[RM_SP_MAX] = {};
   float4* sp_stage[RM_SP_MAX] = {};
-  size_t sp_capacity = 0;  // float4 elements per staged plane
-  int sp_batch_cap = 1;    // samples a slot's staging buffer holds (3 * sp_capacity elements each)
+  size_t sp_elems = 0;     // float4 elements of every slot's staging buffer (3 planes x tile pixels x samples of a batch)
+  int last_pipeline = 0;   // rm_ctx_last_pipeline: what the last render call dispatched
   // Sample batch of rm_render_samples (KParams::batch): 0 = as many samples per launch as bring it to about
   // RM_BATCH_TARGET_TILES workgroups (a whole 4K frame has 16 320), 1 = one launch per sample, 2..RM_BATCH_MAX = fixed.
   int sample_batch = 0;
@@ -245,6 +245,20 @@ int rm_ctx_set_samples_in_flight(rm_ctx* ctx, int n) {
   if (n < 1 || n > RM_SP_MAX) return fail(ctx, RM_ERR_INVALID, "rm_ctx_set_samples_in_flight: n must be in 1..8");
   if (ctx->sp_ready) RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->samples_in_flight = n;
+  ctx->error.clear();
+  if (n > 1) {
+    // every sample in flight renders on a side stream; the HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES
+    // hardware queues (default 4, read when the runtime starts) and streams that share a queue serialise
+    const char* q = std::getenv("GPU_MAX_HW_QUEUES");
+    const int queues = q ? std::atoi(q) : 4;
+    if (queues < n + 2) {
+      char msg[320];
+      std::snprintf(msg, sizeof msg, "warning: %d samples in flight but GPU_MAX_HW_QUEUES is %s%d: the side streams will share hardware queues and "
+                    "serialise (measured: 0.59 instead of 0.42 ms per sample on a 1/8 shard); export GPU_MAX_HW_QUEUES=8 before the process "
+                    "touches the GPU (raymarching_engine_amd.native and js/index.js do)", n, q ? "" : "unset = ", queues);
+      ctx->error = msg;  // accepted all the same: RM_OK, with the note left for rm_last_error
+    }
+  }
   return RM_OK;
 }
 
@@ -288,6 +302,8 @@ int rm_debug_counters(rm_ctx* ctx, unsigned long long* out16, int reset) {
   if (reset) RM_HIP(ctx, hipMemset(ctx->stats, 0, sizeof(unsigned long long) * 16));
   return RM_OK;
 }
+
+int rm_ctx_last_pipeline(const rm_ctx* ctx) { return ctx ? ctx->last_pipeline : RM_PIPELINE_NONE; }
 
 int rm_device_memory(rm_ctx* ctx, size_t* free_bytes, size_t* total_bytes) {
   if (!ctx || !free_bytes || !total_bytes) return fail(ctx, RM_ERR_INVALID, "rm_device_memory: NULL argument");
@@ -655,6 +671,7 @@ static int build_params(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniform
   std::memset(P->batch_noise, 0, sizeof P->batch_noise);
   P->block_order = nullptr;
   P->block_cost = nullptr;
+  P->no_far_jump = (flags & RM_RENDER_NO_FAR_JUMP) ? 1 : 0;
   return RM_OK;
 }
 
@@ -838,6 +855,26 @@ static bool prefer_wavefront(const KParams& P, int flags) {
 
 static hipError_t launch_pixels_ordered(rm_ctx* ctx, const KParams& P, int flags, hipStream_t stream, int slot);
 
+// frees the staging buffers of the samples in flight (the caller has synchronised the device, or is giving the buffers up)
+static void release_staging(rm_ctx* ctx) {
+  for (int s = 0; s < RM_SP_MAX; s++) {
+    if (ctx->sp_stage[s]) (void)hipFree(ctx->sp_stage[s]);
+    ctx->sp_stage[s] = nullptr;
+  }
+  ctx->sp_elems = 0;
+}
+
+// Staging the library may hold for a job: a quarter of what the device has free (counting what staging already holds).
+// rm_render_samples sizes its automatic batch by it, and a launch whose staging cannot be allocated at all renders
+// unstaged, one sample at a time on the context's stream, instead of failing (launch / rm_render_samples).
+static size_t staging_budget(rm_ctx* ctx) {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return (size_t)1 << 30;
+  size_t held = 0;
+  for (int s = 0; s < RM_SP_MAX; s++) held += ctx->sp_stage[s] ? sizeof(float4) * ctx->sp_elems : 0;
+  return (free_b + held) / 4;
+}
+
 // The pixel kernel of one sample -- or of a batch of `batch` samples, randNoise pairs in `noise` -- on a side stream,
 // staged, and its blend on the context's stream (see rm_ctx).
 static hipError_t launch_pixels_in_flight(rm_ctx* ctx, const KParams& P, int flags, int batch = 1, const float* noise = nullptr) {
@@ -852,28 +889,25 @@ static hipError_t launch_pixels_in_flight(rm_ctx* ctx, const KParams& P, int fla
     if ((e = hipEventCreateWithFlags(&ctx->sp_free[s], hipEventDisableTiming)) != hipSuccess) return e;
   }
   ctx->sp_ready = true;
-  const size_t need = (size_t)(P.ty + P.th) * (size_t)P.W;  // staged values sit at the plane index of their pixel
-  if (ctx->sp_capacity < need || ctx->sp_batch_cap < batch) {
+  // A slot's staging holds the launch's TILE, compact (tile pixel i of sample k at k * 3 * stride + i), so it is sized by the
+  // largest batch x tile a job has used -- not by the frame: a subdivided 8192^2 render stages a tile, not 3.2 GB x batch.
+  // One buffer of `sp_elems` float4 per slot; a launch needs 3 * tw * th * batch of them.
+  const size_t tile_px = (size_t)P.tw * (size_t)P.th;
+  const size_t need = 3 * tile_px * (size_t)batch;
+  if (ctx->sp_elems < need) {
     if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
-    for (int s = 0; s < RM_SP_MAX; s++) {
-      if (ctx->sp_stage[s]) (void)hipFree(ctx->sp_stage[s]);
-      ctx->sp_stage[s] = nullptr;
-    }
-    const size_t cap = need > ctx->sp_capacity ? need : ctx->sp_capacity;
-    const int bcap = batch > ctx->sp_batch_cap ? batch : ctx->sp_batch_cap;
-    ctx->sp_capacity = 0;
+    release_staging(ctx);
     for (int s = 0; s < depth; s++)
-      if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->sp_stage[s]), sizeof(float4) * 3 * cap * (size_t)bcap)) != hipSuccess) return e;
-    ctx->sp_capacity = cap;
-    ctx->sp_batch_cap = bcap;
+      if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->sp_stage[s]), sizeof(float4) * need)) != hipSuccess) { release_staging(ctx); return e; }
+    ctx->sp_elems = need;
   }
   const int slot = (int)(ctx->sp_next++ % (unsigned int)depth);
   if (!ctx->sp_stage[slot]) {  // the depth was raised after the buffers were made
-    if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->sp_stage[slot]), sizeof(float4) * 3 * ctx->sp_capacity * (size_t)ctx->sp_batch_cap)) != hipSuccess) return e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->sp_stage[slot]), sizeof(float4) * ctx->sp_elems)) != hipSuccess) return e;
   }
   KParams Q = P;
   Q.stage = ctx->sp_stage[slot];
-  Q.stage_stride = (long long)ctx->sp_capacity;
+  Q.stage_stride = (long long)tile_px;
   if (batch > 1) {
     Q.batch = batch;
     std::memcpy(Q.batch_noise, noise, sizeof(float) * 2 * (size_t)batch);
@@ -978,10 +1012,14 @@ static hipError_t launch_pixels_ordered(rm_ctx* ctx, const KParams& P, int flags
 static hipError_t launch(rm_ctx* ctx, const KParams& P, int flags) {
   const bool gl = ctx->gl_stack && !(flags & RM_RENDER_FAST);  // the GL-stack arithmetic exists as the pixel kernel only
   const bool wavefront = gl ? false : (flags & RM_RENDER_WAVEFRONT) ? true : (flags & RM_RENDER_MEGAKERNEL) ? false : prefer_wavefront(P, flags);
+  ctx->last_pipeline = wavefront ? RM_PIPELINE_WAVEFRONT : RM_PIPELINE_PIXEL_KERNEL;
   if (wavefront) return launch_wavefront(ctx, P, flags);
   // full mode with at least one bounce: the kernel's only use of the planes is the final blend, which can be split off
-  if (ctx->samples_in_flight > 1 && !(flags & RM_RENDER_NO_OVERLAP) && P.u.renderMode == 0 && P.u.reflections > 0.0f)
-    return launch_pixels_in_flight(ctx, P, flags);
+  if (ctx->samples_in_flight > 1 && !(flags & RM_RENDER_NO_OVERLAP) && P.u.renderMode == 0 && P.u.reflections > 0.0f) {
+    const hipError_t e = launch_pixels_in_flight(ctx, P, flags);
+    if (e != hipErrorOutOfMemory) return e;
+    (void)hipGetLastError();  // no room for the staging of this tile: render it unstaged (same bits, no overlap)
+  }
   return launch_pixels_ordered(ctx, P, flags, ctx->stream, RM_SP_MAX);
 }
 
@@ -1017,11 +1055,22 @@ int rm_render_samples(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms*
       per_launch = tiles > 0 ? (int)((RM_BATCH_TARGET_TILES + tiles / 2) / tiles) : 1;  // to the nearest: a 1/8 shard of the headline frame has 2 160 tiles -> 8
     }
     per_launch = per_launch < 1 ? 1 : per_launch > RM_BATCH_MAX ? RM_BATCH_MAX : per_launch;
+    // the staging of a batch is 48 bytes per tile pixel, sample of the batch and launch in flight: within the budget
+    const size_t per_sample = sizeof(float4) * 3 * (size_t)P.tw * (size_t)P.th * (size_t)ctx->samples_in_flight;
+    const size_t fit = staging_budget(ctx) / (per_sample ? per_sample : 1);
+    if ((size_t)per_launch > fit) per_launch = fit < 1 ? 1 : (int)fit;
   }
+  ctx->last_pipeline = wavefront ? RM_PIPELINE_WAVEFRONT : RM_PIPELINE_PIXEL_KERNEL;
   for (int i = 0; i < count;) {
-    const int n = count - i < per_launch ? count - i : per_launch;
+    int n = count - i < per_launch ? count - i : per_launch;
     if (n > 1) {
-      RM_HIP(ctx, launch_pixels_in_flight(ctx, P, flags, n, rand_noise_pairs + 2 * i));
+      const hipError_t e = launch_pixels_in_flight(ctx, P, flags, n, rand_noise_pairs + 2 * i);
+      if (e == hipErrorOutOfMemory) {  // the batch's staging does not fit after all: one sample per launch from here on
+        (void)hipGetLastError();
+        per_launch = 1;
+        continue;
+      }
+      RM_HIP(ctx, e);
     } else {
       P.u.randNoise[0] = rand_noise_pairs[2 * i];
       P.u.randNoise[1] = rand_noise_pairs[2 * i + 1];
@@ -1100,6 +1149,16 @@ int rm_present_rows(rm_ctx* ctx, rm_fb* fb, int samples, void* out_rgba8_device,
   return RM_OK;
 }
 
+int rm_pack_present_rows(rm_ctx* ctx, rm_fb* fb, void* out_float4_device, void* hip_stream) {
+  if (!ctx || !fb || !out_float4_device) return fail(ctx, RM_ERR_INVALID, "rm_pack_present_rows: NULL argument");
+  if (fb->ctx != ctx) return fail(ctx, RM_ERR_INVALID, "rm_pack_present_rows: framebuffer belongs to another context");
+  if (reinterpret_cast<uintptr_t>(out_float4_device) & 15u) return fail(ctx, RM_ERR_INVALID, "rm_pack_present_rows: the buffer must be 16-byte aligned");
+  RM_HIP(ctx, hipSetDevice(ctx->device));
+  RM_HIP(ctx, rm::launch_pack_rows(fb->plane[0], fb->plane[1], (long long)fb->width * (long long)fb->row_count, static_cast<float4*>(out_float4_device),
+                                   hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream));
+  return RM_OK;
+}
+
 int rm_present_planes(rm_ctx* ctx, const void* color, const void* normal_dof, int width, int height, int samples, uint8_t* out_rgba8) {
   if (!ctx || !color || !out_rgba8) return fail(ctx, RM_ERR_INVALID, "rm_present_planes: NULL argument");
   if (width < 1 || height < 1 || samples < 1) return fail(ctx, RM_ERR_INVALID, "rm_present_planes: width, height and samples must be >= 1");
@@ -1142,7 +1201,7 @@ int rm_probe(rm_ctx* ctx, rm_scene* scene, int what, const float* in, int n, flo
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_out), out_bytes);
   if (e == hipSuccess) e = hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
-    ProbeParams P{scene->dev, d_in, d_out, n, what, param, (flags & RM_RENDER_FAST) ? ctx->retire_eps : 0.0f};
+    ProbeParams P{scene->dev, d_in, d_out, n, what, param, (flags & RM_RENDER_FAST) ? ctx->retire_eps : 0.0f, (flags & RM_RENDER_NO_FAR_JUMP) ? 1 : 0};
     e = (flags & RM_RENDER_FAST) ? rm::launch_probe_fast(P, ctx->stream) : ctx->gl_stack ? rm_gl_launch_probe(&P, ctx->stream) : rm::launch_probe_strict(P, ctx->stream);
   }
   if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream);

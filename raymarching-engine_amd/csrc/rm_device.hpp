@@ -537,23 +537,47 @@ struct Sdf<RM_SCENE_MANDELBULB> {
   // (Tried: skipping the reciprocal in waves whose lanes all bailed out before the first round -- dr = 1 everywhere,
   // rcp(1) = 1 and x * 1 = x exactly; such far-field steps are ~16 % of the headline frame's issue slots.  The ballot
   // and branch per evaluation cost more than the skipped instruction saves: 2.07 against 2.06 ms.)
+  // Round 3: two transcendentals per evaluation instead of three.  sqrt(r2) / dr = r2 * rsq(r2 dr^2): one v_rsq for the
+  // v_sqrt + v_rcp pair (a transcendental costs 3.2 issue slots, the two extra multiplications one each); when dr^2
+  // overflows (dr > 1.8e19: the point is on the set, the true step is < 1e-18) rsq(Inf) = 0 makes the step 0, which moves
+  // the ray exactly as far as the true value did.  A point that bailed out before its first round has dr = 1: no
+  // reciprocal at all (pow8_distance_far: the bits of the three-transcendental form, rcp(1) = 1 and x * 1 = x).
   static RM_DEV float pow8_distance(float r2, float dr) {
+#ifdef RM_DIST_3T  // experiment builds: round 2's form
     return __builtin_amdgcn_logf(r2) * 0.17328680f * FM::sqrt(r2) * FM::rcp(dr);
+#else
+    return (__builtin_amdgcn_logf(r2) * 0.17328680f) * (r2 * __builtin_amdgcn_rsqf((r2 * dr) * dr));
+#endif
   }
+  static RM_DEV float pow8_distance_far(float r2) { return __builtin_amdgcn_logf(r2) * 0.17328680f * FM::sqrt(r2); }
   // ITERS = 8: the usual round count, unrolled -- no loop bookkeeping between the exec-mask regions (11 % on the
   // headline frame); ITERS = 0: the count is a scene parameter
   template <int ITERS>
   static RM_DEV float eval_pow8_n(const DevScene& sc, v3 pos) {
     const float bail2 = sc.p[RM_P_BULB_BAILOUT] * sc.p[RM_P_BULB_BAILOUT];
     v3 z = pos;
-    float dr = 1.0f, r2 = 0.0f;
-    if (ITERS == 8) {
+    float dr = 1.0f;
+    float rho2 = pow8_rho2(z);
+    float r2 = FM::fma(z.z, z.z, rho2);
+    const int iterations = ITERS == 8 ? 8 : (int)sc.p[RM_P_BULB_ITERATIONS];
+    if (ITERS != 8 && iterations < 1) return pow8_distance(0.0f, 1.0f);  // no round at all: r stays 0 (as in eval_generic)
 #ifdef RM_LANE_STATS
-      int rounds = 0;
+    int rounds = 0;
 #endif
+    if (r2 > bail2) {  // the far field: no round, dr = 1
+#ifdef RM_LANE_STATS
+      lane_stats(rounds);
+#endif
+      return pow8_distance_far(r2);
+    }
+    pow8_round(z, dr, pos, rho2, r2);
+#ifdef RM_LANE_STATS
+    rounds++;
+#endif
+    if (ITERS == 8) {
 #pragma unroll
-      for (int i = 0; i < 8; i++) {
-        const float rho2 = pow8_rho2(z);
+      for (int i = 1; i < 8; i++) {
+        rho2 = pow8_rho2(z);
         r2 = FM::fma(z.z, z.z, rho2);
         if (r2 > bail2) break;
         pow8_round(z, dr, pos, rho2, r2);
@@ -561,34 +585,36 @@ struct Sdf<RM_SCENE_MANDELBULB> {
         rounds++;
 #endif
       }
-#ifdef RM_LANE_STATS
-      {  // diagnostic build (tools/lane_stats.py): lanes x rounds used against lanes x rounds issued
-        const unsigned long long act = ballot(true);
-        unsigned long long lane_rounds = 0, wave_rounds = 0;
-        for (int r = 1; r <= 8; r++) {
-          const unsigned long long m = ballot(rounds >= r);
-          lane_rounds += __popcll(m);
-          wave_rounds += m != 0ull ? 1 : 0;
-        }
-        if ((int)__lane_id() == __ffsll((long long)act) - 1) {
-          atomicAdd(&g_lane_stats[0], lane_rounds);
-          atomicAdd(&g_lane_stats[1], wave_rounds * 64ull);
-          atomicAdd(&g_lane_stats[2], (unsigned long long)__popcll(act));
-          atomicAdd(&g_lane_stats[3], 64ull);
-        }
-      }
-#endif
     } else {
-      const int iterations = (int)sc.p[RM_P_BULB_ITERATIONS];
-      for (int i = 0; i < iterations; i++) {
-        const float rho2 = pow8_rho2(z);
+      for (int i = 1; i < iterations; i++) {
+        rho2 = pow8_rho2(z);
         r2 = FM::fma(z.z, z.z, rho2);
         if (r2 > bail2) break;
         pow8_round(z, dr, pos, rho2, r2);
       }
     }
+#ifdef RM_LANE_STATS
+    lane_stats(rounds);
+#endif
     return pow8_distance(r2, dr);
   }
+#ifdef RM_LANE_STATS
+  static RM_DEV void lane_stats(int rounds) {  // diagnostic build (tools/lane_stats.py): lanes x rounds used against lanes x rounds issued
+    const unsigned long long act = ballot(true);
+    unsigned long long lane_rounds = 0, wave_rounds = 0;
+    for (int r = 1; r <= 8; r++) {
+      const unsigned long long m = ballot(rounds >= r);
+      lane_rounds += __popcll(m);
+      wave_rounds += m != 0ull ? 1 : 0;
+    }
+    if ((int)__lane_id() == __ffsll((long long)act) - 1) {
+      atomicAdd(&g_lane_stats[0], lane_rounds);
+      atomicAdd(&g_lane_stats[1], wave_rounds * 64ull);
+      atomicAdd(&g_lane_stats[2], (unsigned long long)__popcll(act));
+      atomicAdd(&g_lane_stats[3], 64ull);
+    }
+  }
+#endif
   static RM_DEV float eval_pow8(const DevScene& sc, v3 pos) {
     return (int)sc.p[RM_P_BULB_ITERATIONS] == 8 ? eval_pow8_n<8>(sc, pos) : eval_pow8_n<0>(sc, pos);
   }
@@ -597,6 +623,32 @@ struct Sdf<RM_SCENE_MANDELBULB> {
     if (M::fast && sc.p[RM_P_BULB_POWER] == 8.0f) return eval_pow8(sc, p);
     return eval_generic<M>(sc, p);
   }
+  // ---- the far field, jumped (round 3; fast policy, power 8) ------------------------------------------------
+  // Outside the bailout sphere the estimate is d = 0.25 ln(r^2) r (no round, dr = 1), and a ray that is out there and
+  // not moving inward (p . dir >= 0) never comes back: with s = p . dir, one step maps (r^2, s) to (r^2 + 2 d s + d^2,
+  // s + d), both growing, d >= 0.3466 r for r >= 2.  So the rest of its march is known: r^2 reaches the overflow of
+  // fp32 in at most 26 steps (worst case: r = 2, s = 0, |dir|^2 = 0.98, every product rounded down by 1e-3; from r = 100
+  // it takes 18, from 1e6 12), the step after that is d = Inf, which makes every coordinate +-Inf by the sign of its
+  // direction component (NaN where that is 0: 0 x Inf), and that pattern is the march's fixed point -- unless it holds a
+  // NaN: then the next evaluation is NaN (NaN > bailout is false: the rounds run on it) and one more step leaves every
+  // coordinate NaN.  A ray with at least far_jump_steps steps left therefore ends exactly there, and 89 % of the
+  // headline frame's pixels end their camera ray this way and all of those their shadow ray (their steps were ~16 % of
+  // the frame's issue slots).  Exact: the end point has the bits the stepwise march produces (tested on the whole
+  // frame against RM_RENDER_NO_FAR_JUMP), so the wavefront pipeline, which marches on, stays bit-identical.
+  static constexpr int far_jump_steps = 30;
+  static RM_DEV bool far_jump_applies(const DevScene& sc) { return sc.p[RM_P_BULB_POWER] == 8.0f && sc.p[RM_P_BULB_ITERATIONS] >= 1.0f; }
+  static RM_DEV bool far_jump(const DevScene& sc, v3 p, v3 dir, int left, v3& end) {
+    const float bail2 = sc.p[RM_P_BULB_BAILOUT] * sc.p[RM_P_BULB_BAILOUT];
+    const float r2 = FM::fma(p.z, p.z, pow8_rho2(p));  // what the evaluation starts with
+    if (!(r2 > gmax(bail2, 4.0f) && r2 < 1e30f) || left < far_jump_steps) return false;
+    const float s = dot<FM>(p, dir), dd = dot<FM>(dir, dir);
+    if (!(s >= 0.0f && dd > 0.98f && dd < 1.02f)) return false;
+    v3 e = dir * __builtin_inff();
+    if (e.x != e.x || e.y != e.y || e.z != e.z) e = V(e.x + e.y + e.z, e.x + e.y + e.z, e.x + e.y + e.z);
+    end = e;
+    return true;
+  }
+
   // Cost classes.  The evaluation runs 0..`iterations` rounds of z -> z^n + c
   // depending on how close p is to the set: far points bail out at once, points
   // on the surface run them all (about 10x the cost).  eval_cheap is eval() with
@@ -616,15 +668,17 @@ struct Sdf<RM_SCENE_MANDELBULB> {
       const float bail2 = sc.p[RM_P_BULB_BAILOUT] * sc.p[RM_P_BULB_BAILOUT];
       v3 z = p;
       float dr = 1.0f, r2 = 0.0f;
+      int rounds = 0;
       for (int i = 0; i <= cheap_cap; i++) {
         const float rho2 = pow8_rho2(z);
         r2 = FM::fma(z.z, z.z, rho2);
         if (r2 > bail2) { bailed = true; break; }
         if (i == cheap_cap) break;
         pow8_round(z, dr, p, rho2, r2);
+        rounds++;
       }
       if (!bailed) return false;
-      d = pow8_distance(r2, dr);
+      d = rounds == 0 ? pow8_distance_far(r2) : pow8_distance(r2, dr);  // as eval_pow8_n ends
       return true;
     }
     const float power = sc.p[RM_P_BULB_POWER], bailout = sc.p[RM_P_BULB_BAILOUT];
@@ -650,7 +704,13 @@ template <>
 struct Sdf<RM_KIND_BULB8> : Sdf<RM_SCENE_MANDELBULB> {
   template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds&, v3 p) { return eval_pow8_n<8>(sc, p); }
+  static RM_DEV bool far_jump_applies(const DevScene&) { return true; }
 };
+
+// kinds whose fast march may jump an escaping ray to its end state (Sdf<RM_SCENE_MANDELBULB>::far_jump)
+template <int KIND> struct FarJump { static constexpr bool value = false; };
+template <> struct FarJump<RM_SCENE_MANDELBULB> { static constexpr bool value = true; };
+template <> struct FarJump<RM_KIND_BULB8> { static constexpr bool value = true; };
 
 // kernels that may evaluate the power-8 Mandelbulb on the fast policy start with this (FM::omod_mode)
 template <int KIND, bool FAST> RM_DEV void enter_math_mode() {

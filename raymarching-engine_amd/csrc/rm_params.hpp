@@ -50,6 +50,7 @@ struct KParams {
   // leaves its duration in block_cost[tile] for the next sample's order (rm_order_kernel).  nullptr = in launch order.
   const unsigned int* block_order;
   unsigned int* block_cost;
+  int no_far_jump;  // RM_RENDER_NO_FAR_JUMP: march escaping rays step by step (a measurement / test switch, same bits)
 };
 
 // image row of a local (plane) row
@@ -66,6 +67,7 @@ struct ProbeParams {
   int what;
   float param;
   float retire_eps;
+  int no_far_jump;
 };
 
 namespace rm {
@@ -117,6 +119,7 @@ hipError_t wf_launch_shade_strict(const WfParams& W, hipStream_t stream);
 hipError_t wf_launch_shade_fast(const WfParams& W, hipStream_t stream);
 bool wf_kind_has_cost_classes(int kind);
 hipError_t launch_assemble(const void* src, int parts, int max_rows, long long row_bytes, int H, int stripe_rows, void* dst, hipStream_t stream);
+hipError_t launch_pack_rows(const float4* color, const float4* normal_dof, long long pixels, float4* out, hipStream_t stream);
 hipError_t launch_present_rows(const float4* color, long long pixels, float brightness, uchar4* out, hipStream_t stream);
 hipError_t launch_present(const float4* color, const float4* normal_dof, int W, int H, float brightness, uchar4* out, hipStream_t stream);
 hipError_t wf_launch_stage(const WfParams& W, int stage, hipStream_t stream);

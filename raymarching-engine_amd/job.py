@@ -197,14 +197,40 @@ class RenderJobContext:
     loadRenderJobContext (LoadRenderJobContext.tsx:162-287): the native
     context, a scene cache keyed by scene description (programCache,
     ShaderCache.tsx:91-119 -- errors are cached too) and the framebuffer cache
-    keyed (w, h, frameid) with its <= 3 entry "purgatory" of released sets."""
+    keyed (w, h, frameid) with its <= 3 entry "purgatory" of released sets.
 
-    def __init__(self, device: int = 0, flags: int = abi.RM_RENDER_STRICT, rows: Optional[Tuple[int, int]] = None):
+    Sharded mode (`group`: a dist.ShardGroup -- one process per GPU, torch.distributed).  The reference's tile loop
+    (RenderJobExecutor.tsx:148-182) is the precedent for cutting a job's frame; here the frame's rows are dealt to the
+    ranks in 8-row stripes (shard.py), every rank runs the SAME job -- same schema, same do_render_job, same yields --
+    on the stripes it holds, and what fbo.create hands out is a dist.ShardedFramebuffer: the `present` callback of every
+    rank calls its collective ``present(samples)`` at every yield and rank 0 gets the assembled canvas, with and without
+    depth of field (dist.py).  The context makes a torch stream of its own current for the job's device work, so that
+    renders, snapshots, the collective and the assembly are ordered on one stream.
+    """
+
+    group = None   # a dist.ShardGroup when the context is sharded
+    stream = None  # the torch stream a sharded context orders its device work on (GPU)
+
+    def __init__(self, device: int = 0, flags: int = abi.RM_RENDER_STRICT, rows: Optional[Tuple[int, int]] = None, group=None,
+                 native_context=None):
         from . import native
 
-        self.native = native.Context(device)
+        self.native = native_context if native_context is not None else native.Context(device)
         self.flags = flags
         self.rows = rows  # (row_begin, row_count) window of this GPU, None = whole image
+        self.group = group if (group is not None and group.sharded) else None
+        self.stream = None
+        if self.group is not None:
+            if rows is not None:
+                raise ValueError("RenderJobContext: a sharded context holds stripes, not a row window")
+            import torch
+
+            dev = torch.device(self.group.device)
+            if dev.type == "cuda":
+                # not torch's default stream: its handle is NULL, which the context's own non-blocking stream is not ordered with
+                self.stream = torch.cuda.Stream(device=dev)
+                torch.cuda.set_stream(self.stream)
+                self.native.set_stream(self.stream.cuda_stream)
         self._scenes: Dict[bytes, object] = {}
         self._live: Dict[Tuple[int, int, int], object] = {}
         self._purgatory: list = []
@@ -236,8 +262,14 @@ class RenderJobContext:
                     pfb.clear()  # :196-208: a new frameid restarts the accumulation
                 self._live[key] = pfb
                 return pfb
-        rb, rc = self.rows if self.rows is not None else (0, height)
-        fb = self.native.create_framebuffer(width, height, rb, rc)
+        if self.group is not None:
+            from . import dist as rmdist
+
+            fb = rmdist.ShardedFramebuffer(self.native, self.group, width, height,
+                                           render_stream=self.stream.cuda_stream if self.stream is not None else None)
+        else:
+            rb, rc = self.rows if self.rows is not None else (0, height)
+            fb = self.native.create_framebuffer(width, height, rb, rc)
         self._live[key] = fb
         return fb
 
@@ -282,6 +314,10 @@ def do_render_job(schema: dict, context: RenderJobContext):
     if isinstance(handle, dict):  # :129-136
         return fail(handle)
 
+    sharded = getattr(fb, "sharded", False)
+    if sharded:
+        fb.dof = schema["dof"]["amount"] != 0.0  # selects what the ranks gather for a present (dist.ShardedFramebuffer)
+
     def gen(present: Callable):
         samples = 0
         n = r["subdivisions"]
@@ -291,7 +327,8 @@ def do_render_job(schema: dict, context: RenderJobContext):
                 left = r["samplesPerPixel"]
                 while left > 0:
                     if samples % r["sampleYieldInterval"] == 0:  # :163-166
-                        context.native.sync()
+                        if not sharded:  # (a sharded present is ordered on the job's stream: the next samples render while the frame travels)
+                            context.native.sync()
                         present(schema, context, fb, samples)
                         yield
                     # the samples up to the next yield differ in randNoise only (:219-222): one native call for all of them
@@ -305,7 +342,8 @@ def do_render_job(schema: dict, context: RenderJobContext):
                     samples += k
                     left -= k
         context.fbo_delete(r["width"], r["height"], r["frameid"])  # :333-337
-        context.native.sync()
+        if not sharded:
+            context.native.sync()
         present(schema, context, fb, samples)
         return {"success": True}
 
@@ -319,3 +357,17 @@ def drain(generator) -> dict:
             next(generator)
     except StopIteration as stop:
         return stop.value
+
+
+def collect_presents(frames: list) -> Callable:
+    """A ``present`` callback for drain(): appends (samples, canvas) for every present of the job that has samples to
+    show -- the reference presents once BEFORE the first sample too (RenderJobExecutor.tsx:163 at samplesRenderedSoFar
+    = 0: the previous job's accumulation; its presenter divides by its own running count, index.tsx:25-39), which has
+    no brightness here.  `canvas` = framebuffer.present(samples): RGBA8 [H, W, 4], row 0 = bottom; on a sharded job the
+    call is the ranks' collective and the canvas is None on every rank but 0."""
+
+    def present(schema, context, fb, samples):
+        if samples > 0:
+            frames.append((samples, fb.present(samples)))
+
+    return present

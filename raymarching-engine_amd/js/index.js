@@ -11,13 +11,18 @@
 // Types: index.d.ts.  (The container has Node 12 / N-API 8 and no tsc, so the
 // host is JavaScript with hand-written typings.)
 "use strict";
+// Process environment the device path depends on (read by the HIP / HSA runtime when it starts, i.e. when the addon
+// first touches the GPU): more hardware queues than the runtime's default 4, so that the side streams of the samples in
+// flight do not share one and serialise, and dmabuf IPC.  Set unless the user has set them (native.py does the same).
+if (process.env.GPU_MAX_HW_QUEUES === undefined) process.env.GPU_MAX_HW_QUEUES = "8";
+if (process.env.HSA_ENABLE_IPC_MODE_LEGACY === undefined) process.env.HSA_ENABLE_IPC_MODE_LEGACY = "0";
 const addon = require("./rm_napi.node");
 
 const RM = {
   MAX_BOUNCES: 10, MAX_LIGHTS: 10,
   SCENE_TABLE: 0, SCENE_MANDELBULB: 1, SCENE_SPHERE_GRID: 2, SCENE_SPHERE_LATTICE: 3, SCENE_MENGER: 4, SCENE_KIFS_TREE: 5, SCENE_KIFS_BOX: 6,
   PRIM_SPHERE: 0, PRIM_BOX: 1, PRIM_REPEAT: 2, PRIM_FOLD: 3, OP_UNION: 0, OP_SMOOTH_UNION: 1, OP_SUBTRACT: 2, OP_INTERSECT: 3,
-  RENDER_STRICT: 0, RENDER_FAST: 1, RENDER_COLOR_ONLY: 2, RENDER_MEGAKERNEL: 4,
+  RENDER_STRICT: 0, RENDER_FAST: 1, RENDER_COLOR_ONLY: 2, RENDER_MEGAKERNEL: 4, RENDER_WAVEFRONT: 16, RENDER_NO_OVERLAP: 32, RENDER_NO_FAR_JUMP: 64,
 };
 
 // ---- struct layouts (include/hip_raymarch.h; all fields are 4 bytes) ----------------

@@ -16,9 +16,15 @@ from .scene import Scene
 
 import os
 
-# more hardware queues than the HIP runtime's default 4, so that the side streams of the samples in flight do not share one
-# (bench.py has the measurement); only effective if set before the runtime starts in this process
+# Process environment the device path depends on, set where the library is loaded so that EVERY host gets it (bench.py,
+# the job API, the tests), unless the user has set it.  Both are read by the HIP / HSA runtime when it starts, so they
+# have to be in place before anything in this process touches the GPU:
+#  * GPU_MAX_HW_QUEUES=8: the runtime deals a process's streams over 4 hardware queues by default, and streams that share
+#    one serialise -- with samples in flight (side streams), torch's stream and RCCL's, a sharded rank's renders stopped
+#    overlapping (0.59 instead of 0.42 ms per sample at 8 GPUs).  rm_ctx_set_samples_in_flight warns when it is lower.
+#  * HSA_ENABLE_IPC_MODE_LEGACY=0: dmabuf IPC, which RCCL needs across processes on this driver.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 # RM_LIB selects an experiment build of the SAME library (tools/); default = the in-tree product
 LIB_PATH = Path(os.environ.get("RM_LIB") or Path(__file__).resolve().parent / "libhip_raymarch.so")
@@ -28,7 +34,7 @@ EXPORTS = [
     "rm_abi_version", "rm_material_default", "rm_ctx_create", "rm_ctx_destroy", "rm_last_error", "rm_ctx_set_stream",
     "rm_ctx_set_retire_eps", "rm_ctx_set_samples_in_flight", "rm_ctx_set_cost_order", "rm_debug_counters", "rm_device_memory", "rm_sync", "rm_scene_create", "rm_scene_destroy", "rm_fb_create", "rm_fb_create_striped", "rm_fb_rows", "rm_fb_width", "rm_fb_height", "rm_fb_wrap", "rm_fb_clear", "rm_fb_destroy",
     "rm_fb_download", "rm_fb_upload", "rm_fb_device_ptr", "rm_buffer_create", "rm_buffer_destroy", "rm_buffer_download", "rm_buffer_upload", "rm_render_sample", "rm_render_samples", "rm_ctx_set_sample_batch", "rm_ctx_set_gl_stack", "rm_render_timed",
-    "rm_probe", "rm_probe_camera", "rm_probe_rng", "rm_assemble_striped", "rm_assemble_striped_bytes", "rm_present", "rm_present_planes", "rm_present_device", "rm_present_rows",
+    "rm_probe", "rm_probe_camera", "rm_probe_rng", "rm_assemble_striped", "rm_assemble_striped_bytes", "rm_present", "rm_present_planes", "rm_present_device", "rm_present_rows", "rm_pack_present_rows", "rm_ctx_last_pipeline",
 ]
 
 
@@ -121,6 +127,8 @@ def load_library():
         "rm_assemble_striped_bytes": (ip, [vp, vp, ip, ip, C.c_longlong, ip, ip, vp, vp]),
         "rm_present_device": (ip, [vp, vp, vp, ip, ip, ip, vp, vp]),
         "rm_present_rows": (ip, [vp, vp, ip, vp, vp]),
+        "rm_pack_present_rows": (ip, [vp, vp, vp, vp]),
+        "rm_ctx_last_pipeline": (ip, [vp]),
         "rm_present": (ip, [vp, vp, ip, C.POINTER(C.c_uint8)]),
         "rm_present_planes": (ip, [vp, vp, vp, ip, ip, ip, C.POINTER(C.c_uint8)]),
     }
@@ -201,6 +209,11 @@ class Context:
     def set_samples_in_flight(self, n: int):
         """Consecutive full-mode samples that may overlap on the GPU (1 = none); the planes get the same bits."""
         self._check(self.lib.rm_ctx_set_samples_in_flight(self.h, int(n)))
+        note = self.lib.rm_last_error(self.h).decode()
+        if note.startswith("warning:"):  # accepted, but the process environment will keep the samples from overlapping
+            import warnings
+
+            warnings.warn(note)
 
     def device_memory(self):
         """(free, total) bytes of the context's GPU."""
@@ -243,6 +256,15 @@ class Context:
     def present_rows(self, fb: "Framebuffer", samples: int, out_ptr: int, stream: Optional[int] = None):
         """Tone-map the rows `fb` holds (no depth of field) into DEVICE memory (rows*width*4 bytes), asynchronous."""
         self._check(self.lib.rm_present_rows(self.h, fb.h, int(samples), C.c_void_p(out_ptr), C.c_void_p(stream) if stream else None))
+
+    def pack_present_rows(self, fb: "Framebuffer", out_ptr: int, stream: Optional[int] = None):
+        """(colour.rgb, normal_dof.w) of the rows `fb` holds into DEVICE memory (rows*width float4), asynchronous: what a
+        sharded job with depth of field gathers; assembled, it is both planes of present_device."""
+        self._check(self.lib.rm_pack_present_rows(self.h, fb.h, C.c_void_p(out_ptr), C.c_void_p(stream) if stream else None))
+
+    def last_pipeline(self) -> str:
+        """Which implementation the last render call dispatched: "megakernel" (the pixel kernel) or "wavefront"."""
+        return {abi.RM_PIPELINE_PIXEL_KERNEL: "megakernel", abi.RM_PIPELINE_WAVEFRONT: "wavefront"}.get(int(self.lib.rm_ctx_last_pipeline(self.h)), "none")
 
     def set_cost_order(self, on: bool):
         """Start the tiles of a job most-expensive-first by their cost in the previous sample (scheduling only)."""

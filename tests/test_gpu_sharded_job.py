@@ -1,0 +1,172 @@
+"""The sharded render job on the GPU, through the render-job API (job.do_render_job on a sharded job.RenderJobContext):
+N processes -- one per rank, as on a node -- run the SAME job on their stripes of the frame, every rank's `present`
+callback calls the framebuffer's collective present at every yield, and the canvases rank 0 gets are compared, byte for
+byte, with what ONE framebuffer presents for the same samples (native.Framebuffer.present = rm_present) -- without depth
+of field (RGBA8 rows travel) and with it (the packed (colour, DoF radius) rows travel and rank 0 runs the blur on the
+assembled frame).  A gpurun box has one GPU, so the ranks share it and the rows travel over gloo (RCCL refuses two ranks
+on one device) -- the testing aid bench.py's RM_BENCH_SHARE_GPU uses; a second test runs the same job with ONE rank over
+RCCL itself (ShardGroup(force=True)), both payloads.
+RenderJobExecutor.tsx:77-341 (the job), index.tsx:25-59 + display.frag:16-64 (what present shows)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H = 200, 116  # 14.5 stripes: the ranks hold different numbers of rows, the last stripe is half a stripe
+
+_WORKER = r'''
+import os, sys, time
+t0 = time.time()
+root, out_path, backend, force = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4] == "force"
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import numpy as np
+import torch
+import torch.distributed as dist
+import test_gpu_sharded_job as T
+from raymarching_engine_amd import abi, dist as rmdist, job as J
+
+dev = torch.device("cuda", 0)  # every rank on GPU 0: the box has one
+torch.cuda.set_device(dev)
+if backend == "nccl":
+    import datetime
+    dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=120))
+else:
+    dist.init_process_group("gloo")
+print(f"process group up after {time.time() - t0:.1f} s", flush=True)
+group = rmdist.ShardGroup(dist, dev, force=force)
+ctx = J.RenderJobContext(0, flags=abi.RM_RENDER_STRICT, group=group)
+assert ctx.group is not None and ctx.stream is not None
+ctx.native.set_samples_in_flight(3)
+out = {}
+for name in T.JOBS:
+    schema = T.job_schema(name)
+    J.reset_halton()
+    frames = []
+    res = J.drain(J.do_render_job(schema, ctx)(J.collect_presents(frames)))
+    assert res == {"success": True}, res
+    assert [n for n, _ in frames] == T.presents_of(schema), [n for n, _ in frames]
+    for n, canvas in frames:
+        assert (canvas is None) == (group.rank != 0)
+        if canvas is not None:
+            out[f"{name}_{n}"] = canvas
+torch.cuda.synchronize()
+if group.rank == 0:
+    np.savez(out_path, **out)
+dist.barrier()
+dist.destroy_process_group()
+print("SHARDED_JOB_OK", flush=True)
+'''
+
+JOBS = ("plain", "dof", "dof_mix")
+
+
+def job_schema(name):
+    import golden_cases as GC
+    from raymarching_engine_amd import job as J, scene as S
+
+    sc = S.Mandelbulb()
+    kw = dict(counts=(40, 20), render_mode="full", position=(0.0, 0.0, -2.5), lights=GC.LIGHT, samples_per_pixel=5, sample_yield_interval=2,
+              frameid={"plain": 1, "dof": 2, "dof_mix": 3}[name])
+    if name != "plain":
+        kw.update(dof_amount=0.03, dof_distance=1.6)  # blur radii from 0 to the 16-pixel cap across the frame
+    if name == "dof_mix":
+        kw.update(blend_mode="mix", blend_factor=0.6, subdivisions=2, samples_per_pixel=2, sample_yield_interval=3)
+    return J.make_schema(sc, W, H, **kw)
+
+
+def presents_of(schema):
+    """sample counts at which a job presents something (RenderJobExecutor.tsx:163, :338; the present before the first sample has nothing to show)"""
+    r = schema["render"]
+    total = r["samplesPerPixel"] * r["subdivisions"] ** 2
+    return [n for n in range(1, total) if n % r["sampleYieldInterval"] == 0] + [total]
+
+
+def _reference(ctx, name):
+    from raymarching_engine_amd import job as J
+
+    schema = job_schema(name)
+    J.reset_halton()
+    frames = []
+    assert J.drain(J.do_render_job(schema, ctx)(J.collect_presents(frames))) == {"success": True}
+    return {f"{name}_{n}": c for n, c in frames}
+
+
+def _launch(tmp_path, world, backend, force):
+    script = tmp_path / "sharded_job_worker.py"
+    script.write_text(_WORKER)
+    out = tmp_path / "canvases.npz"
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, NCCL_IB_DISABLE="1", NCCL_SOCKET_IFNAME="lo", HSA_ENABLE_IPC_MODE_LEGACY="0", GPU_MAX_HW_QUEUES="8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script), ROOT, str(out), backend, "force" if force else "-"]
+    last = None
+    for attempt in range(2):
+        try:
+            last = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env)
+        except subprocess.TimeoutExpired as e:
+            last = e
+            continue
+        break
+    if isinstance(last, subprocess.TimeoutExpired):
+        so = last.stdout.decode(errors="replace") if isinstance(last.stdout, bytes) else str(last.stdout or "")
+        where = "before the process group was up (torch / rendezvous / collective library start-up)" if "process group up" not in so else "inside the job"
+        pytest.fail(f"the {world}-rank sharded job ({backend}) did not finish in 2 x 400 s: stalled {where}\n{so[-1500:]}")
+    assert last.returncode == 0 and last.stdout.count("SHARDED_JOB_OK") == world, (last.stdout[-2500:], last.stderr[-2500:])
+    return dict(np.load(out))
+
+
+def _compare(got, ctx):
+    for name in JOBS:
+        want = _reference(ctx, name)
+        assert set(k for k in got if k.startswith(name + "_")) == set(want)
+        for k, canvas in want.items():
+            assert canvas.shape == (H, W, 4) and got[k].shape == (H, W, 4)
+            assert np.array_equal(got[k], canvas), f"{k}: {int((got[k] != canvas).any(-1).sum())} pixels differ from the one-framebuffer present"
+        last = want[f"{name}_{presents_of(job_schema(name))[-1]}"]
+        assert int(last[..., :3].max()) > 100 and len(np.unique(last[..., 0])) > 50  # an image, not a blank canvas
+    # depth of field did blur: the dof job's canvas is not the plain job's
+    assert not np.array_equal(got["dof_5"], got["plain_5"])
+
+
+def test_four_ranks_drive_do_render_job_and_rank0_presents_the_single_gpu_bytes(tmp_path):
+    from raymarching_engine_amd import abi, job as J
+
+    got = _launch(tmp_path, 4, "gloo", force=False)
+    ctx = J.RenderJobContext(0, flags=abi.RM_RENDER_STRICT)
+    try:
+        _compare(got, ctx)
+    finally:
+        ctx.native.close()
+
+
+def test_three_ranks_an_odd_world(tmp_path):
+    from raymarching_engine_amd import abi, job as J
+
+    got = _launch(tmp_path, 3, "gloo", force=False)
+    ctx = J.RenderJobContext(0, flags=abi.RM_RENDER_STRICT)
+    try:
+        _compare(got, ctx)
+    finally:
+        ctx.native.close()
+
+
+def test_the_sharded_job_over_rccl_with_one_rank(tmp_path):
+    """The same classes with the collective on RCCL itself (backend nccl; one rank, forced: the box has one GPU):
+    rm_present_rows / rm_pack_present_rows -> ncclGather -> rm_assemble_striped_bytes -> rm_present_device, on the
+    job's stream."""
+    from raymarching_engine_amd import abi, job as J
+
+    got = _launch(tmp_path, 1, "nccl", force=True)
+    ctx = J.RenderJobContext(0, flags=abi.RM_RENDER_STRICT)
+    try:
+        _compare(got, ctx)
+    finally:
+        ctx.native.close()
