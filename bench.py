@@ -314,6 +314,7 @@ def main():
     row_count = fb.row_count
     scene = jctx.get_scene(sc)
     samples = [0]
+    base_exposure = schema["render"]["exposure"] / schema["render"]["samplesPerPixel"]
 
     def run(n, interval):
         """n samples of the job through do_render_job: `interval` of them between two yields (one rm_render_samples call);
@@ -321,6 +322,7 @@ def main():
         previous frame is assembled on rank 0 first (at most one gather is outstanding)."""
         r = schema["render"]
         r["samplesPerPixel"], r["sampleYieldInterval"] = n, interval
+        r["exposure"] = base_exposure * n  # the shader's exposure is render.exposure / samplesPerPixel (RenderJobExecutor.tsx:254-256): the same per sample in every leg
         base = samples[0]
 
         def present(schema_, context_, fb_, k):

@@ -251,7 +251,7 @@ int rm_ctx_set_samples_in_flight(rm_ctx* ctx, int n) {
     // hardware queues (default 4, read when the runtime starts) and streams that share a queue serialise
     const char* q = std::getenv("GPU_MAX_HW_QUEUES");
     const int queues = q ? std::atoi(q) : 4;
-    if (queues < n + 2) {
+    if (queues < 8) {
       char msg[320];
       std::snprintf(msg, sizeof msg, "warning: %d samples in flight but GPU_MAX_HW_QUEUES is %s%d: the side streams will share hardware queues and "
                     "serialise (measured: 0.59 instead of 0.42 ms per sample on a 1/8 shard); export GPU_MAX_HW_QUEUES=8 before the process "

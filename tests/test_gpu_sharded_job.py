@@ -126,7 +126,7 @@ def _launch(tmp_path, world, backend, force):
 def _compare(got, ctx):
     for name in JOBS:
         want = _reference(ctx, name)
-        assert set(k for k in got if k.startswith(name + "_")) == set(want)
+        assert set(k for k in got if k.rsplit("_", 1)[0] == name) == set(want)
         for k, canvas in want.items():
             assert canvas.shape == (H, W, 4) and got[k].shape == (H, W, 4)
             assert np.array_equal(got[k], canvas), f"{k}: {int((got[k] != canvas).any(-1).sum())} pixels differ from the one-framebuffer present"
