@@ -1327,6 +1327,59 @@ def test_headline_frame_fast_against_strict_at_full_size(ctx):
     assert abs(ratio - 1.0) < 0.005 and abs(float(b.mean() / a.mean()) - 1.0) < 0.003
 
 
+# How far the fast build may be from the parity build, ANCHORED: GLSL leaves the precision of sin / cos / log / pow / acos /
+# atan (and min / max of NaN, fract at the ends) to the implementation, so the reference's own image exists once per GL
+# stack.  This library has two GLSL-legal arithmetics of the parity path: the strict default (IEEE operations, ~0.5 ulp
+# transcendentals) and the GL stack the goldens were rendered under (rm_ctx_set_gl_stack: SwiftShader's polynomials).  The
+# disagreement between those two on the headline frame is the yardstick: what one conforming implementation of the
+# reference differs from another by.  The stated fp32 tolerance of the fast build is FAST_TOLERANCE_K times that spread,
+# statistic by statistic -- it cannot be per pixel: sceneNormal is a forward difference with delta = 1e-5
+# (raymarcher.frag:153-160,:264), which turns any last-bit difference of a hit point into a different pixel.
+FAST_TOLERANCE_K = 1.0
+
+
+def test_fast_build_tolerance_is_anchored_to_the_spread_between_glsl_legal_arithmetics(ctx):
+    """Headline frame (3840x2160, full, [256], the light), 4 samples per pixel, same random stream in all three renders:
+    fast against strict, and GL-stack strict against default strict.  For the whole frame, for the pixels that show the
+    fractal, and for the two silhouette crops: the fraction of pixels off by > 1e-3 and by > 1e-5 (relative to max(1,
+    value)) and the ratio of the mean radiances.  The fast build has to be no further from the strict build than the
+    other legal arithmetic is (k = FAST_TOLERANCE_K), plus the standard error of the mean ratio."""
+    sc, schema = _c3b()
+    noises = GC.halton_pairs(4)
+    strict = render_gpu(ctx, sc, schema, noises, STRICT | MK)
+    fast = render_gpu(ctx, sc, schema, noises, FAST)
+    ctx.set_gl_stack(1)
+    try:
+        legal = render_gpu(ctx, sc, schema, noises, STRICT | MK)
+    finally:
+        ctx.set_gl_stack(0)
+    fractal = strict[2][..., 3] < 3.5e6  # at least one of the four camera rays did not escape (raymarcher.frag:278-283, :343)
+    regions = {"whole frame": np.ones_like(fractal), "fractal pixels": fractal}
+    for name, (x0, y0) in C3B_CROPS.items():
+        m = np.zeros_like(fractal)
+        m[y0:y0 + 32, x0:x0 + 128] = True
+        regions[f"crop {name}"] = m
+    a = strict[0][..., :3]
+    print()
+    for name, m in regions.items():
+        stats = {}
+        for other, img in (("fast", fast), ("gl-stack", legal)):
+            b = img[0][..., :3]
+            d = rel_diff(strict[0][..., :3], b).max(-1)[m]
+            fin = np.isfinite(a[m]).all(-1) & np.isfinite(b[m]).all(-1)
+            ratio = float(b[m][fin].mean() / a[m][fin].mean())
+            diff = (b[m][fin] - a[m][fin]).mean(-1)
+            se = float(diff.std() / np.sqrt(max(1, diff.size)) / a[m][fin].mean())
+            stats[other] = dict(gt3=float((d > 1e-3).mean()), gt5=float((d > 1e-5).mean()), ratio=ratio, se=se)
+        f, g = stats["fast"], stats["gl-stack"]
+        print(f"{name:15s} ({int(m.sum())} px)  fast vs strict: > 1e-3 {f['gt3']:.4f}, > 1e-5 {f['gt5']:.4f}, means {f['ratio']:.5f} +- {f['se']:.5f}   |   "
+              f"GL-stack vs strict: > 1e-3 {g['gt3']:.4f}, > 1e-5 {g['gt5']:.4f}, means {g['ratio']:.5f} +- {g['se']:.5f}")
+        k = FAST_TOLERANCE_K
+        assert f["gt3"] <= k * g["gt3"] + 1e-4, name
+        assert f["gt5"] <= k * g["gt5"] + 1e-4, name
+        assert abs(f["ratio"] - 1.0) <= k * abs(g["ratio"] - 1.0) + 3.0 * max(f["se"], g["se"]), name
+
+
 @pytest.mark.parametrize("scene", ["bulb", "csg64"])
 def test_cost_ordered_dispatch_leaves_the_same_bits(ctx, scene):
     """From the second sample of a job on, the pixel kernel starts its tiles
@@ -1548,9 +1601,10 @@ def test_frame_gatherer_over_rccl_one_rank(payload, streams, tmp_path):
     err = getattr(last, "stderr", "") or ""
     out = out.decode(errors="replace") if isinstance(out, bytes) else str(out)
     if isinstance(last, subprocess.TimeoutExpired) and "process group up" not in out:
-        # torch's first GPU use / RCCL's start-up did not finish in 2 x 240 s on this box (seen on freshly provisioned
-        # machines while the image pages in): nothing of this repository has run yet, so there is nothing to judge
-        pytest.skip("torch / RCCL start-up stalled on this box (2 x 240 s) before the test body ran")
+        # (a stall is a FAILURE that says where it stalled -- a skip would leave the suite green with the only collective
+        # that runs on hardware unexecuted, and `pytest -q` would not say why)
+        pytest.fail("RCCL one-rank run: torch / RCCL start-up stalled (2 x 240 s) BEFORE the process group was up -- nothing of this "
+                    f"repository had run yet; the collective path is UNTESTED on this box\n{out[-800:]}\n{str(err)[-800:]}")
     pytest.fail(f"RCCL one-rank run failed or timed out:\n{out[-1500:]}\n{str(err)[-1500:]}")
 
 
@@ -1573,8 +1627,9 @@ def test_bench_under_the_drivers_launcher_with_one_rank(tmp_path):
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=500, env=env)
-    except subprocess.TimeoutExpired:
-        pytest.skip("torch.distributed.run / RCCL start-up stalled on this box (500 s); steady state is 15-25 s")
+    except subprocess.TimeoutExpired as e:
+        pytest.fail("bench.py under the driver's launcher (one rank, RCCL forced) did not finish in 500 s (steady state is 15-25 s): "
+                    f"stalled in torch.distributed.run / RCCL start-up or in the run itself\n{str(e.stdout or '')[-800:]}\n{str(e.stderr or '')[-800:]}")
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -1600,8 +1655,9 @@ def test_bench_with_four_ranks_sharing_this_gpu(tmp_path):
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "16", "--warmup", "8", "--no-cpu-baseline", "--check-frame"]
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=500, env=env)
-    except subprocess.TimeoutExpired:
-        pytest.skip("four torch processes did not start within 500 s on this box; steady state is ~20 s")
+    except subprocess.TimeoutExpired as e:
+        pytest.fail("`bench.py --gpus 4` with the ranks sharing this GPU did not finish in 500 s (steady state is ~20 s)\n"
+                    f"{str(e.stdout or '')[-800:]}\n{str(e.stderr or '')[-800:]}")
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
     assert len(lines) == 1, r.stdout[-2000:]
