@@ -207,6 +207,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c3b", choices=list(WORKLOADS))
     ap.add_argument("--rows", default="", help="render only image rows A:B of the frame (e.g. one shard of C4/C5 on one GPU)")
+    ap.add_argument("--stripe-of", type=int, default=0, help="one GPU standing in for rank 0 of an N-way split: render its 8-row stripes of the frame (no collective)")
     ap.add_argument("--strict", action="store_true", help="parity build instead of the fast build")
     ap.add_argument("--megakernel", action="store_true", help="force the one-thread-one-pixel kernel (default: the library picks per job)")
     ap.add_argument("--wavefront", action="store_true", help="force the wavefront pipeline")
@@ -294,8 +295,14 @@ def main():
             sys.exit("bench.py: --rows is a one-GPU option")
         a, b = (int(v) for v in args.rows.split(":"))
         rows_window = (a, b)
+    stripes = None
+    if args.stripe_of > 1:  # one GPU standing in for rank 0 of an N-way split: its 8-row stripes of the frame, no collective
+        if sharded or rows_window:
+            sys.exit("bench.py: --stripe-of is a one-GPU option (and not with --rows)")
+        stripes = (args.stripe_of, 0)
     group = rmdist.ShardGroup(dist, dev, force=force_dist) if sharded else None
-    jctx = J.RenderJobContext(local_rank, flags=flags, group=group, rows=(rows_window[0], rows_window[1] - rows_window[0]) if rows_window else None)
+    jctx = J.RenderJobContext(local_rank, flags=flags, group=group, rows=(rows_window[0], rows_window[1] - rows_window[0]) if rows_window else None,
+                              stripes=stripes)
     ctx = jctx.native
     if not sharded:
         render_stream = torch.cuda.Stream(device=dev)
@@ -365,7 +372,7 @@ def main():
     regions = sorted(timed(args.steps, yield_interval) for _ in range(max(1, args.repeats)))
     elapsed = regions[len(regions) // 2]
 
-    px_frame = W * H if rows_window is None else W * (rows_window[1] - rows_window[0])
+    px_frame = W * row_count if (rows_window is not None or stripes is not None) else W * H
     ms_per_step = elapsed / args.steps * 1e3
     value = px_frame * args.steps / elapsed / 1e6
     spread = {"regions": len(regions), "steps_each": args.steps, "ms_per_step_min": regions[0] / args.steps * 1e3,
@@ -432,7 +439,8 @@ def main():
 
     out = None
     if rank == 0:
-        rows_held = shard.owned_rows(H, world, rank) if rows_window is None else np.arange(rows_window[0], rows_window[1])
+        rows_held = (np.arange(rows_window[0], rows_window[1]) if rows_window is not None else shard.owned_rows(H, stripes[0], stripes[1]) if stripes is not None
+                     else shard.owned_rows(H, world, rank))
         px_launch = len(rows_held) * W
         flops_launch, flops_px, fixture = instrumented_flops(args.workload, rows_held)
         cpu = None
@@ -443,7 +451,7 @@ def main():
         roof = None
         # measured in separate rocprofv3 --pmc runs of this command (profiles/r03_counters.json says how and from which file)
         traffic = executed = counters_file = None
-        ent = counters_entry(args.workload, args.strict, pipeline, rows_window is not None)
+        ent = counters_entry(args.workload, args.strict, pipeline, rows_window is not None or stripes is not None)
         if ent:
             traffic = ent["hbm_bytes_per_frame"] * px_launch / ent["pixels_per_frame"]
             executed = ent["executed_lane_flops_per_frame"] * px_launch / ent["pixels_per_frame"]
@@ -467,7 +475,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "spread": spread,
             "config": {"workload": wl["name"] + (" + depth of field 0.01 @ 1.5" if args.dof else ""), "build": "strict" if args.strict else "fast",
-                       "rows_per_gpu": row_count if rows_window is None else rows_window[1] - rows_window[0],
+                       "rows_per_gpu": row_count, "stripe_of": args.stripe_of if stripes else None,
                        "pipeline": pipeline + ("" if (args.megakernel or args.wavefront) else " (the library's choice)"),
                        "host": "job.do_render_job on a job.RenderJobContext" + (" (sharded: dist.ShardGroup)" if sharded else ""),
                        "sharding": (f"{shard.STRIPE_ROWS}-row stripes round-robin over ranks; a step = one sample of every pixel, plus -- every {yield_interval} sample(s) "

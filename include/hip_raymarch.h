@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RM_ABI_VERSION 5 /* 3: rm_ctx_set_sample_batch, rm_buffer_*; 4: rm_ctx_set_gl_stack; 5: rm_pack_present_rows, rm_ctx_last_pipeline, RM_RENDER_NO_FAR_JUMP (additions only) */
+#define RM_ABI_VERSION 5 /* 3: rm_ctx_set_sample_batch, rm_buffer_*; 4: rm_ctx_set_gl_stack; 5: rm_pack_present_rows, rm_present_sharded, rm_ctx_last_pipeline, RM_RENDER_NO_FAR_JUMP (additions only) */
 
 #define RM_MAX_BOUNCES 10 /* raymarchingStepCountsArray[10], raymarcher.frag:31 */
 #define RM_MAX_LIGHTS 10  /* lightPositions[10],             raymarcher.frag:37-39 */
@@ -438,6 +438,17 @@ int rm_present_rows(rm_ctx* ctx, rm_fb* fb, int samples, void* out_rgba8_device,
  * the other): the bytes are those rm_present gives for the unsharded frame (raymarching_engine_amd/dist.py,
  * index.tsx:25-59 is the caller this serves). */
 int rm_pack_present_rows(rm_ctx* ctx, rm_fb* fb, void* out_float4_device, void* hip_stream);
+/* The present of a frame that ONE process renders on several GPUs -- the shape of the reference's own host: one
+ * thread, one render loop (index.tsx:120), here with a context per GPU, each holding one part of the frame's stripes
+ * (rm_fb_create_striped with parts = `parts`, part = p on ctxs[p]; the host hands every sample to each context in turn
+ * and the GPUs render concurrently, launches being asynchronous).  Every context tone-maps (dof == 0, rm_present_rows) or
+ * packs (dof != 0, rm_pack_present_rows) the rows it holds on its own stream, the rows travel to ctxs[0]'s GPU by
+ * peer copies over xGMI (hipMemcpyPeerAsync; no collective library, no second process), are put in image order there
+ * and -- with depth of field -- blurred and tone-mapped there (display.frag:16-64).  out_rgba8 = height*width*4 bytes of
+ * HOST memory, row 0 = bottom: the bytes rm_present gives for the same samples on one framebuffer.  Synchronous.
+ * (Hosts with a process per GPU -- bench.py, job.RenderJobContext(group=...) -- gather the same rows over RCCL instead:
+ * raymarching_engine_amd/dist.py.) */
+int rm_present_sharded(rm_ctx* const* ctxs, rm_fb* const* fbs, int parts, int samples, int dof, uint8_t* out_rgba8);
 
 #ifdef __cplusplus
 }

@@ -96,6 +96,13 @@ struct rm_ctx {
   std::unordered_map<void*, size_t> buffers;  // rm_buffer_create: base address -> bytes
   uchar4* present_buf = nullptr;   // device staging of rm_present / rm_present_planes, grown on demand
   size_t present_cap = 0;          // pixels
+  // rm_present_sharded (one process driving several GPUs): this context's rows of the payload, and on the context that
+  // shows the frame the gathered parts and the frame in image order; grown on demand, freed with the context
+  void* shard_rows = nullptr;  size_t shard_rows_cap = 0;
+  void* shard_recv = nullptr;  size_t shard_recv_cap = 0;
+  void* shard_frame = nullptr; size_t shard_frame_cap = 0;
+  hipEvent_t shard_ev = nullptr;
+  unsigned long long peer_enabled = 0;  // devices this context's GPU has been given peer access to
   std::string error;
 };
 
@@ -217,6 +224,10 @@ void rm_ctx_destroy(rm_ctx* ctx) {
     if (ctx->sp_stage[s]) (void)hipFree(ctx->sp_stage[s]);
   }
   if (ctx->present_buf) (void)hipFree(ctx->present_buf);
+  if (ctx->shard_rows) (void)hipFree(ctx->shard_rows);
+  if (ctx->shard_recv) (void)hipFree(ctx->shard_recv);
+  if (ctx->shard_frame) (void)hipFree(ctx->shard_frame);
+  if (ctx->shard_ev) (void)hipEventDestroy(ctx->shard_ev);
   for (auto& b : ctx->buffers) (void)hipFree(b.first);  // rm_buffer_create'd memory the host did not destroy
   if (ctx->switch_ev) (void)hipEventDestroy(ctx->switch_ev);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -1185,6 +1196,76 @@ int rm_present(rm_ctx* ctx, rm_fb* fb, int samples, uint8_t* out_rgba8) {
   if (fb->stripe_rows > 0 || fb->row_begin != 0 || fb->row_count != fb->height)
     return fail(ctx, RM_ERR_INVALID, "rm_present: the blur reads neighbouring rows, so it needs the whole frame: gather the planes and use rm_present_planes (or rm_present_rows when depth of field is off)");
   return rm_present_planes(ctx, fb->plane[0], fb->plane[1], fb->width, fb->height, samples, out_rgba8);
+}
+
+// ---- present of a frame sharded over the GPUs of ONE process ----------------------------------------
+
+static int grow(rm_ctx* ctx, void** p, size_t* cap, size_t bytes) {
+  if (*cap >= bytes) return RM_OK;
+  RM_HIP(ctx, hipSetDevice(ctx->device));
+  if (*p) {
+    RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+  }
+  if (hipMalloc(p, bytes) != hipSuccess) { (void)hipGetLastError(); return fail(ctx, RM_ERR_DEVICE, "rm_present_sharded: out of device memory"); }
+  *cap = bytes;
+  return RM_OK;
+}
+
+int rm_present_sharded(rm_ctx* const* ctxs, rm_fb* const* fbs, int parts, int samples, int dof, uint8_t* out_rgba8) {
+  rm_ctx* root = (ctxs && parts >= 1) ? ctxs[0] : nullptr;
+  if (!root || !fbs || !out_rgba8) return fail(root, RM_ERR_INVALID, "rm_present_sharded: NULL argument");
+  if (samples < 1) return fail(root, RM_ERR_INVALID, "rm_present_sharded: samples must be >= 1");
+  const rm_fb* f0 = fbs[0];
+  for (int p = 0; p < parts; p++) {
+    const rm_fb* f = fbs[p];
+    if (!ctxs[p] || !f || f->ctx != ctxs[p]) return fail(root, RM_ERR_INVALID, "rm_present_sharded: framebuffer p must belong to context p");
+    if (f->stripe_rows < 1 || f->parts != parts || f->part != p || f->width != f0->width || f->height != f0->height || f->stripe_rows != f0->stripe_rows)
+      return fail(root, RM_ERR_INVALID, "rm_present_sharded: framebuffer p must be part p of `parts` striped windows of one image (rm_fb_create_striped)");
+    if (dof && !f->plane[1]) return fail(root, RM_ERR_INVALID, "rm_present_sharded: depth of field needs the normal_dof plane");
+  }
+  const int W = f0->width, H = f0->height, stripe = f0->stripe_rows;
+  const int max_rows = striped_rows_below(H, stripe, parts, 0);  // part 0 holds the most rows
+  const size_t px_bytes = dof ? sizeof(float4) : sizeof(uchar4);  // packed (colour, DoF radius) rows, or tone-mapped RGBA8 rows
+  const size_t row_bytes = (size_t)W * px_bytes, part_bytes = (size_t)max_rows * row_bytes;
+  if (int rc = grow(root, &root->shard_recv, &root->shard_recv_cap, part_bytes * (size_t)parts)) return rc;
+  if (int rc = grow(root, &root->shard_frame, &root->shard_frame_cap, (size_t)H * row_bytes)) return rc;
+  for (int p = 0; p < parts; p++) {
+    rm_ctx* c = ctxs[p];
+    rm_fb* f = fbs[p];
+    const size_t bytes = (size_t)f->row_count * row_bytes;
+    if (int rc = grow(c, &c->shard_rows, &c->shard_rows_cap, part_bytes)) return rc == RM_OK ? rc : fail(root, rc, rm_last_error(c));
+    RM_HIP(root, hipSetDevice(c->device));
+    if (!c->shard_ev) RM_HIP(root, hipEventCreateWithFlags(&c->shard_ev, hipEventDisableTiming));
+    const long long pixels = (long long)W * (long long)f->row_count;
+    if (dof) RM_HIP(root, rm::launch_pack_rows(f->plane[0], f->plane[1], pixels, static_cast<float4*>(c->shard_rows), c->stream));
+    else RM_HIP(root, (c->gl_stack ? rm_gl_launch_present_rows : rm::launch_present_rows)(f->plane[0], pixels, 1.0f / (float)samples, static_cast<uchar4*>(c->shard_rows), c->stream));
+    // this part's rows to the root's GPU, on the stream that wrote them: a peer copy over xGMI (a plain copy on one device)
+    void* dst = static_cast<char*>(root->shard_recv) + part_bytes * (size_t)p;
+    if (c->device == root->device) RM_HIP(root, hipMemcpyAsync(dst, c->shard_rows, bytes, hipMemcpyDeviceToDevice, c->stream));
+    else {
+      if (!(c->peer_enabled & (1ull << (root->device & 63)))) {  // direct access over xGMI where the topology has it (the copy works either way)
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, c->device, root->device) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(root->device, 0);
+        (void)hipGetLastError();  // "already enabled" is fine
+        c->peer_enabled |= 1ull << (root->device & 63);
+      }
+      RM_HIP(root, hipMemcpyPeerAsync(dst, root->device, c->shard_rows, c->device, bytes, c->stream));
+    }
+    RM_HIP(root, hipEventRecord(c->shard_ev, c->stream));
+  }
+  RM_HIP(root, hipSetDevice(root->device));
+  for (int p = 0; p < parts; p++) RM_HIP(root, hipStreamWaitEvent(root->stream, ctxs[p]->shard_ev, 0));
+  RM_HIP(root, rm::launch_assemble(root->shard_recv, parts, max_rows, (long long)row_bytes, H, stripe, root->shard_frame, root->stream));
+  if (!dof) {
+    RM_HIP(root, hipMemcpyAsync(out_rgba8, root->shard_frame, (size_t)H * row_bytes, hipMemcpyDeviceToHost, root->stream));
+    RM_HIP(root, hipStreamSynchronize(root->stream));
+    return RM_OK;
+  }
+  // the assembled (colour.rgb, DoF radius) buffer is both planes of the present pass
+  return rm_present_planes(root, root->shard_frame, root->shard_frame, W, H, samples, out_rgba8);
 }
 
 // ---- probes ----------------------------------------------------------------------

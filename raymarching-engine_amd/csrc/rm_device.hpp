@@ -258,9 +258,14 @@ RM_DEV void box_muller(Rng& r, float& ox, float& oy) {
   r.seed += 0.123123213f;
   const float u2 = gold_noise(r, gfract(r.n1 + r.seed));
   const float two_pi_u2 = 2.0f * 3.141592f * u2;
+#if RM_BUILD_FAST && defined(RM_SHADE_FAST)  // experiment builds (tools/): the hardware's transcendentals in the random directions
+  const float rad = __builtin_amdgcn_sqrtf(-2.0f * (__builtin_amdgcn_logf(u1) * 0.69314718056f));
+  float sn = __builtin_amdgcn_sinf(two_pi_u2 * 0.15915494309189535f), cs = __builtin_amdgcn_cosf(two_pi_u2 * 0.15915494309189535f);
+#else
   const float rad = sqrtf(-2.0f * PM::log(u1));
   float sn, cs;
   PM::sincos(two_pi_u2, sn, cs);  // one range reduction for both
+#endif
   ox = rad * cs;
   oy = rad * sn;
 }

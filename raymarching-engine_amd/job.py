@@ -211,13 +211,16 @@ class RenderJobContext:
     group = None   # a dist.ShardGroup when the context is sharded
     stream = None  # the torch stream a sharded context orders its device work on (GPU)
 
+    stripes = None  # (parts, part): this context holds one part's 8-row stripes of every frame, with no group (measurement: one GPU standing in for a rank)
+
     def __init__(self, device: int = 0, flags: int = abi.RM_RENDER_STRICT, rows: Optional[Tuple[int, int]] = None, group=None,
-                 native_context=None):
+                 native_context=None, stripes: Optional[Tuple[int, int]] = None):
         from . import native
 
         self.native = native_context if native_context is not None else native.Context(device)
         self.flags = flags
         self.rows = rows  # (row_begin, row_count) window of this GPU, None = whole image
+        self.stripes = stripes
         self.group = group if (group is not None and group.sharded) else None
         self.stream = None
         if self.group is not None:
@@ -267,6 +270,10 @@ class RenderJobContext:
 
             fb = rmdist.ShardedFramebuffer(self.native, self.group, width, height,
                                            render_stream=self.stream.cuda_stream if self.stream is not None else None)
+        elif self.stripes is not None:
+            from . import shard
+
+            fb = self.native.create_striped_framebuffer(width, height, shard.STRIPE_ROWS, self.stripes[0], self.stripes[1])
         else:
             rb, rc = self.rows if self.rows is not None else (0, height)
             fb = self.native.create_framebuffer(width, height, rb, rc)

@@ -54,8 +54,20 @@ export class RenderJobContext {
   fboDelete(width: number, height: number, frameid: number): void;
   close(): void;
 }
+/** A frame sharded over several GPUs by this one process: a native context per device, each holding one part of the frame's
+ *  8-row stripes; `present(samples)` of its framebuffer set assembles the canvas on the first GPU (rm_present_sharded). */
+export type ShardedFramebufferInfo = {
+  width: number; height: number; frameid: number; sharded: true; dof: boolean; rows(): number[];
+  present(samples: number, dof?: boolean): Uint8Array; toDataURL(samples: number): string;
+};
+export class ShardedRenderJobContext {
+  constructor(devices?: number[], flags?: number, samplesInFlight?: number);
+  fboCreate(width: number, height: number, frameid: number): ShardedFramebufferInfo;
+  fboDelete(width: number, height: number, frameid: number): void;
+  close(): void;
+}
 export type Present = (schema: RenderJobSchema, context: RenderJobContext, framebuffers: RenderJobFramebufferInfo, samplesSoFar: number) => void;
-export function doRenderJob(schema: RenderJobSchema, context: RenderJobContext): Promise<
+export function doRenderJob(schema: RenderJobSchema, context: RenderJobContext | ShardedRenderJobContext): Promise<
   (present: Present) => Generator<undefined, { success: boolean; why?: ShaderError | { type: "general"; infoLog: string } }, unknown>
 >;
 export function uniformsFromSchema(schema: RenderJobSchema, randNoise: [number, number]): ArrayBuffer;

@@ -200,6 +200,67 @@ class RenderJobContext {  // RenderJobContext + loadRenderJobContext (LoadRender
             for (const s of this.scenes.values()) if (!(s && s.infoLog)) addon.sceneDestroy(s); addon.ctxDestroy(this.ctx); }
 }
 
+// A frame sharded over several GPUs by THIS process -- the reference's host is one thread with one render loop
+// (index.tsx:120), and so is a Node host: one native context per GPU, each holding one part of the frame's 8-row stripes
+// (rm_fb_create_striped: pixel coordinates stay global, so the assembled frame has the single-GPU bits).  doRenderJob
+// hands every batch of samples to each context in turn -- the launches are asynchronous, so the GPUs render
+// concurrently -- and `present(samples)` of the framebuffer set is rm_present_sharded: every GPU tone-maps (or, with
+// depth of field, packs) its rows, peer copies over xGMI bring them to the first GPU, which puts them in image order and
+// runs the blur.  Same interface as RenderJobContext, so the reference's `present` callback does not change.
+// (The tile loop of the reference, RenderJobExecutor.tsx:148-182, is the precedent for cutting a job's frame.)
+const STRIPE_ROWS = 8;
+class ShardedRenderJobContext {
+  constructor(devices = [0], flags = RM.RENDER_STRICT, samplesInFlight = 3) {
+    if (!Array.isArray(devices) || devices.length < 1) throw new TypeError("ShardedRenderJobContext(devices: number[], flags?)");
+    this.devices = devices.slice(); this.flags = flags;
+    this.ctxs = devices.map((d) => addon.ctxCreate(d));
+    for (const c of this.ctxs) addon.setSamplesInFlight(c, samplesInFlight);
+    this.ctx = this.ctxs[0];
+    this.scenes = new Map(); this.live = new Map(); this.purgatory = [];
+  }
+  getScene(scene) {  // one handle per context; a failure (on any of them) is cached like a failed compile
+    const key = scene.key();
+    if (!this.scenes.has(key)) {
+      const made = [];
+      try { const d = scene.desc(); for (const c of this.ctxs) made.push(addon.sceneCreate(c, d.desc, d.prims)); this.scenes.set(key, { handles: made }); }
+      catch (e) { for (const h of made) addon.sceneDestroy(h); this.scenes.set(key, { type: "fragment", infoLog: String(e.message) }); }
+    }
+    return this.scenes.get(key);
+  }
+  fboCreate(w, h, frameid) {
+    const key = `${w}x${h}#${frameid}`;
+    if (this.live.has(key)) return this.live.get(key);
+    const i = this.purgatory.findIndex((e) => e.w === w && e.h === h);
+    let fbs;
+    if (i >= 0) { const e = this.purgatory.splice(i, 1)[0]; if (e.frameid !== frameid) for (const fb of e.fbs) addon.fbClear(fb); fbs = e.fbs; }
+    else {
+      fbs = [];
+      try { this.ctxs.forEach((c, p) => fbs.push(addon.fbCreateStriped(c, w, h, STRIPE_ROWS, this.ctxs.length, p))); }
+      catch (e) { for (const fb of fbs) addon.fbDestroy(fb); throw e; }
+    }
+    const info = { fbs, width: w, height: h, frameid, sharded: true, dof: false,
+                   rows: () => fbs.map((fb) => addon.fbRows(fb)),
+                   // the canvas of the assembled frame (display.frag, with its blur when the job has depth of field): RGBA8, row 0 = bottom
+                   present: (samples, dof = info.dof) => { const out = new Uint8Array(w * h * 4); addon.presentSharded(this.ctxs, fbs, samples, !!dof, out); return out; },
+                   toDataURL: (samples) => "data:image/png;base64," + encodePng(info.present(samples), w, h).toString("base64") };
+    this.live.set(key, info);
+    return info;
+  }
+  fboDelete(w, h, frameid) {
+    const key = `${w}x${h}#${frameid}`, info = this.live.get(key);
+    if (!info) return;
+    this.live.delete(key);
+    this.purgatory.push({ w, h, frameid, fbs: info.fbs });
+    while (this.purgatory.length > 3) for (const fb of this.purgatory.shift().fbs) addon.fbDestroy(fb);
+  }
+  close() {
+    for (const e of this.purgatory) for (const fb of e.fbs) addon.fbDestroy(fb);
+    for (const v of this.live.values()) for (const fb of v.fbs) addon.fbDestroy(fb);
+    for (const s of this.scenes.values()) if (s.handles) for (const h of s.handles) addon.sceneDestroy(h);
+    for (const c of this.ctxs) addon.ctxDestroy(c);
+  }
+}
+
 async function doRenderJob(schema, context) {  // RenderJobExecutor.tsx:77
   const fail = (why) => function* () { return { success: false, why }; };
   const r = schema.render;
@@ -210,23 +271,31 @@ async function doRenderJob(schema, context) {  // RenderJobExecutor.tsx:77
   const scene = context.getScene(schema.sdfScene);
   if (scene && scene.infoLog !== undefined) return fail(scene);
   let samples = 0;
+  // a sharded context: the same calls on every GPU's context, each with its part of the stripes (the tile is clipped to them)
+  const ctxs = framebuffers.sharded ? context.ctxs : [context.ctx];
+  const fbs = framebuffers.sharded ? framebuffers.fbs : [framebuffers.fb];
+  const scenes = framebuffers.sharded ? scene.handles : [scene];
+  if (framebuffers.sharded) framebuffers.dof = schema.dof.amount !== 0;  // what a present gathers (rm_present_sharded)
+  const syncAll = () => { for (const c of ctxs) addon.sync(c); };
   return function* (present) {
     for (let yp = 0; yp < r.subdivisions; yp++) for (let xp = 0; xp < r.subdivisions; xp++) {
       const tile = tileRect(schema, xp, yp);
       for (let left = r.samplesPerPixel; left > 0;) {
-        if (samples % r.sampleYieldInterval === 0) { addon.sync(context.ctx); present(schema, context, framebuffers, samples); yield; }
+        if (samples % r.sampleYieldInterval === 0) { syncAll(); present(schema, context, framebuffers, samples); yield; }
         // the samples up to the next yield differ in randNoise only (:219-222): one native call for all of them
         const k = Math.min(left, r.sampleYieldInterval - samples % r.sampleYieldInterval);
         const noise = new Float32Array(2 * k);
         for (let i = 0; i < k; i++) { noise[2 * i] = halton2.next().value; noise[2 * i + 1] = halton3.next().value; }
         const u = uniformsFromSchema(schema, [noise[0], noise[1]]);
-        if (k === 1) addon.renderSample(context.ctx, scene, framebuffers.fb, u, tile, context.flags);
-        else addon.renderSamples(context.ctx, scene, framebuffers.fb, u, noise, tile, context.flags);
+        for (let g = 0; g < ctxs.length; g++) {
+          if (k === 1) addon.renderSample(ctxs[g], scenes[g], fbs[g], u, tile, context.flags);
+          else addon.renderSamples(ctxs[g], scenes[g], fbs[g], u, noise, tile, context.flags);
+        }
         samples += k; left -= k;
       }
     }
     context.fboDelete(r.width, r.height, r.frameid);
-    addon.sync(context.ctx);
+    syncAll();
     present(schema, context, framebuffers, samples);
     return { success: true };
   };
@@ -256,4 +325,4 @@ function encodePng(rgba, width, height, bottomUp = true) {
 }
 
 module.exports = { RM, addon, encodePng, Scene, CsgScene, Mandelbulb, singleSphere, DEFAULT_MATERIAL, halton, resetHalton, uniformsFromSchema, packUniforms,
-                   tileRect, RenderJobContext, doRenderJob, U_OFFSET };
+                   tileRect, RenderJobContext, ShardedRenderJobContext, doRenderJob, U_OFFSET };

@@ -75,6 +75,53 @@ const rm = require("./index.js");
     fs.writeFileSync(out, JSON.stringify(all));
     return;
   }
+  if (mode === "sharded") {  // GPU: the same job on ONE context and on a ShardedRenderJobContext with N contexts (all on device 0 here), with and without depth of field
+    const n = parseInt(process.argv[4] || "3", 10);
+    const jobs = { plain: {}, dof: { dof: { amount: 0.03, distance: 3.5, showFocusedArea: false } } };
+    const result = {};
+    for (const name of Object.keys(jobs)) {
+      const sch = Object.assign({}, schema, jobs[name], { render: Object.assign({}, schema.render, { width: 96, height: 52, frameid: name === "plain" ? 1 : 2 }) });
+      const run = async (ctx) => {
+        rm.resetHalton();
+        const shown = [];
+        const gen = (await rm.doRenderJob(sch, ctx))((s, c, fb, k) => { if (k > 0) shown.push([k, Buffer.from(fb.present(k)).toString("base64")]); });
+        let it = gen.next();
+        while (!it.done) it = gen.next();
+        return { res: it.value, shown };
+      };
+      const one = new rm.RenderJobContext(0, rm.RM.RENDER_STRICT);
+      const a = await run(one);
+      one.close();
+      const many = new rm.ShardedRenderJobContext(new Array(n).fill(0), rm.RM.RENDER_STRICT);
+      const b = await run(many);
+      const rows = many.fboCreate(96, 52, sch.render.frameid).rows();
+      many.close();
+      result[name] = { one: a, many: b, rows };
+    }
+    fs.writeFileSync(out, JSON.stringify(result));
+    return;
+  }
+  if (mode === "sharded-replay") {  // no GPU needed: the calls a sharded job makes, recorded
+    const a = rm.addon;
+    const events = [];
+    let serial = 0;
+    a.ctxCreate = (d) => ({ ctx: ++serial, device: d }); a.ctxDestroy = () => {}; a.sync = (c) => events.push(["sync", c.ctx]); a.setSamplesInFlight = () => {};
+    a.sceneCreate = (c) => ({ scene: c.ctx }); a.sceneDestroy = () => {};
+    a.fbCreateStriped = (c, w, h, stripe, parts, part) => { events.push(["fbCreateStriped", c.ctx, w, h, stripe, parts, part]); return { fb: c.ctx }; };
+    a.fbClear = () => {}; a.fbDestroy = () => {}; a.fbRows = () => 0;
+    a.renderSample = (c, sc, fb, u, tile) => events.push(["render", c.ctx, sc.scene, fb.fb, 1, Array.from(tile)]);
+    a.renderSamples = (c, sc, fb, u, noise, tile) => events.push(["render", c.ctx, sc.scene, fb.fb, noise.length / 2, Array.from(tile)]);
+    a.presentSharded = (ctxs, fbs, samples, dof, o) => events.push(["presentSharded", ctxs.map((c) => c.ctx), fbs.map((f) => f.fb), samples, dof]);
+    const ctx = new rm.ShardedRenderJobContext([0, 1, 2], rm.RM.RENDER_FAST);
+    rm.resetHalton();
+    const sch = Object.assign({}, schema, { dof: { amount: 0.01, distance: 1.5, showFocusedArea: false } });
+    const gen = (await rm.doRenderJob(sch, ctx))((s, c, fb, k) => { if (k > 0) fb.present(k); });
+    let it = gen.next();
+    while (!it.done) { events.push(["yield"]); it = gen.next(); }
+    events.push(["done", it.value]);
+    fs.writeFileSync(out, JSON.stringify(events));
+    return;
+  }
   if (mode === "layout") {  // no GPU needed: the uniform block bytes and the scene description
     const u = rm.uniformsFromSchema(schema, [0.5, 1 / 3]);
     const d = schema.sdfScene.desc();

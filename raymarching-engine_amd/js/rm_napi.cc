@@ -233,6 +233,98 @@ static napi_value Present(napi_env env, napi_callback_info info) {
   return nullptr;
 }
 
+// fbCreateStriped(ctx, width, height, stripeRows, parts, part): the stripes k with k % parts == part of a width x height image,
+// planes owned by the library (rm_fb_create_striped) -- what one GPU of a sharded frame holds
+static napi_value FbCreateStriped(napi_env env, napi_callback_info info) {
+  size_t argc = 6;
+  napi_value argv[6];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  rm_ctx* ctx = get_external<rm_ctx>(env, argv[0]);
+  if (!ctx || argc < 6) {
+    napi_throw_type_error(env, nullptr, "fbCreateStriped(ctx, width, height, stripeRows, parts, part)");
+    return nullptr;
+  }
+  int32_t v[5] = {0, 0, 0, 0, 0};
+  for (int i = 0; i < 5; i++) napi_get_value_int32(env, argv[1 + i], &v[i]);
+  rm_fb* fb = nullptr;
+  if (rm_fb_create_striped(ctx, v[0], v[1], v[2], v[3], v[4], nullptr, nullptr, nullptr, &fb) != RM_OK) return throw_rm(env, ctx, "rm_fb_create_striped");
+  return make_external(env, fb);
+}
+
+// fbRows(fb): image rows the framebuffer holds
+static napi_value FbRows(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1], out;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  rm_fb* fb = get_external<rm_fb>(env, argv[0]);
+  if (!fb) {
+    napi_throw_type_error(env, nullptr, "fbRows(fb): not a framebuffer handle");
+    return nullptr;
+  }
+  NAPI_OK(napi_create_int32(env, rm_fb_rows(fb), &out));
+  return out;
+}
+
+// setSamplesInFlight(ctx, n): rm_ctx_set_samples_in_flight
+static napi_value SetSamplesInFlight(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  rm_ctx* ctx = get_external<rm_ctx>(env, argv[0]);
+  int32_t n = 1;
+  if (argc > 1) napi_get_value_int32(env, argv[1], &n);
+  if (!ctx) {
+    napi_throw_type_error(env, nullptr, "setSamplesInFlight(ctx, n): not a context handle");
+    return nullptr;
+  }
+  if (rm_ctx_set_samples_in_flight(ctx, n) != RM_OK) return throw_rm(env, ctx, "rm_ctx_set_samples_in_flight");
+  return nullptr;
+}
+
+// presentSharded(ctxs: ctx[], fbs: fb[], samples, dof: boolean, out: Uint8Array(width * height * 4)) = rm_present_sharded:
+// the canvas of a frame whose stripes this process renders on several GPUs (part p on ctxs[p]); RGBA8, row 0 = bottom
+static napi_value PresentSharded(napi_env env, napi_callback_info info) {
+  size_t argc = 5;
+  napi_value argv[5];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  uint32_t n = 0, m = 0;
+  bool is_a = false, is_b = false;
+  if (argc < 5 || napi_is_array(env, argv[0], &is_a) != napi_ok || !is_a || napi_is_array(env, argv[1], &is_b) != napi_ok || !is_b ||
+      napi_get_array_length(env, argv[0], &n) != napi_ok || napi_get_array_length(env, argv[1], &m) != napi_ok || n == 0 || n != m || n > 64) {
+    napi_throw_type_error(env, nullptr, "presentSharded(ctxs: ctx[], fbs: fb[], samples, dof, out: Uint8Array): the two arrays must have the same length (1..64)");
+    return nullptr;
+  }
+  rm_ctx* ctxs[64];
+  rm_fb* fbs[64];
+  for (uint32_t i = 0; i < n; i++) {
+    napi_value a, b;
+    NAPI_OK(napi_get_element(env, argv[0], i, &a));
+    NAPI_OK(napi_get_element(env, argv[1], i, &b));
+    ctxs[i] = get_external<rm_ctx>(env, a);
+    fbs[i] = get_external<rm_fb>(env, b);
+    if (!ctxs[i] || !fbs[i]) {
+      napi_throw_type_error(env, nullptr, "presentSharded: wrong or destroyed handle in ctxs / fbs");
+      return nullptr;
+    }
+  }
+  int32_t samples = 1;
+  napi_get_value_int32(env, argv[2], &samples);
+  bool dof = false;
+  napi_get_value_bool(env, argv[3], &dof);
+  void* d = nullptr;
+  size_t len = 0;
+  if (!get_buffer(env, argv[4], &d, &len)) {
+    napi_throw_type_error(env, nullptr, "presentSharded: out must be a Uint8Array");
+    return nullptr;
+  }
+  if (len < (size_t)rm_fb_width(fbs[0]) * (size_t)rm_fb_height(fbs[0]) * 4) {
+    napi_throw_range_error(env, nullptr, "presentSharded: out is smaller than width * height * 4 bytes");
+    return nullptr;
+  }
+  if (rm_present_sharded(ctxs, fbs, (int)n, samples, dof ? 1 : 0, static_cast<uint8_t*>(d)) != RM_OK) return throw_rm(env, ctxs[0], "rm_present_sharded");
+  return nullptr;
+}
+
 // renderSample(ctx, scene, fb, uniforms: ArrayBuffer(sizeof RmUniforms), tile: Int32Array(4) | null, flags)
 static napi_value RenderSample(napi_env env, napi_callback_info info) {
   size_t argc = 6;
@@ -322,6 +414,7 @@ static napi_value Init(napi_env env, napi_value exports) {
   const struct { const char* name; napi_callback fn; } fns[] = {
       {"ctxCreate", CtxCreate}, {"ctxDestroy", CtxDestroy}, {"sync", Sync}, {"sceneCreate", SceneCreate}, {"sceneDestroy", SceneDestroy},
       {"fbCreate", FbCreate}, {"fbClear", FbClear}, {"fbDestroy", FbDestroy}, {"fbDownload", FbDownload}, {"present", Present}, {"renderSample", RenderSample}, {"renderSamples", RenderSamples},
+      {"fbCreateStriped", FbCreateStriped}, {"fbRows", FbRows}, {"setSamplesInFlight", SetSamplesInFlight}, {"presentSharded", PresentSharded},
       {"sizes", Sizes}};
   for (const auto& f : fns) {
     napi_value fn;

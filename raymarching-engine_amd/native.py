@@ -34,7 +34,7 @@ EXPORTS = [
     "rm_abi_version", "rm_material_default", "rm_ctx_create", "rm_ctx_destroy", "rm_last_error", "rm_ctx_set_stream",
     "rm_ctx_set_retire_eps", "rm_ctx_set_samples_in_flight", "rm_ctx_set_cost_order", "rm_debug_counters", "rm_device_memory", "rm_sync", "rm_scene_create", "rm_scene_destroy", "rm_fb_create", "rm_fb_create_striped", "rm_fb_rows", "rm_fb_width", "rm_fb_height", "rm_fb_wrap", "rm_fb_clear", "rm_fb_destroy",
     "rm_fb_download", "rm_fb_upload", "rm_fb_device_ptr", "rm_buffer_create", "rm_buffer_destroy", "rm_buffer_download", "rm_buffer_upload", "rm_render_sample", "rm_render_samples", "rm_ctx_set_sample_batch", "rm_ctx_set_gl_stack", "rm_render_timed",
-    "rm_probe", "rm_probe_camera", "rm_probe_rng", "rm_assemble_striped", "rm_assemble_striped_bytes", "rm_present", "rm_present_planes", "rm_present_device", "rm_present_rows", "rm_pack_present_rows", "rm_ctx_last_pipeline",
+    "rm_probe", "rm_probe_camera", "rm_probe_rng", "rm_assemble_striped", "rm_assemble_striped_bytes", "rm_present", "rm_present_planes", "rm_present_device", "rm_present_rows", "rm_pack_present_rows", "rm_ctx_last_pipeline", "rm_present_sharded",
 ]
 
 
@@ -129,6 +129,7 @@ def load_library():
         "rm_present_rows": (ip, [vp, vp, ip, vp, vp]),
         "rm_pack_present_rows": (ip, [vp, vp, vp, vp]),
         "rm_ctx_last_pipeline": (ip, [vp]),
+        "rm_present_sharded": (ip, [C.POINTER(vp), C.POINTER(vp), ip, ip, ip, C.POINTER(C.c_uint8)]),
         "rm_present": (ip, [vp, vp, ip, C.POINTER(C.c_uint8)]),
         "rm_present_planes": (ip, [vp, vp, vp, ip, ip, ip, C.POINTER(C.c_uint8)]),
     }
@@ -137,6 +138,18 @@ def load_library():
         fn.restype, fn.argtypes = res, args
     _lib = lib
     return lib
+
+
+def present_sharded(contexts, framebuffers, samples: int, dof: bool) -> np.ndarray:
+    """rm_present_sharded: the canvas [H, W, 4] of a frame whose stripes ONE process renders on several contexts (part p of
+    len(contexts) on contexts[p]); the rows travel to contexts[0]'s GPU by peer copies."""
+    n = len(contexts)
+    assert n == len(framebuffers) and n >= 1
+    cs = (C.c_void_p * n)(*[c.h for c in contexts])
+    fs = (C.c_void_p * n)(*[f.h for f in framebuffers])
+    out = np.empty((framebuffers[0].height, framebuffers[0].width, 4), np.uint8)
+    contexts[0]._check(contexts[0].lib.rm_present_sharded(cs, fs, n, int(samples), 1 if dof else 0, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+    return out
 
 
 def scene_key(scene: Scene) -> bytes:

@@ -112,6 +112,53 @@ def test_js_do_render_job_matches_oracle(tmp_path):
     assert dd.max() <= 1 and np.mean(dd == 0) >= 0.99
 
 
+def test_js_sharded_job_makes_the_same_calls_on_every_context(tmp_path):
+    """js/index.js ShardedRenderJobContext + doRenderJob with the addon's calls recorded (no GPU): three contexts, each
+    created with its part of the 8-row stripes; every batch of samples goes to each context with ITS scene and framebuffer
+    handles and the job's tile; a present is one rm_present_sharded over all of them, with the job's depth-of-field flag;
+    yields and sample counts as in the single-context job (RenderJobExecutor.tsx:147-339)."""
+    out = tmp_path / "events.json"
+    subprocess.run(["node", str(JS / "render_cli.js"), str(out), "sharded-replay"], check=True, timeout=60)
+    ev = json.loads(out.read_text())
+    created = [e for e in ev if e[0] == "fbCreateStriped"]
+    assert [e[1:] for e in created] == [[1, 64, 32, 8, 3, 0], [2, 64, 32, 8, 3, 1], [3, 64, 32, 8, 3, 2]]
+    renders = [e for e in ev if e[0] == "render"]
+    # 4 tiles x 3 samples, yield every 2 samples: batches of (2, 1) then (1, 2) ... per tile, each issued to the 3 contexts in turn
+    assert len(renders) % 3 == 0 and sum(e[4] for e in renders) == 3 * 12
+    for i in range(0, len(renders), 3):
+        trio = renders[i:i + 3]
+        assert [e[1] for e in trio] == [1, 2, 3] and [e[2] for e in trio] == [1, 2, 3] and [e[3] for e in trio] == [1, 2, 3]  # ctx p with scene p and framebuffer p
+        assert trio[0][4] == trio[1][4] == trio[2][4] and trio[0][5] == trio[1][5] == trio[2][5]
+    presents = [e for e in ev if e[0] == "presentSharded"]
+    assert [e[3] for e in presents] == [2, 4, 6, 8, 10, 12] and all(e[1] == [1, 2, 3] and e[2] == [1, 2, 3] and e[4] is True for e in presents)
+    assert ev[-1] == ["done", {"success": True}] and sum(1 for e in ev if e == ["yield"]) == 6
+
+
+@pytest.mark.gpu
+def test_js_sharded_context_presents_the_single_context_bytes(tmp_path):
+    """The Node host's sharded mode on the GPU: one process, three native contexts (all on GPU 0: the box has one), each
+    with a third of the frame's stripes; the canvases of every present -- without depth of field (RGBA8 rows copied to
+    the first context) and with it (packed rows, blur on the assembled frame) -- equal the single-context job's byte
+    for byte (rm_present_sharded against rm_present)."""
+    import base64
+
+    out = tmp_path / "sharded.json"
+    r = subprocess.run(["node", str(JS / "render_cli.js"), str(out), "sharded", "3"], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr
+    res = json.loads(out.read_text())
+    canv = {}
+    for name in ("plain", "dof"):
+        one, many = res[name]["one"], res[name]["many"]
+        assert one["res"] == {"success": True} and many["res"] == {"success": True}
+        assert [k for k, _ in one["shown"]] == [k for k, _ in many["shown"]] == [2, 4, 6, 8, 10, 12]
+        assert sorted(res[name]["rows"]) == [16, 16, 20] and sum(res[name]["rows"]) == 52  # 6.5 stripes over 3 contexts
+        for (k, a), (_, b) in zip(one["shown"], many["shown"]):
+            assert a == b, f"{name}: the canvas after {k} samples differs"
+        canv[name] = np.frombuffer(base64.b64decode(one["shown"][-1][1]), np.uint8).reshape(52, 96, 4)
+        assert int(canv[name][..., :3].max()) > 100
+    assert not np.array_equal(canv["plain"], canv["dof"])
+
+
 def test_js_render_job_host_replays_the_reference_loop_call_by_call(tmp_path):
     """js/index.js doRenderJob over the 40 random schemas of tests/golden/host_reference.json.gz with the addon's calls
     recorded (no GPU): the same presents, yields, tiles and uniform blocks, to the float32 bit, as the reference's own

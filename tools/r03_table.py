@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Round 3: table scenes (CSG-64) by library variant: python tools/r03_table.py default tools/_exp_x.so ...
+ms per sample of C4 (4096^2 full frame, both implementations), one 8-way shard of it, one 8-way shard of C5, and C2."""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if len(sys.argv) >= 2 and sys.argv[1] != "--child":
+    for lib in sys.argv[1:]:
+        env = dict(os.environ, RM_LIB=os.path.abspath(lib) if lib != "default" else "")
+        r = subprocess.run([sys.executable, __file__, "--child"], env=env, capture_output=True, text=True)
+        print("==", lib); print(r.stdout.strip()); print(r.stderr.strip()[-600:])
+    sys.exit(0)
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import golden_cases as GC
+from raymarching_engine_amd import abi, job as J, native, scene as S, shard
+ctx = native.Context(0)
+F, MK, WF = abi.RM_RENDER_FAST, abi.RM_RENDER_MEGAKERNEL, abi.RM_RENDER_WAVEFRONT
+soft = [J.point_light((2.0, 3.0, -4.0), size=0.3)]
+cases = [("c4 full", S.csg64(), dict(width=4096, height=4096, counts=(128,), render_mode="full", position=(0, 0, -5.0), lights=GC.LIGHT), None, (MK, WF)),
+         ("c4 shard/8", S.csg64(), dict(width=4096, height=4096, counts=(128,), render_mode="full", position=(0, 0, -5.0), lights=GC.LIGHT), 8, (MK, WF)),
+         ("c5 shard/8", S.csg64(), dict(width=8192, height=8192, counts=(128, 64, 64), render_mode="full", position=(0, 0, -5.0), lights=soft), 8, (MK, WF)),
+         ("c2", S.single_sphere(), dict(width=1920, height=1080, counts=(128,), render_mode="preview", position=(0, 0, -3.0)), None, (MK,)),
+         ("csg_mixed 1080p", GC.build_scene("csg_mixed"), dict(width=1920, height=1080, counts=(128, 64), render_mode="full", position=(0.3, 0.2, -4.0), lights=GC.LIGHT), None, (MK,))]
+for name, sc, kw, parts, impls in cases:
+    schema = J.make_schema(sc, **kw); h = ctx.create_scene(sc)
+    fb = ctx.create_framebuffer(kw["width"], kw["height"]) if parts is None else ctx.create_striped_framebuffer(kw["width"], kw["height"], shard.STRIPE_ROWS, parts, 0)
+    u = J.uniforms_from_schema(schema, (0.5, 1 / 3))
+    for impl in impls:
+        ctx.render_timed(h, fb, u, 2, None, F | impl | abi.RM_RENDER_NO_OVERLAP)
+        ms = min(ctx.render_timed(h, fb, u, 3, None, F | impl | abi.RM_RENDER_NO_OVERLAP) for _ in range(2))
+        print(f"{name} {'wavefront' if impl == WF else 'pixel kernel'}: {ms:.3f} ms")
+    fb.destroy(); h.destroy()

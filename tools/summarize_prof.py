@@ -1,4 +1,6 @@
-"""Condense rocprofv3 csv output (kernel stats + PMC passes) into a short text summary."""
+"""Condense rocprofv3 csv output (kernel stats + PMC passes) into a short text summary.
+Per kernel: the dispatch count n, the mean per dispatch and the SUM over the run's dispatches (a pipeline of several kernels
+per frame is priced per frame by the sums: tools/update_counters.py)."""
 import csv, glob, os, sys
 from collections import defaultdict
 
@@ -23,4 +25,4 @@ for k in acc:
     print(k, meta[k])
     for c in sorted(acc[k]):
         v = acc[k][c]
-        print(f"   {c:26s} n={len(v):3d} mean {sum(v)/len(v):.6g}")
+        print(f"   {c:26s} n={len(v):3d} mean {sum(v)/len(v):.6g} sum {sum(v):.6g}")
