@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RM_ABI_VERSION 5 /* 3: rm_ctx_set_sample_batch, rm_buffer_*; 4: rm_ctx_set_gl_stack; 5: rm_pack_present_rows, rm_present_sharded, rm_ctx_last_pipeline, RM_RENDER_NO_FAR_JUMP (additions only) */
+#define RM_ABI_VERSION 5 /* 3: rm_ctx_set_sample_batch, rm_buffer_*; 4: rm_ctx_set_gl_stack; 5: RmSurface / RmSceneDesc.surfaces (the struct grew), rm_pack_present_rows, rm_present_sharded, rm_ctx_last_pipeline, RM_RENDER_NO_FAR_JUMP (additions only) */
 
 #define RM_MAX_BOUNCES 10 /* raymarchingStepCountsArray[10], raymarcher.frag:31 */
 #define RM_MAX_LIGHTS 10  /* lightPositions[10],             raymarcher.frag:37-39 */
@@ -116,7 +116,7 @@ enum { RM_OP_UNION = 0, RM_OP_SMOOTH_UNION = 1, RM_OP_SUBTRACT = 2, RM_OP_INTERS
  * fold  d = shape[0];  d = op_i(d, shape[i])  over the shape rows, in table order
  * (the operator of the first shape row is ignored); at least one row must be a shape. */
 typedef struct RmPrim {
-  int32_t type; /* RM_PRIM_* in bits 0..7, RM_OP_* in bits 8..15 */
+  int32_t type; /* RM_PRIM_* in bits 0..7, RM_OP_* in bits 8..15, surface index of a shape row in bits 16..23 (RmSurface) */
   float k;      /* smooth-union radius */
   float center[3];
   float size[3]; /* sphere: size[0] = radius; box: half extents; repeat: period; fold: angles */
@@ -157,12 +157,32 @@ typedef struct RmMaterial {
   int32_t reserved;
 } RmMaterial;
 
+/* Position-dependent materials of a composed scene.  The reference's contract is seven FUNCTIONS of position
+ * (Validate.tsx:18-51; examples/guide.glsl:51-88 writes its own); a primitive table gets them per shape: a shape row
+ * names a surface (RmPrim.type bits 16..23: 0 = the scene's RmMaterial block, k = surfaces[k - 1]) and the material
+ * functions at `position` return the values of the shape row whose distance there -- the row's own term of the fold,
+ * domain rows applied, before its operator -- is the smallest (the earliest such row on a tie, a NaN distance never
+ * wins); the cut-off radii and the sky (emission) stay the scene's.  The composer emits the same rule as GLSL
+ * (scene.py / js/index.js: rmSurfaceIndex + the seven functions), which is what pins it against the reference's shader. */
+#define RM_MAX_SURFACES 15
+typedef struct RmSurface {
+  float diffuse[3];
+  float roughness;
+  float specular[3];
+  float subsurface;
+  float subsurface_color[3];
+  float ior;
+} RmSurface;
+
 typedef struct RmSceneDesc {
   int32_t kind;
   int32_t nprims;
   const RmPrim* prims; /* host pointer, nprims rows (RM_SCENE_TABLE only) */
   float params[16];
   RmMaterial material;
+  int32_t nsurfaces;         /* 0..RM_MAX_SURFACES (RM_SCENE_TABLE only) */
+  int32_t reserved;
+  const RmSurface* surfaces; /* host pointer, nsurfaces entries, or NULL */
 } RmSceneDesc;
 
 /* Fills *m with the reference defaults of Validate.tsx:18-51. */

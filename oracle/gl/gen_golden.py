@@ -96,28 +96,31 @@ def gen_cast(only=None):
              normal_points=pts, normal=gn.reshape(-1, 4)[: len(pts), :3])
 
 
-def gen_misc():
+def gen_misc(only=None):
+    """`only`: material scenes to (re)generate alone (python oracle/gl/gen_golden.py misc:csg_surfaces); the points are the same draws."""
     w, h = 64, 16
     rng = np.random.default_rng(3)
     n = w * h
     # schlick(cosTheta, n1, n2), raymarcher.frag:172-175; invExpDist :148-150
     a = np.stack([rng.uniform(0, 1, n), rng.uniform(1, 2, n), rng.uniform(1, 100, n), rng.uniform(0.01, 3, n)], -1).astype(np.float32)
     harness = "void main(void){ " + FETCH + " fragColor = vec4(schlick(t.x, t.y, t.z), invExpDist(t.x, t.w), schlick(t.x, 1.0, 100.0), 0.0); }"
-    g = glref.run_gl(glref.splice(scene_text("sphere")[1], harness), w, h, {}, init_prev0=a.reshape(h, w, 4))["planes"][0]
-    save("misc_schlick", inputs=a, out=g.reshape(-1, 4)[:, :3])
+    if not only:
+        g = glref.run_gl(glref.splice(scene_text("sphere")[1], harness), w, h, {}, init_prev0=a.reshape(h, w, 4))["planes"][0]
+        save("misc_schlick", inputs=a, out=g.reshape(-1, 4)[:, :3])
     # rodrigues(v, k, theta), :61-65, with v = fixed unit vector given as uniform
     k = rng.normal(size=(n, 3))
     k /= np.linalg.norm(k, axis=1, keepdims=True)
     b = np.concatenate([k, rng.uniform(0, 0.5, (n, 1))], -1).astype(np.float32)
     v = np.array([0.48, -0.6, 0.64], np.float32)
     harness = "uniform vec3 hv;\nvoid main(void){ " + FETCH + " fragColor = vec4(rodrigues(hv, t.xyz, t.w), 0.0); }"
-    g = glref.run_gl(glref.splice(scene_text("sphere")[1], harness), w, h, {"hv": glref.u_float(*v)}, init_prev0=b.reshape(h, w, 4))["planes"][0]
-    save("misc_rodrigues", v=v, inputs=b, out=g.reshape(-1, 4)[:, :3])
+    if not only:
+        g = glref.run_gl(glref.splice(scene_text("sphere")[1], harness), w, h, {"hv": glref.u_float(*v)}, init_prev0=b.reshape(h, w, 4))["planes"][0]
+        save("misc_rodrigues", v=v, inputs=b, out=g.reshape(-1, 4)[:, :3])
     # material functions (defaults and the lattice example's own), near and far points
     p = rng.uniform(-3, 3, (n, 3))
     p[n // 2:] *= 30.0
     p = p.astype(np.float32)
-    for name in ("sphere", "lattice"):
+    for name in (only or GC.MATERIAL_SCENES):
         outs = []
         for fn in ("sceneDiffuseColor", "sceneSpecularColor", "sceneEmission"):
             harness = "void main(void){ " + FETCH + f" fragColor = vec4({fn}(t.xyz), 0.0); }}"

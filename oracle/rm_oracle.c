@@ -485,13 +485,74 @@ static float scene_sdf(const RmSceneDesc* sc, v3 p) {
 
 /* ---- material functions: Validate.tsx:18-51 with the constants in RmMaterial */
 
+/* Position-dependent materials of a composed scene (include/hip_raymarch.h RmSurface; the reference's contract is seven
+ * functions of position, Validate.tsx:18-51, examples/guide.glsl:51-88): the values of the shape row whose distance term at
+ * p is the smallest -- the loop the composer emits as rmSurfaceIndex(), statement for statement: the terms of sdf()'s fold
+ * before their operators, `if (di < best)`, so the earliest row wins a tie and a NaN term never wins.  surface 0 = the
+ * scene's material block. */
+static int table_has_surfaces(const RmSceneDesc* sc) {
+  if (sc->kind != RM_SCENE_TABLE) return 0;
+  for (int i = 0; i < sc->nprims; i++)
+    if ((sc->prims[i].type >> 16) & 0xff) return 1;
+  return 0;
+}
+static int surface_index(const RmSceneDesc* sc, v3 p) {
+  float best = 0.0f, factor = 1.0f;
+  int first = 1, domain = 0, surface = 0;
+  v3 q = p;
+  for (int i = 0; i < sc->nprims; i++) domain |= (sc->prims[i].type & 0xff) >= RM_PRIM_REPEAT;
+  for (int i = 0; i < sc->nprims; i++) {
+    const RmPrim* pr = &sc->prims[i];
+    v3 c = V(pr->center[0], pr->center[1], pr->center[2]);
+    const int prim = pr->type & 0xff;
+    if (prim == RM_PRIM_REPEAT) {
+      q = V(gl_mod(q.x + 0.5f * pr->size[0], pr->size[0]) - 0.5f * pr->size[0], gl_mod(q.y + 0.5f * pr->size[1], pr->size[1]) - 0.5f * pr->size[1],
+            gl_mod(q.z + 0.5f * pr->size[2], pr->size[2]) - 0.5f * pr->size[2]);
+      continue;
+    }
+    if (prim == RM_PRIM_FOLD) {
+      q = V(q.x / pr->k, q.y / pr->k, q.z / pr->k);
+      q = vsub(vabs(q), c);
+      q = kifs_rotate(q, pr->size);
+      factor = factor * pr->k;
+      continue;
+    }
+    float di;
+    if (prim == RM_PRIM_SPHERE) di = sdf_sphere(q, c, pr->size[0]);
+    else di = sd_box(vsub(q, c), V(pr->size[0], pr->size[1], pr->size[2]));
+    if (domain) di = di * factor;
+    if (first || di < best) { best = di; surface = (pr->type >> 16) & 0xff; }
+    first = 0;
+  }
+  return surface;
+}
+typedef struct OSurface {
+  float diffuse[3], specular[3], subsurface_color[3], roughness, subsurface, ior;
+} OSurface;
+static OSurface surface_at(const RmSceneDesc* sc, v3 p) {
+  OSurface o;
+  const int k = table_has_surfaces(sc) ? surface_index(sc, p) : 0;
+  if (k > 0 && k <= sc->nsurfaces && sc->surfaces) {
+    const RmSurface* f = &sc->surfaces[k - 1];
+    memcpy(o.diffuse, f->diffuse, sizeof o.diffuse); memcpy(o.specular, f->specular, sizeof o.specular);
+    memcpy(o.subsurface_color, f->subsurface_color, sizeof o.subsurface_color);
+    o.roughness = f->roughness; o.subsurface = f->subsurface; o.ior = f->ior;
+  } else {
+    const RmMaterial* m = &sc->material;
+    memcpy(o.diffuse, m->diffuse, sizeof o.diffuse); memcpy(o.specular, m->specular, sizeof o.specular);
+    memcpy(o.subsurface_color, m->subsurface_color, sizeof o.subsurface_color);
+    o.roughness = m->roughness; o.subsurface = m->subsurface; o.ior = m->ior;
+  }
+  return o;
+}
+
 static v3 cut_color(const float* col, float cutoff, v3 p) {
   FL(1);
   if (vlength(p) > cutoff) return V(0, 0, 0);
   return V(col[0], col[1], col[2]);
 }
-static v3 scene_diffuse(const RmSceneDesc* sc, v3 p) { return cut_color(sc->material.diffuse, sc->material.diffuse_cutoff, p); }
-static v3 scene_specular(const RmSceneDesc* sc, v3 p) { return cut_color(sc->material.specular, sc->material.specular_cutoff, p); }
+static v3 scene_diffuse(const RmSceneDesc* sc, v3 p) { const OSurface f = surface_at(sc, p); return cut_color(f.diffuse, sc->material.diffuse_cutoff, p); }
+static v3 scene_specular(const RmSceneDesc* sc, v3 p) { const OSurface f = surface_at(sc, p); return cut_color(f.specular, sc->material.specular_cutoff, p); }
 /* Validate.tsx:47-51 */
 static v3 scene_emission(const RmSceneDesc* sc, v3 p) {
   const RmMaterial* m = &sc->material;
@@ -649,7 +710,8 @@ static void pixel_main(const RmSceneDesc* sc, const RmUniforms* u, int W, int H,
 
     /* :266-271 */
     FL(4);
-    float subsurf = -1.0f / sc->material.subsurface * o_log(1.0f - uniform_sample(&s));
+    const OSurface sf = surface_at(sc, pos); /* sceneSubsurfaceScattering / ...Color / IOR / SpecularRoughness(rayPosition), :266, :286, :325, :329 */
+    float subsurf = -1.0f / sf.subsurface * o_log(1.0f - uniform_sample(&s));
     v3 sdir = vnormalize(sphere_sample(&s));
     sdir = V(gl_mix(dir.x, sdir.x, 1.0f), gl_mix(dir.y, sdir.y, 1.0f), gl_mix(dir.z, sdir.z, 1.0f));
     sdir = vnormalize(sdir);
@@ -669,7 +731,7 @@ static void pixel_main(const RmSceneDesc* sc, const RmUniforms* u, int W, int H,
       specular_col = V(1, 1, 1);
       prev_dir = dir;
     } else if (scene_sdf(sc, subsurf_pos) > 0.001f) { /* :284-288 */
-      albedo = vmul(albedo, V(sc->material.subsurface_color[0], sc->material.subsurface_color[1], sc->material.subsurface_color[2]));
+      albedo = vmul(albedo, V(sf.subsurface_color[0], sf.subsurface_color[1], sf.subsurface_color[2]));
       pos = subsurf_pos;
       v3 sp = sphere_sample(&s);
       dir = vnormalize(V(gl_mix(dir.x, sp.x, 1.0f), gl_mix(dir.y, sp.y, 1.0f), gl_mix(dir.z, sp.z, 1.0f)));
@@ -684,13 +746,13 @@ static void pixel_main(const RmSceneDesc* sc, const RmUniforms* u, int W, int H,
         dir = vscale(nd, gl_sign(vdot(normal, nd)));
       } else { /* specular, :322-330 */
         FL(1);
-        float f = gl_clamp(schlick(-vdot(dir, normal), 1.0f, sc->material.ior), 0.0f, 1.0f);
+        float f = gl_clamp(schlick(-vdot(dir, normal), 1.0f, sf.ior), 0.0f, 1.0f);
         albedo = vmul(albedo, vscale(specular_col, f));
         v3 rv = sphere_sample(&s);
         dir = vreflect(dir, normal);
         v3 axis = vnormalize(vcross(rv, dir));
         FL(1);
-        dir = rodrigues(dir, axis, sc->material.roughness * uniform_sample(&s));
+        dir = rodrigues(dir, axis, sf.roughness * uniform_sample(&s));
       }
     }
     pos = vadd(pos, vscale(dir, 0.001f)); /* :334 */
@@ -719,7 +781,7 @@ static void pixel_main(const RmSceneDesc* sc, const RmUniforms* u, int W, int H,
       FL(1);
       if (vdistance(result, adj) >= vdistance(pos, adj)) {
         float r = gl_max(0.0f, vdot(to_light, vreflect(prev_dir, normal)));
-        float rough = sc->material.roughness;
+        float rough = surface_at(sc, pos).roughness; /* sceneSpecularRoughness(rayPosition) at the MOVED position, :366 */
         float ndl = gl_max(0.0f, vdot(to_light, normal));
         FL(9);
         float denom = gl_pow(r * r * (rough * rough - 1.0f) + 1.0f, 2.0f);
@@ -829,7 +891,7 @@ void or_material(const RmSceneDesc* sc, const float* p, int n, float* out) {
     float* o = out + 12 * i;
     o[0] = d.x; o[1] = d.y; o[2] = d.z; o[3] = s.x; o[4] = s.y; o[5] = s.z;
     o[6] = e.x; o[7] = e.y; o[8] = e.z;
-    o[9] = sc->material.roughness; o[10] = sc->material.subsurface; o[11] = sc->material.ior;
+    { const OSurface f = surface_at(sc, q); o[9] = f.roughness; o[10] = f.subsurface; o[11] = f.ior; }
   }
 }
 

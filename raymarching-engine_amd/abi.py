@@ -78,6 +78,20 @@ class RmMaterial(C.Structure):
     ]
 
 
+RM_MAX_SURFACES = 15
+
+
+class RmSurface(C.Structure):
+    _fields_ = [
+        ("diffuse", C.c_float * 3),
+        ("roughness", C.c_float),
+        ("specular", C.c_float * 3),
+        ("subsurface", C.c_float),
+        ("subsurface_color", C.c_float * 3),
+        ("ior", C.c_float),
+    ]
+
+
 class RmSceneDesc(C.Structure):
     _fields_ = [
         ("kind", C.c_int32),
@@ -85,6 +99,9 @@ class RmSceneDesc(C.Structure):
         ("prims", C.POINTER(RmPrim)),
         ("params", C.c_float * 16),
         ("material", RmMaterial),
+        ("nsurfaces", C.c_int32),
+        ("reserved", C.c_int32),
+        ("surfaces", C.POINTER(RmSurface)),
     ]
 
 
@@ -92,4 +109,4 @@ class RmRect(C.Structure):
     _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("w", C.c_int32), ("h", C.c_int32)]
 
 
-assert C.sizeof(RmPrim) == 32
+assert C.sizeof(RmPrim) == 32 and C.sizeof(RmSurface) == 48

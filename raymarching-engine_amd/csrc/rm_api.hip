@@ -110,6 +110,7 @@ struct rm_scene {
   rm_ctx* ctx = nullptr;
   DevScene dev{};
   RmPrim* d_prims = nullptr;
+  RmSurface* d_surfaces = nullptr;
 };
 
 struct rm_fb {
@@ -348,6 +349,12 @@ int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out) {
   }
   if (!finite_all(desc->params, 16)) return fail(ctx, RM_ERR_INVALID, "scene: non-finite parameter");
   if (desc->material.sky_axis < 0 || desc->material.sky_axis > 2) return fail(ctx, RM_ERR_INVALID, "scene: material.sky_axis must be 0, 1 or 2");
+  if (desc->nsurfaces < 0 || desc->nsurfaces > RM_MAX_SURFACES || (desc->nsurfaces > 0 && (!desc->surfaces || desc->kind != RM_SCENE_TABLE))) {
+    std::snprintf(buf, sizeof buf, "scene: 0..%d surfaces, for a primitive table (got %d)", RM_MAX_SURFACES, desc->nsurfaces);
+    return fail(ctx, RM_ERR_INVALID, buf);
+  }
+  for (int i = 0; i < desc->nsurfaces; i++)
+    if (!finite_all(reinterpret_cast<const float*>(&desc->surfaces[i]), 12)) return fail(ctx, RM_ERR_INVALID, "scene: non-finite surface value");
   if (desc->kind == RM_SCENE_TABLE) {
     if (desc->nprims < 1 || desc->nprims > RM_MAX_PRIMS || !desc->prims) {
       std::snprintf(buf, sizeof buf, "scene: primitive table needs 1..%d rows (got %d)", RM_MAX_PRIMS, desc->nprims);
@@ -357,8 +364,13 @@ int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out) {
     for (int i = 0; i < desc->nprims; i++) {
       const RmPrim& p = desc->prims[i];
       const int type = p.type & 0xff, op = (p.type >> 8) & 0xff;
-      if (type > RM_PRIM_FOLD || op > RM_OP_INTERSECT || (p.type >> 16) != 0) {
+      if (type > RM_PRIM_FOLD || op > RM_OP_INTERSECT || (p.type >> 24) != 0) {
         std::snprintf(buf, sizeof buf, "scene: row %d: unknown primitive/operator 0x%x", i, p.type);
+        return fail(ctx, RM_ERR_INVALID, buf);
+      }
+      const int surface = (p.type >> 16) & 0xff;
+      if (surface > desc->nsurfaces || (surface != 0 && type != RM_PRIM_SPHERE && type != RM_PRIM_BOX)) {
+        std::snprintf(buf, sizeof buf, "scene: row %d: surface %d of %d (only shape rows name a surface)", i, surface, desc->nsurfaces);
         return fail(ctx, RM_ERR_INVALID, buf);
       }
       if (!finite_all(p.center, 3) || !finite_all(p.size, 3) || !std::isfinite(p.k)) {
@@ -396,14 +408,16 @@ int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out) {
   s->dev.kind = desc->kind;
   s->dev.nprims = desc->kind == RM_SCENE_TABLE ? desc->nprims : 0;
   if (desc->kind == RM_SCENE_TABLE) {
-    bool spheres_smooth = true, domain = false, boxes = false;
+    bool spheres_smooth = true, domain = false, boxes = false, surfaces = false;
     for (int i = 0; i < desc->nprims; i++) {
       const int type = desc->prims[i].type & 0xff, op = (desc->prims[i].type >> 8) & 0xff;
+      if (((desc->prims[i].type >> 16) & 0xff) != 0) surfaces = true;
       if (type != RM_PRIM_SPHERE || (i > 0 && op != RM_OP_SMOOTH_UNION)) spheres_smooth = false;
       if (type == RM_PRIM_REPEAT || type == RM_PRIM_FOLD) domain = true;
       if (type == RM_PRIM_BOX) boxes = true;
     }
-    s->dev.table_flags = (spheres_smooth ? RM_TABLE_SPHERES_SMOOTH : 0) | (domain ? RM_TABLE_HAS_DOMAIN : 0) | (boxes ? 0 : RM_TABLE_NO_BOXES);
+    s->dev.table_flags = (spheres_smooth ? RM_TABLE_SPHERES_SMOOTH : 0) | (domain ? RM_TABLE_HAS_DOMAIN : 0) | (boxes ? 0 : RM_TABLE_NO_BOXES) |
+                         (surfaces ? RM_TABLE_HAS_SURFACES : 0);
     if (spheres_smooth && desc->nprims >= 2 && desc->nprims * 3 <= RM_MAX_PRIMS * 2) {  // one smooth-union radius for the whole table (the usual case): it travels as a kernel argument, and a compact image of the rows fits behind them in LDS
       bool one_k = true;
       for (int i = 2; i < desc->nprims; i++) one_k = one_k && desc->prims[i].k == desc->prims[1].k;
@@ -428,6 +442,24 @@ int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out) {
     }
     s->dev.prims = s->d_prims;
   }
+  if (s->dev.table_flags & RM_TABLE_HAS_SURFACES) {  // entry 0 = the scene's own material block, then the surfaces as given
+    RmSurface all[RM_MAX_SURFACES + 1];
+    const RmMaterial& m = desc->material;
+    all[0] = RmSurface{{m.diffuse[0], m.diffuse[1], m.diffuse[2]}, m.roughness, {m.specular[0], m.specular[1], m.specular[2]}, m.subsurface,
+                       {m.subsurface_color[0], m.subsurface_color[1], m.subsurface_color[2]}, m.ior};
+    for (int i = 0; i < desc->nsurfaces; i++) all[i + 1] = desc->surfaces[i];
+    const size_t bytes = sizeof(RmSurface) * (size_t)(desc->nsurfaces + 1);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_surfaces), bytes);
+    if (e == hipSuccess) e = hipMemcpy(s->d_surfaces, all, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      if (s->d_surfaces) (void)hipFree(s->d_surfaces);
+      if (s->d_prims) (void)hipFree(s->d_prims);
+      delete s;
+      return fail(ctx, RM_ERR_DEVICE, std::string("rm_scene_create: ") + hipGetErrorString(e));
+    }
+    s->dev.surfaces = s->d_surfaces;
+    s->dev.nsurfaces = desc->nsurfaces;
+  }
   *out = s;
   return RM_OK;
 }
@@ -437,6 +469,7 @@ void rm_scene_destroy(rm_scene* scene) {
   (void)hipSetDevice(scene->ctx->device);
   (void)hipStreamSynchronize(scene->ctx->stream);
   if (scene->d_prims) (void)hipFree(scene->d_prims);
+  if (scene->d_surfaces) (void)hipFree(scene->d_surfaces);
   delete scene;
 }
 
@@ -860,8 +893,18 @@ static hipError_t launch_wavefront(rm_ctx* ctx, const KParams& P, int flags) {
 static bool prefer_wavefront(const KParams& P, int flags) {
   (void)flags;
   if (P.u.renderMode == 1) return false;
+  if (P.scene.table_flags & RM_TABLE_HAS_SURFACES) return false;  // (see uses_wavefront)
   if ((long long)P.tw * (long long)P.th < (1ll << 23)) return false;
   return P.scene.kind == RM_SCENE_TABLE && P.scene.nprims >= 16;
+}
+
+// The implementation a render call uses.  The GL-stack arithmetic exists as the pixel kernel only, and so do
+// position-dependent materials (RM_TABLE_HAS_SURFACES): the pipeline's stages carry one material block per scene -- its light
+// stage has no scene table staged -- so such scenes render with the pixel kernel whatever the flags ask for (same results).
+static bool uses_wavefront(const rm_ctx* ctx, const KParams& P, int flags) {
+  if (ctx->gl_stack && !(flags & RM_RENDER_FAST)) return false;
+  if (P.scene.table_flags & RM_TABLE_HAS_SURFACES) return false;
+  return (flags & RM_RENDER_WAVEFRONT) ? true : (flags & RM_RENDER_MEGAKERNEL) ? false : prefer_wavefront(P, flags);
 }
 
 static hipError_t launch_pixels_ordered(rm_ctx* ctx, const KParams& P, int flags, hipStream_t stream, int slot);
@@ -1021,8 +1064,7 @@ static hipError_t launch_pixels_ordered(rm_ctx* ctx, const KParams& P, int flags
 }
 
 static hipError_t launch(rm_ctx* ctx, const KParams& P, int flags) {
-  const bool gl = ctx->gl_stack && !(flags & RM_RENDER_FAST);  // the GL-stack arithmetic exists as the pixel kernel only
-  const bool wavefront = gl ? false : (flags & RM_RENDER_WAVEFRONT) ? true : (flags & RM_RENDER_MEGAKERNEL) ? false : prefer_wavefront(P, flags);
+  const bool wavefront = uses_wavefront(ctx, P, flags);
   ctx->last_pipeline = wavefront ? RM_PIPELINE_WAVEFRONT : RM_PIPELINE_PIXEL_KERNEL;
   if (wavefront) return launch_wavefront(ctx, P, flags);
   // full mode with at least one bounce: the kernel's only use of the planes is the final blend, which can be split off
@@ -1053,8 +1095,7 @@ int rm_render_samples(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms*
   if (empty) return RM_OK;
   RM_HIP(ctx, hipSetDevice(ctx->device));
   // Samples the pixel kernel can stage (the conditions of launch()) go out in batches: one launch per batch.
-  const bool gl = ctx->gl_stack && !(flags & RM_RENDER_FAST);  // the GL-stack arithmetic exists as the pixel kernel only
-  const bool wavefront = gl ? false : (flags & RM_RENDER_WAVEFRONT) ? true : (flags & RM_RENDER_MEGAKERNEL) ? false : prefer_wavefront(P, flags);
+  const bool wavefront = uses_wavefront(ctx, P, flags);
   const bool stageable = !wavefront && !(flags & RM_RENDER_NO_OVERLAP) && P.u.renderMode == 0 && P.u.reflections > 0.0f;
   int per_launch = 1;
   if (stageable && ctx->sample_batch != 1) {

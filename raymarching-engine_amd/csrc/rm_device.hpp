@@ -319,6 +319,7 @@ RM_DEV bool is_neg_zero(float x) { return __float_as_uint(x) == 0x80000000u; }
 // the iterated fractal kinds, the per-level scale factors pow(scale, i).
 struct SceneLds {
   float4 rows[RM_MAX_PRIMS * 2];
+  float4 surf[(RM_MAX_SURFACES + 1) * 3];  // RM_TABLE_HAS_SURFACES: the surfaces' values, 3 x float4 each ([0] = the scene's material block)
 };
 
 // :74-76
@@ -358,6 +359,10 @@ struct Sdf<RM_SCENE_TABLE> {
         const float4 a = src[2 * i], b = src[2 * i + 1];
         lds.rows[2 * sc.nprims + i] = make_float4(a.z, a.w, b.x, b.y);
       }
+    }
+    if (sc.table_flags & RM_TABLE_HAS_SURFACES) {
+      const float4* ssrc = reinterpret_cast<const float4*>(sc.surfaces);
+      for (int i = threadIdx.x; i < (sc.nsurfaces + 1) * 3; i += blockDim.x) lds.surf[i] = ssrc[i];
     }
     for (int i = threadIdx.x; i < sc.nprims * 2; i += blockDim.x) {
       float4 v = src[i];
@@ -433,6 +438,42 @@ struct Sdf<RM_SCENE_TABLE> {
     PM::sincos(ang.z, s, c);
     nx = M::fma(q.z, -s, q.x * c); ny = M::fma(q.z, c, q.x * s); q.x = nx; q.z = ny;
     return q;
+  }
+  // Which surface the material functions use at p (RM_TABLE_HAS_SURFACES; include/hip_raymarch.h RmSurface): the one the
+  // shape row with the smallest distance term names -- the terms of eval()'s fold, row by row, before their operators --
+  // the earliest row on a tie; a NaN term never wins (`<` is false), so a point whose terms are all NaN has the first
+  // shape row's surface.  The composer emits the same loop as GLSL (scene.py rmSurfaceIndex).
+  template <class M>
+  static RM_DEV int surface_index(const DevScene& sc, const SceneLds& lds, v3 p) {
+    const bool domain = (sc.table_flags & RM_TABLE_HAS_DOMAIN) != 0;  // kernel-uniform
+    float best = 0.0f, factor = 1.0f;
+    int surface = 0;
+    bool first = true;
+    v3 q = p;
+    const int n = sc.nprims;
+    for (int i = 0; i < n; i++) {
+      const float4 a = lds.rows[2 * i];
+      float4 b = lds.rows[2 * i + 1];
+      const int type = __builtin_amdgcn_readfirstlane(__float_as_int(a.x));
+      const v3 c = V(a.z, a.w, b.x);
+      const int prim = type & 0xff;
+      if (domain && prim == RM_PRIM_REPEAT) {
+        q = V(gmod<M>(q.x + 0.5f * b.y, b.y) - 0.5f * b.y, gmod<M>(q.y + 0.5f * b.z, b.z) - 0.5f * b.z, gmod<M>(q.z + 0.5f * b.w, b.w) - 0.5f * b.w);
+        continue;
+      }
+      if (domain && prim == RM_PRIM_FOLD) {
+        q = fold_row<M>(q, a.y, c, V(b.y, b.z, b.w));
+        factor = factor * a.y;
+        continue;
+      }
+      float di;
+      if (prim == RM_PRIM_SPHERE) di = sdf_sphere<M>(q, c, b.y);
+      else di = sd_box<M>(q - c, V(b.y, b.z, b.w));
+      if (domain) di = di * factor;
+      if (first || di < best) { best = di; surface = (type >> 16) & 0xff; }
+      first = false;
+    }
+    return surface;
   }
   template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds& lds, v3 p) {
@@ -861,6 +902,17 @@ struct Sdf<RM_SCENE_KIFS_BOX> {
 
 RM_DEV v3 cut_color(const float* col, float cutoff, v3 p) {
   return length<PM>(p) > cutoff ? V(0.0f, 0.0f, 0.0f) : V(col[0], col[1], col[2]);
+}
+RM_DEV v3 cut_color(v3 col, float cutoff, v3 p) { return length<PM>(p) > cutoff ? V(0.0f, 0.0f, 0.0f) : col; }
+// the values of the material functions that can depend on the shape (RmSurface); the cut-offs and the sky are the scene's
+struct Surface {
+  v3 diffuse, specular, subsurface_color;
+  float roughness, subsurface, ior;
+};
+RM_DEV Surface scene_surface(const DevScene& sc) {
+  const RmMaterial& m = sc.mat;
+  return Surface{V(m.diffuse[0], m.diffuse[1], m.diffuse[2]), V(m.specular[0], m.specular[1], m.specular[2]),
+                 V(m.subsurface_color[0], m.subsurface_color[1], m.subsurface_color[2]), m.roughness, m.subsurface, m.ior};
 }
 RM_DEV v3 scene_diffuse(const DevScene& sc, v3 p) { return cut_color(sc.mat.diffuse, sc.mat.diffuse_cutoff, p); }
 RM_DEV v3 scene_specular(const DevScene& sc, v3 p) { return cut_color(sc.mat.specular, sc.mat.specular_cutoff, p); }

@@ -10,6 +10,7 @@
 #define RM_TABLE_HAS_DOMAIN 2      /* the table has domain rows (RM_PRIM_REPEAT / RM_PRIM_FOLD) */
 #define RM_TABLE_NO_BOXES 8         /* no RM_PRIM_BOX row: the sdf of a point with a non-finite coordinate is itself non-finite */
 #define RM_TABLE_UNIFORM_K 4       /* RM_TABLE_SPHERES_SMOOTH with one k for every fold: k in p[0], 0.5 / k in p[1] */
+#define RM_TABLE_HAS_SURFACES 16   /* some shape row names a surface (RmPrim.type bits 16..23): the material functions depend on the position */
 
 #define RM_BATCH_MAX 8  /* samples one pixel-kernel launch can render (KParams::batch) */
 
@@ -21,6 +22,9 @@ struct DevScene {
   const RmPrim* prims;  // device pointer (RM_SCENE_TABLE)
   float p[16];
   RmMaterial mat;
+  const RmSurface* surfaces;  // device pointer: nsurfaces + 1 entries, [0] = the values of `mat` (RM_TABLE_HAS_SURFACES)
+  int nsurfaces;
+  int reserved2;
 };
 
 struct KParams {

@@ -9,11 +9,14 @@ export interface Material {
   diffuse: Vec3; diffuse_cutoff: number; specular: Vec3; specular_cutoff: number; roughness: number; subsurface: number;
   subsurface_color: Vec3; ior: number; sky_color: Vec3; sky_floor: number; sky_scale: number; sky_radius: number; sky_axis: 0 | 1 | 2;
 }
+/** material values a shape of a composed scene can have of its own (RmSurface); missing ones = the reference defaults */
+export interface Surface { diffuse?: Vec3; specular?: Vec3; roughness?: number; subsurface?: number; subsurface_color?: Vec3; ior?: number; }
 export class Scene { kind: number; params: number[]; material: Material; key(): string; }
 export class CsgScene extends Scene {
   constructor(material?: Partial<Material>);
   union(): this; smoothUnion(k: number): this; subtract(): this; intersect(): this;
-  sphere(center: Vec3, radius: number): this; box(center: Vec3, halfExtents: Vec3): this;
+  /** `surface`: the material functions then depend on the position -- at a point, the values of the nearest shape */
+  sphere(center: Vec3, radius: number, surface?: Surface): this; box(center: Vec3, halfExtents: Vec3, surface?: Surface): this;
   /** domain operators: transform the point the FOLLOWING primitives are evaluated at (sphere-grid.glsl's repeat; one level of tree.glsl's fold) */
   repeat(period: Vec3): this; fold(scale: number, offset: Vec3, angles?: Vec3): this;
   glsl(): string;

@@ -59,8 +59,8 @@ const glf = (x) => { const s = String(Math.fround(x)); return /[.e]/.test(s) ? s
 const glv = (v) => `vec3(${glf(v[0])}, ${glf(v[1])}, ${glf(v[2])})`;
 
 class Scene {
-  constructor(kind, params, material) { this.kind = kind; this.params = params || []; this.material = Object.assign({}, DEFAULT_MATERIAL, material || {}); this.prims = []; }
-  // RmSceneDesc bytes: kind, nprims, prims pointer (8, filled natively), params[16], material (22 x 4)
+  constructor(kind, params, material) { this.kind = kind; this.params = params || []; this.material = Object.assign({}, DEFAULT_MATERIAL, material || {}); this.prims = []; this.surfaces = []; }
+  // RmSceneDesc bytes: kind, nprims, prims pointer (8, filled natively), params[16], material (22 x 4), nsurfaces, reserved, surfaces pointer (8, filled natively)
   desc() {
     const buf = new ArrayBuffer(addon.sizes().RmSceneDesc);
     const f = new Float32Array(buf), i = new Int32Array(buf);
@@ -70,15 +70,22 @@ class Scene {
     f.set([...m.diffuse, m.diffuse_cutoff, ...m.specular, m.specular_cutoff, m.roughness, m.subsurface, ...m.subsurface_color, m.ior,
            ...m.sky_color, m.sky_floor, m.sky_scale, m.sky_radius], at);
     i[at + 20] = m.sky_axis;
+    i[at + 22] = this.surfaces.length;
     let prims = null;
     if (this.prims.length) {
       prims = new ArrayBuffer(32 * this.prims.length);
       const pf = new Float32Array(prims), pi = new Int32Array(prims);
-      this.prims.forEach((p, n) => { pi[8 * n] = p.prim | (p.op << 8); pf[8 * n + 1] = p.k; pf.set(p.center, 8 * n + 2); pf.set(p.size, 8 * n + 5); });
+      this.prims.forEach((p, n) => { pi[8 * n] = p.prim | (p.op << 8) | ((p.surface || 0) << 16); pf[8 * n + 1] = p.k; pf.set(p.center, 8 * n + 2); pf.set(p.size, 8 * n + 5); });
     }
-    return { desc: buf, prims };
+    let surfaces = null;
+    if (this.surfaces.length) {  // RmSurface rows: diffuse[3], roughness, specular[3], subsurface, subsurface_color[3], ior
+      surfaces = new ArrayBuffer(48 * this.surfaces.length);
+      const sf = new Float32Array(surfaces);
+      this.surfaces.forEach((u, n) => sf.set([...u.diffuse, u.roughness, ...u.specular, u.subsurface, ...u.subsurface_color, u.ior], 12 * n));
+    }
+    return { desc: buf, prims, surfaces };
   }
-  key() { const d = this.desc(); return Buffer.from(d.desc).toString("hex") + (d.prims ? Buffer.from(d.prims).toString("hex") : ""); }
+  key() { const d = this.desc(); return Buffer.from(d.desc).toString("hex") + (d.prims ? Buffer.from(d.prims).toString("hex") : "") + (d.surfaces ? Buffer.from(d.surfaces).toString("hex") : ""); }
 }
 
 class CsgScene extends Scene {
@@ -87,8 +94,18 @@ class CsgScene extends Scene {
   smoothUnion(k) { this._op = RM.OP_SMOOTH_UNION; this._k = k; return this; }
   subtract() { this._op = RM.OP_SUBTRACT; this._k = 0; return this; }
   intersect() { this._op = RM.OP_INTERSECT; this._k = 0; return this; }
-  sphere(center, radius) { this.prims.push({ prim: RM.PRIM_SPHERE, op: this._op, k: this._k, center, size: [radius, 0, 0] }); return this; }
-  box(center, half) { this.prims.push({ prim: RM.PRIM_BOX, op: this._op, k: this._k, center, size: half }); return this; }
+  // `surface` (optional): material values of this shape's own -- {diffuse, specular, roughness, subsurface, subsurface_color, ior}, missing
+  // ones from the reference defaults (Validate.tsx:18-51); the material functions then depend on the position (materialGlsl)
+  _surface(surface) {
+    if (!surface) return 0;
+    const u = { diffuse: [0.6, 0.6, 0.6], specular: [0.6, 0.6, 0.6], roughness: 0.2, subsurface: 11111115, subsurface_color: [1, 1, 1], ior: 100, ...surface };
+    const same = (a, b) => JSON.stringify(a) === JSON.stringify(b);
+    let k = this.surfaces.findIndex((v) => same(v, u));
+    if (k < 0) { if (this.surfaces.length >= 15) throw new RangeError("a scene has at most 15 surfaces"); this.surfaces.push(u); k = this.surfaces.length - 1; }
+    return k + 1;
+  }
+  sphere(center, radius, surface) { this.prims.push({ prim: RM.PRIM_SPHERE, op: this._op, k: this._k, center, size: [radius, 0, 0], surface: this._surface(surface) }); return this; }
+  box(center, half, surface) { this.prims.push({ prim: RM.PRIM_BOX, op: this._op, k: this._k, center, size: half, surface: this._surface(surface) }); return this; }
   // domain operators (include/hip_raymarch.h): they transform the point the FOLLOWING primitives are evaluated at
   repeat(period) { this.prims.push({ prim: RM.PRIM_REPEAT, op: 0, k: 0, center: [0, 0, 0], size: period }); return this; }
   fold(scale, offset, angles = [0, 0, 0]) { this.prims.push({ prim: RM.PRIM_FOLD, op: 0, k: scale, center: offset, size: angles }); return this; }
@@ -119,6 +136,40 @@ class CsgScene extends Scene {
       else lines.push(`  d = max(d, ${e});`);
     });
     lines.push("  return d;", "}");
+    if (this.prims.some((n) => n.surface)) lines.push(this.materialGlsl());
+    return lines.join("\n");
+  }
+  // The seven material functions of a scene whose shapes name surfaces (scene.py material_glsl, statement for statement): at
+  // `position` the values of the shape row whose distance term there is the smallest (the earliest on a tie; a NaN never wins).
+  materialGlsl() {
+    const isShape = (n) => n.prim === RM.PRIM_SPHERE || n.prim === RM.PRIM_BOX;
+    const domain = this.prims.filter(isShape).length !== this.prims.length, q = domain ? "q" : "p", m = this.material;
+    const all = [{ diffuse: m.diffuse, specular: m.specular, roughness: m.roughness, subsurface: m.subsurface, subsurface_color: m.subsurface_color, ior: m.ior }, ...this.surfaces];
+    const n = all.length, lines = ["int rmSurfaceIndex(vec3 p) {"];
+    if (domain) lines.push("  vec3 q = p; float factor = 1.0;");
+    lines.push("  float best = 0.0; float di; int surface = 0;");
+    let first = true;
+    this.prims.forEach((node) => {
+      if (node.prim === RM.PRIM_REPEAT) { lines.push(`  q = mod(q + 0.5 * ${glv(node.size)}, ${glv(node.size)}) - 0.5 * ${glv(node.size)};`); return; }
+      if (node.prim === RM.PRIM_FOLD) { lines.push(`  q = rmFold(q, ${glf(node.k)}, ${glv(node.center)}, ${glv(node.size)}); factor = factor * ${glf(node.k)};`); return; }
+      let e = node.prim === RM.PRIM_SPHERE ? `sdfSphere(${q}, ${glv(node.center)}, ${glf(node.size[0])})` : `sdBox(${q} - ${glv(node.center)}, ${glv(node.size)})`;
+      if (domain) e = `(${e} * factor)`;
+      if (first) { lines.push(`  best = ${e}; surface = ${node.surface || 0};`); first = false; }
+      else lines.push(`  di = ${e}; if (di < best) { best = di; surface = ${node.surface || 0}; }`);
+    });
+    lines.push("  return surface;", "}");
+    const table = (name, typ, vals) => `const ${typ} ${name}[${n}] = ${typ}[${n}](${vals.join(", ")});`;
+    lines.push(table("rmDiffuse", "vec3", all.map((u) => glv(u.diffuse))), table("rmSpecular", "vec3", all.map((u) => glv(u.specular))),
+      table("rmSubsurfaceColor", "vec3", all.map((u) => glv(u.subsurface_color))), table("rmRoughness", "float", all.map((u) => glf(u.roughness))),
+      table("rmSubsurface", "float", all.map((u) => glf(u.subsurface))), table("rmIor", "float", all.map((u) => glf(u.ior))),
+      `vec3 sceneDiffuseColor(vec3 position) { if (length(position) > ${glf(m.diffuse_cutoff)}) return vec3(0.0); return rmDiffuse[rmSurfaceIndex(position)]; }`,
+      `vec3 sceneSpecularColor(vec3 position) { if (length(position) > ${glf(m.specular_cutoff)}) return vec3(0.0); return rmSpecular[rmSurfaceIndex(position)]; }`,
+      "float sceneSpecularRoughness(vec3 position) { return rmRoughness[rmSurfaceIndex(position)]; }",
+      "float sceneSubsurfaceScattering(vec3 position) { return rmSubsurface[rmSurfaceIndex(position)]; }",
+      "vec3 sceneSubsurfaceScatteringColor(vec3 position) { return rmSubsurfaceColor[rmSurfaceIndex(position)]; }",
+      "float sceneIOR(vec3 position) { return rmIor[rmSurfaceIndex(position)]; }",
+      `vec3 sceneEmission(vec3 position) { float d = max(normalize(position).${"xyz"[m.sky_axis]}, ${glf(m.sky_floor)}); vec3 brightColor = ${glv(m.sky_color)} * d * 1.0;` +
+      ` return (length(position) > ${glf(m.sky_radius)}) ? (brightColor * ${glf(m.sky_scale)}) : vec3(0.0); }`);
     return lines.join("\n");
   }
 }
@@ -169,7 +220,7 @@ class RenderJobContext {  // RenderJobContext + loadRenderJobContext (LoadRender
   getScene(scene) {  // programCache.getProgram: results AND errors are cached (ShaderCache.tsx:91-119)
     const key = scene.key();
     if (!this.scenes.has(key)) {
-      try { const d = scene.desc(); this.scenes.set(key, addon.sceneCreate(this.ctx, d.desc, d.prims)); }
+      try { const d = scene.desc(); this.scenes.set(key, addon.sceneCreate(this.ctx, d.desc, d.prims, d.surfaces)); }
       catch (e) { this.scenes.set(key, { type: "fragment", infoLog: String(e.message) }); }
     }
     return this.scenes.get(key);
@@ -222,7 +273,7 @@ class ShardedRenderJobContext {
     const key = scene.key();
     if (!this.scenes.has(key)) {
       const made = [];
-      try { const d = scene.desc(); for (const c of this.ctxs) made.push(addon.sceneCreate(c, d.desc, d.prims)); this.scenes.set(key, { handles: made }); }
+      try { const d = scene.desc(); for (const c of this.ctxs) made.push(addon.sceneCreate(c, d.desc, d.prims, d.surfaces)); this.scenes.set(key, { handles: made }); }
       catch (e) { for (const h of made) addon.sceneDestroy(h); this.scenes.set(key, { type: "fragment", infoLog: String(e.message) }); }
     }
     return this.scenes.get(key);

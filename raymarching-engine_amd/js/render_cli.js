@@ -26,6 +26,16 @@ const rm = require("./index.js");
     process.stdout.write(JSON.stringify({ prims: Buffer.from(d.prims).toString("hex"), glsl: sc.glsl() }));
     return;
   }
+  if (mode === "surfaces") {  // no GPU needed: a scene whose shapes name surfaces, as the table, the surface rows and GLSL
+    const sc = new rm.CsgScene().box([0, 0, 0], [1.0, 0.5, 0.75]).smoothUnion(0.25)
+      .sphere([-1.25, 0.25, 0.0], 0.5, { diffuse: [0.875, 0.125, 0.125], specular: [0.25, 0.25, 0.25], roughness: 0.5 })
+      .union().sphere([1.25, 0.125, -0.25], 0.625, { diffuse: [0.125, 0.25, 0.875], specular: [0.75, 0.75, 0.75], roughness: 0.0625, ior: 1.5 })
+      .sphere([0.0, 1.0, 0.0], 0.5, { diffuse: [0.5, 0.75, 0.5], specular: [0.5, 0.5, 0.5], subsurface: 4.0, subsurface_color: [0.875, 0.5, 0.25] })
+      .subtract().box([0.0, 1.0, -0.5], [0.25, 0.25, 0.25], { diffuse: [0.75, 0.75, 0.125], specular: [0.125, 0.125, 0.125], roughness: 0.75 });
+    const d = sc.desc();
+    process.stdout.write(JSON.stringify({ desc: Buffer.from(d.desc).toString("hex"), prims: Buffer.from(d.prims).toString("hex"), surfaces: Buffer.from(d.surfaces).toString("hex"), glsl: sc.glsl() }));
+    return;
+  }
   if (mode === "fbo") {  // no GPU needed: RenderJobContext.fboCreate / fboDelete over the operations of tests/golden/fbo_reference.json
     const fx = JSON.parse(fs.readFileSync(process.argv[4]).toString());
     const a = rm.addon;

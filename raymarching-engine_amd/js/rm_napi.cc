@@ -114,8 +114,8 @@ static napi_value Sync(napi_env env, napi_callback_info info) {
 
 // sceneCreate(ctx, descBuffer /* RmSceneDesc bytes, prims pointer ignored */, primsBuffer | null)
 static napi_value SceneCreate(napi_env env, napi_callback_info info) {
-  size_t argc = 3;
-  napi_value argv[3];
+  size_t argc = 4;
+  napi_value argv[4];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
   rm_ctx* ctx = get_external<rm_ctx>(env, argv[0]);
   void* d = nullptr;
@@ -135,6 +135,20 @@ static napi_value SceneCreate(napi_env env, napi_callback_info info) {
       return nullptr;
     }
     desc.prims = static_cast<const RmPrim*>(p);
+  }
+  // sceneCreate(ctx, desc, prims | null, surfaces | null): RmSurface rows (48 bytes each), desc.nsurfaces of them
+  desc.surfaces = nullptr;
+  void* sf = nullptr;
+  size_t sn = 0;
+  if (argc > 3 && get_buffer(env, argv[3], &sf, &sn)) {
+    if (sn != sizeof(RmSurface) * (size_t)desc.nsurfaces) {
+      napi_throw_type_error(env, nullptr, "sceneCreate: surfaces buffer must hold nsurfaces rows of 48 bytes");
+      return nullptr;
+    }
+    desc.surfaces = static_cast<const RmSurface*>(sf);
+  } else if (desc.nsurfaces != 0) {
+    napi_throw_type_error(env, nullptr, "sceneCreate: desc.nsurfaces is set but no surfaces buffer was given");
+    return nullptr;
   }
   rm_scene* scene = nullptr;
   if (rm_scene_create(ctx, &desc, &scene) != RM_OK) return throw_rm(env, ctx, "rm_scene_create");
@@ -402,7 +416,7 @@ static napi_value Sizes(napi_env env, napi_callback_info) {
   NAPI_OK(napi_create_object(env, &o));
   const struct { const char* k; uint32_t v; } items[] = {
       {"RmUniforms", (uint32_t)sizeof(RmUniforms)}, {"RmSceneDesc", (uint32_t)sizeof(RmSceneDesc)}, {"RmPrim", (uint32_t)sizeof(RmPrim)},
-      {"RmMaterial", (uint32_t)sizeof(RmMaterial)}, {"RmRect", (uint32_t)sizeof(RmRect)}, {"abi", (uint32_t)rm_abi_version()}};
+      {"RmMaterial", (uint32_t)sizeof(RmMaterial)}, {"RmRect", (uint32_t)sizeof(RmRect)}, {"RmSurface", (uint32_t)sizeof(RmSurface)}, {"abi", (uint32_t)rm_abi_version()}};
   for (const auto& it : items) {
     NAPI_OK(napi_create_uint32(env, it.v, &v));
     NAPI_OK(napi_set_named_property(env, o, it.k, v));

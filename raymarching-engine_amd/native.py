@@ -157,7 +157,8 @@ def scene_key(scene: Scene) -> bytes:
     by the source string, ShaderCache.tsx:91-119)."""
     d = scene.desc()
     prims = bytes(C.string_at(d.prims, C.sizeof(abi.RmPrim) * d.nprims)) if d.nprims else b""
-    return bytes([d.kind & 0xFF]) + bytes(d.params) + bytes(d.material) + prims
+    surfaces = bytes(C.string_at(d.surfaces, C.sizeof(abi.RmSurface) * d.nsurfaces)) if d.nsurfaces else b""
+    return bytes([d.kind & 0xFF]) + bytes(d.params) + bytes(d.material) + prims + surfaces
 
 
 def _fp(a: np.ndarray):

@@ -106,6 +106,31 @@ class Material:
         )
 
 
+@dataclass
+class Surface:
+    """The material values a shape of a composed scene can have of its own (RmSurface): the reference's material
+    contract is seven functions of POSITION (Validate.tsx:18-51, examples/guide.glsl:51-88), and for a CsgScene whose shapes
+    name surfaces they return, at a position, the values of the nearest shape (CsgScene.material_glsl).  The cut-off radii
+    and the sky stay the scene's (Material)."""
+
+    diffuse: Sequence[float] = (0.6, 0.6, 0.6)
+    specular: Sequence[float] = (0.6, 0.6, 0.6)
+    roughness: float = 0.2
+    subsurface: float = 11111115.0
+    subsurface_color: Sequence[float] = (1.0, 1.0, 1.0)
+    ior: float = 100.0
+
+    def to_c(self) -> abi.RmSurface:
+        f = abi.RmSurface()
+        f.diffuse[:] = list(self.diffuse)
+        f.specular[:] = list(self.specular)
+        f.roughness = self.roughness
+        f.subsurface = self.subsurface
+        f.subsurface_color[:] = list(self.subsurface_color)
+        f.ior = self.ior
+        return f
+
+
 class Scene:
     """Base: a scene kind with parameters and a material."""
 
@@ -130,6 +155,9 @@ class Scene:
         emitted GLSL bakes its parameters as literals, so: none)."""
         return {}
 
+    def surfaces(self) -> List["Surface"]:
+        return []
+
     def desc(self) -> abi.RmSceneDesc:
         d = abi.RmSceneDesc()
         d.kind = self.kind
@@ -139,6 +167,12 @@ class Scene:
             arr = (abi.RmPrim * len(prims))(*prims)
             d.prims = C.cast(arr, C.POINTER(abi.RmPrim))
             d._keepalive = arr  # the desc borrows the table
+        surfaces = self.surfaces()
+        d.nsurfaces = len(surfaces)
+        if surfaces:
+            sarr = (abi.RmSurface * len(surfaces))(*[f.to_c() for f in surfaces])
+            d.surfaces = C.cast(sarr, C.POINTER(abi.RmSurface))
+            d._keepalive_surfaces = sarr
         p = self.params()
         for i, v in enumerate(p):
             d.params[i] = v
@@ -156,6 +190,7 @@ class _Node:
     k: float
     center: Sequence[float]
     size: Sequence[float]
+    surface: int = 0  # 0 = the scene's material; k = the k-th Surface given to the scene's shapes
 
 
 class CsgScene(Scene):
@@ -184,6 +219,22 @@ class CsgScene(Scene):
         self._nodes: List[_Node] = []
         self._op = abi.RM_OP_UNION
         self._k = 0.0
+        self._surfaces: List[Surface] = []
+
+    def _surface(self, surface: Optional[Surface]) -> int:
+        """The index a shape row carries for `surface` (0 = none: the scene's material block)."""
+        if surface is None:
+            return 0
+        for i, f in enumerate(self._surfaces):
+            if f == surface:
+                return i + 1
+        if len(self._surfaces) >= abi.RM_MAX_SURFACES:
+            raise ValueError(f"a scene has at most {abi.RM_MAX_SURFACES} surfaces")
+        self._surfaces.append(surface)
+        return len(self._surfaces)
+
+    def surfaces(self) -> List[Surface]:
+        return list(self._surfaces)
 
     def union(self):
         self._op, self._k = abi.RM_OP_UNION, 0.0
@@ -201,12 +252,13 @@ class CsgScene(Scene):
         self._op, self._k = abi.RM_OP_INTERSECT, 0.0
         return self
 
-    def sphere(self, center: Sequence[float], radius: float):
-        self._nodes.append(_Node(abi.RM_PRIM_SPHERE, self._op, self._k, tuple(center), (radius, 0.0, 0.0)))
+    def sphere(self, center: Sequence[float], radius: float, surface: Optional[Surface] = None):
+        """`surface`: material values of this shape's own (Surface); the material functions then depend on the position."""
+        self._nodes.append(_Node(abi.RM_PRIM_SPHERE, self._op, self._k, tuple(center), (radius, 0.0, 0.0), self._surface(surface)))
         return self
 
-    def box(self, center: Sequence[float], half_extents: Sequence[float]):
-        self._nodes.append(_Node(abi.RM_PRIM_BOX, self._op, self._k, tuple(center), tuple(half_extents)))
+    def box(self, center: Sequence[float], half_extents: Sequence[float], surface: Optional[Surface] = None):
+        self._nodes.append(_Node(abi.RM_PRIM_BOX, self._op, self._k, tuple(center), tuple(half_extents), self._surface(surface)))
         return self
 
     def repeat(self, period: Sequence[float]):
@@ -223,7 +275,7 @@ class CsgScene(Scene):
         out = []
         for n in self._nodes:
             p = abi.RmPrim()
-            p.type = n.prim | (n.op << 8)
+            p.type = n.prim | (n.op << 8) | (n.surface << 16)
             p.k = n.k
             p.center[:] = list(n.center)
             p.size[:] = list(n.size)
@@ -252,24 +304,10 @@ class CsgScene(Scene):
                 " return q; }"
             )
         lines.append("float sdf(vec3 p) {")
-        q = "p"
         if domain:
             lines.append("  vec3 q = p; float factor = 1.0; float d;")
-            q = "q"
         first = True
-        for n in self._nodes:
-            if n.prim == abi.RM_PRIM_REPEAT:
-                lines.append(f"  q = mod(q + 0.5 * {_v3(n.size)}, {_v3(n.size)}) - 0.5 * {_v3(n.size)};")
-                continue
-            if n.prim == abi.RM_PRIM_FOLD:
-                lines.append(f"  q = rmFold(q, {_f(n.k)}, {_v3(n.center)}, {_v3(n.size)}); factor = factor * {_f(n.k)};")
-                continue
-            if n.prim == abi.RM_PRIM_SPHERE:
-                e = f"sdfSphere({q}, {_v3(n.center)}, {_f(n.size[0])})"
-            else:
-                e = f"sdBox({q} - {_v3(n.center)}, {_v3(n.size)})"
-            if domain:
-                e = f"({e} * factor)"
+        for n, e in self._terms(lines, domain):
             if first:
                 lines.append(f"  d = {e};" if domain else f"  float d = {e};")
                 first = False
@@ -284,6 +322,77 @@ class CsgScene(Scene):
         lines.append("  return d;")
         lines.append("}")
         return "\n".join(lines)
+
+    def _terms(self, lines: List[str], domain: bool):
+        """The shape rows in table order with the GLSL expression of each one's distance term; the statements of the domain
+        rows in between are appended to `lines` as they come (they act on `q` / `factor`)."""
+        q = "q" if domain else "p"
+        for n in self._nodes:
+            if n.prim == abi.RM_PRIM_REPEAT:
+                lines.append(f"  q = mod(q + 0.5 * {_v3(n.size)}, {_v3(n.size)}) - 0.5 * {_v3(n.size)};")
+                continue
+            if n.prim == abi.RM_PRIM_FOLD:
+                lines.append(f"  q = rmFold(q, {_f(n.k)}, {_v3(n.center)}, {_v3(n.size)}); factor = factor * {_f(n.k)};")
+                continue
+            if n.prim == abi.RM_PRIM_SPHERE:
+                e = f"sdfSphere({q}, {_v3(n.center)}, {_f(n.size[0])})"
+            else:
+                e = f"sdBox({q} - {_v3(n.center)}, {_v3(n.size)})"
+            if domain:
+                e = f"({e} * factor)"
+            yield n, e
+
+    def material_glsl(self) -> str:
+        """The seven material functions of a scene whose shapes name surfaces: at `position` the values of the shape row
+        whose distance term there is the smallest (rmSurfaceIndex: the terms of sdf()'s fold before their operators; the
+        earliest row on a tie, a NaN never wins) -- the rule the kernel and the oracle implement (rm_device.hpp
+        surface_index).  Cut-offs and the sky are the scene's."""
+        m = self.material
+        shapes = [n for n in self._nodes if n.prim in (abi.RM_PRIM_SPHERE, abi.RM_PRIM_BOX)]
+        domain = len(shapes) != len(self._nodes)
+        all_surfaces = [Surface(m.diffuse, m.specular, m.roughness, m.subsurface, m.subsurface_color, m.ior)] + self._surfaces
+        n = len(all_surfaces)
+        lines = ["int rmSurfaceIndex(vec3 p) {"]
+        if domain:
+            lines.append("  vec3 q = p; float factor = 1.0;")
+        lines.append("  float best = 0.0; float di; int surface = 0;")
+        first = True
+        for node, e in self._terms(lines, domain):
+            if first:
+                lines.append(f"  best = {e}; surface = {node.surface};")
+                first = False
+            else:
+                lines.append(f"  di = {e}; if (di < best) {{ best = di; surface = {node.surface}; }}")
+        lines += ["  return surface;", "}"]
+
+        def table(name, typ, values):
+            return f"const {typ} {name}[{n}] = {typ}[{n}](" + ", ".join(values) + ");"
+
+        lines += [
+            table("rmDiffuse", "vec3", [_v3(f.diffuse) for f in all_surfaces]),
+            table("rmSpecular", "vec3", [_v3(f.specular) for f in all_surfaces]),
+            table("rmSubsurfaceColor", "vec3", [_v3(f.subsurface_color) for f in all_surfaces]),
+            table("rmRoughness", "float", [_f(f.roughness) for f in all_surfaces]),
+            table("rmSubsurface", "float", [_f(f.subsurface) for f in all_surfaces]),
+            table("rmIor", "float", [_f(f.ior) for f in all_surfaces]),
+            f"vec3 sceneDiffuseColor(vec3 position) {{ if (length(position) > {_f(m.diffuse_cutoff)}) return vec3(0.0); return rmDiffuse[rmSurfaceIndex(position)]; }}",
+            f"vec3 sceneSpecularColor(vec3 position) {{ if (length(position) > {_f(m.specular_cutoff)}) return vec3(0.0); return rmSpecular[rmSurfaceIndex(position)]; }}",
+            "float sceneSpecularRoughness(vec3 position) { return rmRoughness[rmSurfaceIndex(position)]; }",
+            "float sceneSubsurfaceScattering(vec3 position) { return rmSubsurface[rmSurfaceIndex(position)]; }",
+            "vec3 sceneSubsurfaceScatteringColor(vec3 position) { return rmSubsurfaceColor[rmSurfaceIndex(position)]; }",
+            "float sceneIOR(vec3 position) { return rmIor[rmSurfaceIndex(position)]; }",
+        ]
+        ax = "xyz"[m.sky_axis]
+        lines.append("vec3 sceneEmission(vec3 position) {"
+                     f" float d = max(normalize(position).{ax}, {_f(m.sky_floor)});"
+                     f" vec3 brightColor = {_v3(m.sky_color)} * d * 1.0;"
+                     f" return (length(position) > {_f(m.sky_radius)}) ? (brightColor * {_f(m.sky_scale)}) : vec3(0.0); }}")
+        return "\n".join(lines)
+
+    def glsl(self) -> str:
+        if any(n.surface for n in self._nodes):
+            return self.sdf_glsl() + "\n" + self.material_glsl() + "\n"
+        return super().glsl()
 
 
 def single_sphere(center=(0.0, 0.0, 0.0), radius=1.0, material: Optional[Material] = None) -> CsgScene:

@@ -54,6 +54,17 @@ SCENES = {
         .box((0, 0, 0), (1.0, 0.1, 0.1)).union().sphere((0.0, 0.0, 0.0), 0.3),
         None,
     ),
+    # round 3: shapes with surfaces of their own -- the material functions depend on the position (RmSurface; the composer emits
+    # rmSurfaceIndex + the seven functions): a matte red sphere smooth-joined to the scene-material box, a glossy blue one with a
+    # finite ior, and a scattering one (subsurface mean free path 1/4, tinted) carved by a subtracted box that names a fourth
+    "csg_surfaces": (
+        lambda: S.CsgScene().box((0, 0, 0), (1.0, 0.5, 0.75)).smooth_union(0.25)
+        .sphere((-1.25, 0.25, 0.0), 0.5, surface=S.Surface(diffuse=(0.875, 0.125, 0.125), specular=(0.25, 0.25, 0.25), roughness=0.5))
+        .union().sphere((1.25, 0.125, -0.25), 0.625, surface=S.Surface(diffuse=(0.125, 0.25, 0.875), specular=(0.75, 0.75, 0.75), roughness=0.0625, ior=1.5))
+        .sphere((0.0, 1.0, 0.0), 0.5, surface=S.Surface(diffuse=(0.5, 0.75, 0.5), specular=(0.5, 0.5, 0.5), subsurface=4.0, subsurface_color=(0.875, 0.5, 0.25)))
+        .subtract().box((0.0, 1.0, -0.5), (0.25, 0.25, 0.25), surface=S.Surface(diffuse=(0.75, 0.75, 0.125), specular=(0.125, 0.125, 0.125), roughness=0.75)),
+        None,
+    ),
     "mandelbulb": (lambda: S.Mandelbulb(), None),
     "lattice": (lambda: S.sphere_lattice_example(), None),
     "fractal1": (lambda: S.SphereGridFractal(), "fractal1.glsl"),
@@ -66,7 +77,9 @@ SCENES = {
 # scenes whose SDF the oracle reproduces bit for bit (only + - * / sqrt floor
 # abs min max); the others go through sin/cos/acos/atan/pow/log where
 # SwiftShader and the oracle (either of its math modes) differ in the last bits (or much more: see test tolerances)
-SDF_BIT_EXACT = ("sphere", "sphere_sss", "csg64", "csg_mixed", "csg_repeat_fold", "lattice", "fractal1")
+SDF_BIT_EXACT = ("sphere", "sphere_sss", "csg64", "csg_mixed", "csg_repeat_fold", "csg_surfaces", "lattice", "fractal1")
+# scenes with a material-function golden (tests/golden/misc_material_<name>.npz)
+MATERIAL_SCENES = ("sphere", "lattice", "csg_surfaces")
 
 IMG_W, IMG_H = 64, 32
 
@@ -102,6 +115,10 @@ IMAGES = {
     "rotation_fractal_full_2b": ("rotation_fractal", 1, dict(render_mode="full", position=(0, 0, -4.0), counts=(48, 24), lights=LIGHT)),
     "csg_repeat_fold_full_2b": ("csg_repeat_fold", 1, dict(render_mode="full", position=(0.2, 0.1, -1.4), counts=(48, 24), lights=LIGHT)),
     "csg_kifs_full_2b": ("csg_kifs", 1, dict(render_mode="full", position=(0.3, 0.2, -2.2), counts=(48, 24), lights=LIGHT)),
+    # round 3: position-dependent materials through the whole main(): every material function at the hit point, the light term's
+    # roughness at the moved point (:366), the subsurface branch of one shape only; and the preview's diffuse + specular (:218-219)
+    "csg_surfaces_full_2b": ("csg_surfaces", 2, dict(render_mode="full", position=(0.25, 0.5, -3.5), counts=(64, 32), lights=THREE_LIGHTS)),
+    "csg_surfaces_preview": ("csg_surfaces", 1, dict(render_mode="preview", position=(0.25, 0.5, -3.5), counts=(64,))),
 }
 
 # cast-ray goldens: scene -> (camera position, steps)

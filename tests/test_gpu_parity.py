@@ -155,7 +155,7 @@ def test_cast_ray_and_normal_probe(ctx, name):
 
 
 def test_material_probe(ctx):
-    for name in ("sphere", "lattice"):
+    for name in GC.MATERIAL_SCENES:
         z = load("misc_material_" + name)
         sc = GC.build_scene(name)
         h = ctx.create_scene(sc)
@@ -924,6 +924,12 @@ def _random_scene(rng):
         sc.repeat(tuple(rng.uniform(2.5, 4.0, 3)))
     if rng.random() < 0.3:
         sc.fold(float(rng.uniform(0.6, 0.9)), tuple(rng.uniform(0.1, 0.5, 3)), tuple(rng.uniform(-0.4, 0.4, 3)) if rng.random() < 0.5 else (0.0, 0.0, 0.0))
+    # round 3: four tables in ten give some of their shapes surfaces of their own (position-dependent material functions)
+    surfaces = []
+    if rng.random() < 0.4:
+        surfaces = [S.Surface(diffuse=tuple(rng.uniform(0.05, 0.95, 3)), specular=tuple(rng.uniform(0.05, 0.95, 3)), roughness=float(rng.uniform(0.05, 0.8)),
+                              subsurface=float(rng.choice([11111115.0, 11111115.0, 4.0, 0.7])), subsurface_color=tuple(rng.uniform(0.3, 1.0, 3)),
+                              ior=float(rng.choice([1.3, 1.5, 100.0]))) for _ in range(int(rng.integers(1, 5)))]
     for i in range(int(rng.integers(1, 11))):
         if i:
             op = rng.integers(0, 4)
@@ -932,8 +938,9 @@ def _random_scene(rng):
             elif op == 2: sc.subtract()
             else: sc.intersect() if rng.random() < 0.3 else sc.smooth_union(0.2)
         c = tuple(rng.uniform(-1.2, 1.2, 3))
-        if rng.random() < 0.6: sc.sphere(c, float(rng.uniform(0.2, 0.9)))
-        else: sc.box(c, tuple(rng.uniform(0.15, 0.8, 3)))
+        surface = surfaces[int(rng.integers(0, len(surfaces)))] if surfaces and rng.random() < 0.6 else None
+        if rng.random() < 0.6: sc.sphere(c, float(rng.uniform(0.2, 0.9)), surface=surface)
+        else: sc.box(c, tuple(rng.uniform(0.15, 0.8, 3)), surface=surface)
     return sc, (0.2, 0.1, -4.0)
 
 

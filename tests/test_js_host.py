@@ -60,6 +60,27 @@ def test_js_domain_operators_match_the_python_composer():
     assert "rmFold(q," in out["glsl"] and "mod(q + 0.5 *" in out["glsl"] and "* factor)" in out["glsl"]
 
 
+def test_js_surfaces_match_the_python_composer():
+    """Shapes with surfaces of their own (RmSurface): the JS composer lays out the same table rows (surface index in bits
+    16-23), the same surface rows and the same description, and emits the same GLSL statements -- rmSurfaceIndex and the
+    seven material functions -- as the Python one, whose text is what the goldens pin against the reference's shader."""
+    import ctypes as C
+
+    out = json.loads(subprocess.run(["node", str(JS / "render_cli.js"), "-", "surfaces"], capture_output=True, text=True, check=True).stdout)
+    sc = GC.build_scene("csg_surfaces")
+    d = sc.desc()
+    assert d.nsurfaces == 4
+    assert out["prims"] == bytes(C.string_at(d.prims, 32 * d.nprims)).hex()
+    assert out["surfaces"] == bytes(C.string_at(d.surfaces, 48 * d.nsurfaces)).hex()
+    raw = bytearray(bytes(d))
+    raw[8:16] = b"\0" * 8    # the two pointers are filled natively
+    raw[-8:] = b"\0" * 8
+    assert out["desc"] == bytes(raw).hex()
+    norm = lambda t: [ln.split("(")[0].strip() for ln in t.splitlines()]
+    assert norm(out["glsl"]) == norm(sc.glsl())
+    assert out["glsl"].count("if (di < best)") == 4 and "rmIor[rmSurfaceIndex(position)]" in out["glsl"]
+
+
 def test_js_png_writer(tmp_path):
     """encodePng of the JS host writes the same picture as the Python writer reads: same
     container rules (RGBA8, filter 0, rows flipped to top-down)."""

@@ -153,7 +153,7 @@ def test_helper_functions_bit_for_bit():
     p5 = O.ss_math("pow", np.abs((f(1) - a[:, 0]).astype(f)), np.full_like(q, 5.0))
     assert same_bits((r0 + ((f(1) - r0).astype(f) * p5).astype(f)).astype(f), z["out"][:, 0]).all()
     assert same_bits((-O.ss_math("log", (f(1) - a[:, 0]).astype(f)) / a[:, 3]).astype(f), z["out"][:, 1]).all()
-    for name in ("sphere", "lattice"):
+    for name in GC.MATERIAL_SCENES:
         z = load("misc_material_" + name)
         got = O.material(GC.build_scene(name), z["points"], **X86)
         assert same_bits(got[:, 0:3], z["diffuse"]).all() and same_bits(got[:, 3:6], z["specular"]).all()
