@@ -1334,6 +1334,48 @@ def test_headline_frame_fast_against_strict_at_full_size(ctx):
     assert abs(ratio - 1.0) < 0.005 and abs(float(b.mean() / a.mean()) - 1.0) < 0.003
 
 
+def test_far_jump_is_exact_on_the_headline_frame(ctx):
+    """The fast Mandelbulb march sets an escaping ray to the end state its remaining steps are known to reach (rm_device.hpp
+    far_jump; castRay, raymarcher.frag:163-170, has no distance bound).  Exact: on the benchmarked frame itself -- 3840x2160,
+    [256], the light, 2 samples -- all three planes equal the stepwise march (RM_RENDER_NO_FAR_JUMP) bit for bit, and the
+    wavefront pipeline, which does not jump, gives the same bits too."""
+    sc, schema = _c3b()
+    noises = GC.halton_pairs(2)
+    jump = render_gpu(ctx, sc, schema, noises, FAST | MK)
+    step = render_gpu(ctx, sc, schema, noises, FAST | MK | abi.RM_RENDER_NO_FAR_JUMP)
+    wf = render_gpu(ctx, sc, schema, noises, FAST | WF)
+    for k in range(3):
+        assert same_bits(jump[k], step[k]).all(), f"plane {k}: {int((~same_bits(jump[k], step[k])).sum())} values differ from the stepwise march"
+        assert same_bits(jump[k], wf[k]).all(), f"plane {k}: the wavefront pipeline differs"
+    assert (step[2][..., 3] > 1.5e6).mean() > 0.8  # most of the frame is sky: both of a pixel's camera rays escaped
+
+
+def test_far_jump_end_points_equal_the_stepwise_march(ctx):
+    """castRay through the probe, fast build, with and without the jump: random rays from inside, near and far outside the
+    bailout sphere (up to 1e6 away), unit directions -- also axis-parallel ones, whose zero components make the end state
+    NaN -- and directions that are not unit (no jump), step budgets around the 30 the jump asks for, power 8 with 1..8
+    rounds and several bailout radii: every end point has the bits of the stepwise march (NaN = NaN)."""
+    rng = np.random.default_rng(505 + SEED_OFFSET)
+    for it in range(12):
+        sc = S.Mandelbulb(power=8.0, iterations=int(rng.integers(1, 9)), bailout=float(rng.choice([2.0, 2.0, 1.5, 3.0, 10.0])))
+        h = ctx.create_scene(sc)
+        n = 4096
+        o = rng.normal(size=(n, 3)) * rng.choice([0.5, 2.0, 3.0, 1e3, 1e6], size=(n, 1))
+        d = rng.normal(size=(n, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        d[: n // 8] = np.eye(3)[rng.integers(0, 3, n // 8)] * rng.choice([-1.0, 1.0], size=(n // 8, 1))  # axis-parallel: zero components
+        d[n // 8: n // 4, int(rng.integers(0, 3))] = 0.0                                                # one zero component, not renormalised
+        d[n // 4: n // 4 + 256] *= 0.5                                                                  # not unit: the jump must not apply
+        rays = np.concatenate([o, d], 1).astype(np.float32)
+        for steps in (10.0, 29.0, 30.0, 31.0, 64.0, 256.0):
+            a = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST)
+            b = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST | abi.RM_RENDER_NO_FAR_JUMP)
+            assert same_bits(a, b).all(), f"scene {it}, {steps} steps: {int((~same_bits(a, b)).any(-1).sum())} end points differ"
+        far = ~np.isfinite(ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, 256.0, FAST)).all(-1)
+        assert far.mean() > 0.2  # the rays do escape: the jump had something to do
+        h.destroy()
+
+
 # How far the fast build may be from the parity build, ANCHORED: GLSL leaves the precision of sin / cos / log / pow / acos /
 # atan (and min / max of NaN, fract at the ends) to the implementation, so the reference's own image exists once per GL
 # stack.  This library has two GLSL-legal arithmetics of the parity path: the strict default (IEEE operations, ~0.5 ulp
