@@ -277,8 +277,8 @@ int rm_ctx_set_retire_eps(rm_ctx* ctx, float eps);
  * only (the wavefront pipeline is not built in this arithmetic); slower than the default strict arithmetic's IEEE-derived
  * shortcuts allow.  Off by default.  on == 2 additionally replaces the portable tangent (the fixed operation sequence every
  * other arithmetic of this library uses for tan(), see RmUniforms / DESIGN.md) by that stack's own tan = sin / cos: what the
- * reference's UNMODIFIED shader text computes under it, random stream and camera included (that switch is one per process:
- * contexts in GL-stack mode share it). */
+ * reference's UNMODIFIED shader text computes under it, random stream and camera included (that switch is one per DEVICE:
+ * the GL-stack contexts of a device share it, and changing it waits for the device). */
 int rm_ctx_set_gl_stack(rm_ctx* ctx, int on);
 /* Diagnostics of the wavefront march, filled only by builds compiled with
  * -DRM_WF_STATS (zeros otherwise): out16[8*shadow + 4*pass2 + {0,1,2}] =

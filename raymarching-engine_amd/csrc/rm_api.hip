@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <unordered_map>
@@ -290,16 +291,21 @@ int rm_ctx_set_retire_eps(rm_ctx* ctx, float eps) {
 
 int rm_ctx_set_gl_stack(rm_ctx* ctx, int on) {
   if (!ctx) return RM_ERR_INVALID;
-  if (ctx->sp_ready) RM_HIP(ctx, hipStreamSynchronize(ctx->stream));  // samples in flight finish in the arithmetic they started in
   if (on != 0 && on != 1 && on != 2) return fail(ctx, RM_ERR_INVALID, "rm_ctx_set_gl_stack: 0 (off), 1 (on) or 2 (on, with the stack's own tan)");
   RM_HIP(ctx, hipSetDevice(ctx->device));
-  RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  static int native_tan = 0;  // the kernels read one device-wide switch: the stack's own tan is a property of the process
-  if (on != 0 && (on == 2) != (native_tan != 0)) {
-    int v = on == 2;
-    RM_HIP(ctx, rm_gl_set_native_tan(v, ctx->stream));
-    RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    native_tan = v;
+  RM_HIP(ctx, hipStreamSynchronize(ctx->stream));  // samples in flight finish in the arithmetic they started in
+  // The kernels read the stack's-own-tan switch from a __device__ symbol: one per DEVICE (the contexts of a device share it).
+  // What each device holds is remembered per device, under a lock; the copy is synchronous (its source is this frame's).
+  static std::mutex guard;
+  static int native_tan[64];  // 0 after the module is loaded on a device, like the symbol
+  if (on != 0) {
+    std::lock_guard<std::mutex> lock(guard);
+    const int slot = ctx->device & 63, v = on == 2 ? 1 : 0;
+    if (native_tan[slot] != v) {
+      RM_HIP(ctx, hipDeviceSynchronize());  // launches of the device's other contexts finish with the value they started with
+      RM_HIP(ctx, rm_gl_set_native_tan(v, nullptr));
+      native_tan[slot] = v;
+    }
   }
   ctx->gl_stack = on != 0;
   return RM_OK;
