@@ -163,7 +163,8 @@ def counters_entry(key, strict, pipeline, windowed):
         spec = importlib.util.spec_from_file_location("update_counters", os.path.join(ROOT, "tools", "update_counters.py"))
         uc = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(uc)
-        ent = cj.get(key + ("_shard" if windowed else "") + ("_strict" if strict else "_fast"))
+        base = key + ("_shard" if windowed else "") + ("_strict" if strict else "_fast")
+        ent = cj.get(base + "_" + pipeline) or cj.get(base)  # (workloads profiled with both implementations carry the implementation in the key)
         if not ent or ent.get("kernel_source_sha256") != uc.kernel_source_hash() or ent.get("pipeline") != pipeline:
             return None
         return ent
