@@ -928,6 +928,10 @@ static void release_staging(rm_ctx* ctx) {
 // rm_render_samples sizes its automatic batch by it, and a launch whose staging cannot be allocated at all renders
 // unstaged, one sample at a time on the context's stream, instead of failing (launch / rm_render_samples).
 static size_t staging_budget(rm_ctx* ctx) {
+  if (const char* v = std::getenv("RM_STAGING_BUDGET_MB")) {  // a fixed budget (tests; hosts that share the device with other allocators)
+    const long long mb = std::atoll(v);
+    if (mb >= 0) return (size_t)mb << 20;
+  }
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return (size_t)1 << 30;
   size_t held = 0;

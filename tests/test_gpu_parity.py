@@ -1334,6 +1334,69 @@ def test_headline_frame_fast_against_strict_at_full_size(ctx):
     assert abs(ratio - 1.0) < 0.005 and abs(float(b.mean() / a.mean()) - 1.0) < 0.003
 
 
+def test_staging_is_sized_by_the_tile_and_bounded_by_a_budget():
+    """Samples in flight and sample batches stage what a launch renders -- its TILE, compact -- not the frame (a
+    subdivided 8192^2 render used to stage 3.2 GB x batch x slots), and rm_render_samples sizes its automatic batch by a byte
+    budget (a quarter of the free device memory; RM_STAGING_BUDGET_MB for a fixed one).  A tiled job on a 1024 x 1024 frame:
+    (1) the device memory the library holds after rendering 64 x 64 tiles with 8-sample batches and 3 launches in flight is
+    the planes plus at most a few MB -- a frame-sized staging would be 1.2 GB; (2) with a budget of 0 MB the batches collapse
+    to one sample per launch and the planes are still bit-identical; (3) the getter says which implementation ran."""
+    import subprocess
+    import sys
+
+    code = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np
+import golden_cases as GC
+from raymarching_engine_amd import abi, job as J, native, scene as S
+ctx = native.Context(0)
+sc = S.Mandelbulb()
+W = H = 1024
+schema = J.make_schema(sc, W, H, counts=(32,), render_mode="full", position=(0, 0, -2.5), lights=GC.LIGHT)
+h = ctx.create_scene(sc)
+noises = GC.halton_pairs(8)
+u = J.uniforms_from_schema(schema, noises[0])
+ctx.set_samples_in_flight(3)
+fb = ctx.create_framebuffer(W, H)
+warm = ctx.create_framebuffer(W, H)  # what the runtime allocates with a kernel's first launch (code, scratch) is not staging: spend it first
+ctx.render_sample(h, warm, u, abi.RmRect(0, 0, 64, 64), abi.RM_RENDER_FAST | abi.RM_RENDER_NO_OVERLAP)
+ctx.sync()
+free0, _ = ctx.device_memory()
+tiles = [abi.RmRect(x, y, 64, 64) for y in (0, 448, 960) for x in (0, 512, 960)]
+for t in tiles:
+    ctx.render_samples(h, fb, u, noises, t, abi.RM_RENDER_FAST)
+ctx.sync()
+assert ctx.last_pipeline() == "megakernel"
+free1, _ = ctx.device_memory()
+got = [fb.download(k) for k in range(3)]
+ref = ctx.create_framebuffer(W, H)
+ctx.set_samples_in_flight(1)
+for t in tiles:
+    for nz in noises:
+        ctx.render_sample(h, ref, J.uniforms_from_schema(schema, nz), t, abi.RM_RENDER_FAST | abi.RM_RENDER_NO_OVERLAP)
+want = [ref.download(k) for k in range(3)]
+same = all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(got, want))
+print("STAGING", int(free0 - free1), same, flush=True)
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    held = {}
+    for budget in (None, "0"):
+        env = dict(os.environ)
+        if budget is not None:
+            env["RM_STAGING_BUDGET_MB"] = budget
+        r = subprocess.run([sys.executable, "-c", code, root], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("STAGING")][-1].split()
+        assert line[2] == "True", "staged tiles differ from one unstaged launch per sample"
+        held[budget] = int(line[1])
+    # 8 samples x 3 planes x 64 x 64 x 16 B = 1.5 MB per slot, 3 slots; one sample per launch: 0.2 MB per slot.  (Both runs
+    # also hold ~240 MB that is not the library's: the runtime gives every new stream's hardware queue its own scratch.)
+    # Frame-sized staging would be 48 MB per sample: 1.2 GB for the batches, 150 MB for single samples.
+    assert 0 <= held[None] - held["0"] < 16 << 20, held
+    assert held[None] < 400 << 20, held
+
+
 def test_far_jump_is_exact_on_the_headline_frame(ctx):
     """The fast Mandelbulb march sets an escaping ray to the end state its remaining steps are known to reach (rm_device.hpp
     far_jump; castRay, raymarcher.frag:163-170, has no distance bound).  Exact: on the benchmarked frame itself -- 3840x2160,
