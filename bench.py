@@ -71,15 +71,19 @@ WORKLOADS = {
                mode="full", position=(0.0, 0.0, -5.0), light=True),
     "c5": dict(name="C5 csg64 8192x8192 full [128,64,64] soft light", scene="csg64", width=8192, height=8192, counts=(128, 64, 64),
                mode="full", position=(0.0, 0.0, -5.0), light="soft"),
+    # not a BASELINE configuration: the job the reference's page starts with (index.tsx:121-182,308-333: the fractal1 example scene, 1280x720,
+    # full mode, [128,128,64,32,32], no lights) -- what a user who switches over runs first
+    "live": dict(name="live default: fractal1 (sphere-grid fractal) 1280x720 full [128,128,64,32,32]", scene="fractal1", width=1280, height=720,
+                 counts=(128, 128, 64, 32, 32), mode="full", position=(0.0, 0.0, 0.0), light=False),
 }
-NOMINAL_FLOPS_PX = {"c3b": 145.5e3, "c3a": 71.7e3, "c2": 2.2e3, "c4": 403e3, "c5": 817e3}  # SURVEY.md 8(d), fixed-E estimate
+NOMINAL_FLOPS_PX = {"c3b": 145.5e3, "c3a": 71.7e3, "c2": 2.2e3, "c4": 403e3, "c5": 817e3, "live": 409 * 150.0}  # SURVEY.md 8(d), fixed-E estimate
 
 
 def make_workload(key):
     from raymarching_engine_amd import job as J, scene as S
 
     w = WORKLOADS[key]
-    sc = {"mandelbulb": S.Mandelbulb, "sphere": S.single_sphere, "csg64": S.csg64}[w["scene"]]()
+    sc = {"mandelbulb": S.Mandelbulb, "sphere": S.single_sphere, "csg64": S.csg64, "fractal1": S.SphereGridFractal}[w["scene"]]()
     lights = []
     if w["light"]:
         lights = [J.point_light((2.0, 3.0, -4.0), size=0.3 if w["light"] == "soft" else 0.0)]
@@ -143,7 +147,7 @@ def reference_gl(key):
         rows = json.load(open(os.path.join(ROOT, "profiles", "r01_b1_swiftshader_reference.json")))
     except Exception:
         return None
-    tag = {"c3b": "C3b", "c3a": "C3a", "c2": "C2", "c4": "C4", "c5": "C5"}[key]
+    tag = {"c3b": "C3b", "c3a": "C3a", "c2": "C2", "c4": "C4", "c5": "C5"}.get(key, "-")
     hits = [r for r in rows if r["case"].startswith(tag + " ")]
     if not hits:
         return None
