@@ -678,9 +678,9 @@ struct Sdf<RM_SCENE_MANDELBULB> {
   // direction component (NaN where that is 0: 0 x Inf), and that pattern is the march's fixed point -- unless it holds a
   // NaN: then the next evaluation is NaN (NaN > bailout is false: the rounds run on it) and one more step leaves every
   // coordinate NaN.  A ray with at least far_jump_steps steps left therefore ends exactly there, and 89 % of the
-  // headline frame's pixels end their camera ray this way and all of those their shadow ray (their steps were ~16 % of
+  // headline frame's pixels end their camera ray this way and all of those their shadow ray (the skipped steps were ~5 % of
   // the frame's issue slots).  Exact: the end point has the bits the stepwise march produces (tested on the whole
-  // frame against RM_RENDER_NO_FAR_JUMP), so the wavefront pipeline, which marches on, stays bit-identical.
+  // frame against RM_RENDER_NO_FAR_JUMP); both implementations jump (cast_ray / cast_ray_block, wf_march) and stay bit-identical.
   static constexpr int far_jump_steps = 30;
   static RM_DEV bool far_jump_applies(const DevScene& sc) { return sc.p[RM_P_BULB_POWER] == 8.0f && sc.p[RM_P_BULB_ITERATIONS] >= 1.0f; }
   static RM_DEV bool far_jump(const DevScene& sc, v3 p, v3 dir, int left, v3& end) {
