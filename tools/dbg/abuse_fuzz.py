@@ -37,6 +37,20 @@ for it in range(n):
             prims[q].center[a] = nasty(0.01); prims[q].size[a] = nasty(0.01, 0.05, 1.5)
     d.nprims = nprims
     d.prims = C.cast(prims, C.POINTER(abi.RmPrim)) if rng.random() < 0.95 else None
+    # round 3: surfaces (RmSurface) -- counts in and out of range, a missing array, indices beyond the count, on domain rows, nasty values
+    if rng.random() < 0.4:
+        nsurf = int(rng.choice([1, 2, 4, 15, 15, 3, 0, 16, -2, 200]))
+        surf = (abi.RmSurface * max(min(nsurf, 256), 1))()
+        for q in range(max(min(nsurf, 256), 0)):
+            for name, ty in abi.RmSurface._fields_:
+                if ty is C.c_float: setattr(surf[q], name, nasty(0.03, 0.0, 2.0))
+                else:
+                    for a in range(3): getattr(surf[q], name)[a] = nasty(0.03, 0.0, 1.0)
+        d.nsurfaces = nsurf
+        d.surfaces = C.cast(surf, C.POINTER(abi.RmSurface)) if rng.random() < 0.9 else None
+        for q in range(max(nprims, 0)):
+            if rng.random() < 0.5:
+                prims[q].type |= int(rng.choice([1, 2, 3, 15, 1, 2, 16, 255] if rng.random() < 0.1 else [1, 2, 3, 1, 2, max(1, min(nsurf, 15))])) << 16
     if rng.random() < 0.3:
         for name, ty in abi.RmMaterial._fields_:
             if name in ("sky_axis", "reserved"): setattr(d.material, name, int(rng.choice([0, 1, 2, 3, -1])))
@@ -66,7 +80,7 @@ for it in range(n):
         for a in range(3): u.lightPositions[j][a] = nasty(0.2, -4.0, 4.0); u.lightColors[j][a] = nasty(0.2, 0.0, 3.0)
         u.lightSizes[j] = nasty(0.3, 0.0, 1.0)
     u.showDofFocalPlane = int(rng.choice([0, 1, 5]))
-    flags = int(rng.choice([0, 1])) | int(rng.choice([0, 4, 16])) | int(rng.choice([0, 0, 2]))
+    flags = int(rng.choice([0, 1])) | int(rng.choice([0, 4, 16])) | int(rng.choice([0, 0, 2])) | int(rng.choice([0, 0, 64]))
     tile = abi.RmRect(int(rng.integers(-5, 30)), int(rng.integers(-5, 20)), int(rng.integers(-3, 40)), int(rng.integers(-3, 30)))
     print(f"render mode {u.renderMode} refl {u.reflections} lights {u.lightCount} flags {flags}", end=" ", flush=True)
     rc = lib.rm_render_sample(ctx.h, h, fb.h, C.byref(u), C.byref(tile) if rng.random() < 0.5 else None, flags)
