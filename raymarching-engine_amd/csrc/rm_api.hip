@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <mutex>
 #include <new>
 #include <string>
@@ -344,6 +345,42 @@ static bool finite_all(const float* p, int n) {
   return true;
 }
 
+// Where an escaping ray of a primitive table ends (Sdf<RM_SCENE_TABLE>::far_jump).  Without domain rows every shape lies
+// inside a sphere about the origin, and outside it the fold is bounded below: a shape's distance is >= |p| - (|c| + extent),
+// min / max keep that bound (max(d, -di) and max(d, di) only raise d), a smooth union lowers it by at most k / 4.  A ray out
+// there that is not moving inward never returns and doubles its distance from step to step until |p|^2 overflows; at that
+// step p - c = p for every shape (the centres are below the spacing of floats of that size), so every shape's distance is
+// +Inf at once and the march's step is the fold of all-+Inf terms: +Inf -- the position becomes +-Inf by the sign of the
+// direction components, a fixed point -- or NaN, when a smooth union meets Inf - Inf -- then every coordinate is NaN, for
+// good.  That fold is evaluated here, with the operators' own semantics (IEEE minNum / maxNum drop a NaN, as v_min / v_max do).
+static void table_far_field(const RmSceneDesc* desc, DevScene* dev) {
+  dev->far_end = 0;
+  dev->far_r2 = 0.0f;
+  double reach = 0.0, kmax = 0.0;
+  int smooth = 0;
+  float d = 0.0f;
+  bool first = true;
+  const float inf = std::numeric_limits<float>::infinity();
+  for (int i = 0; i < desc->nprims; i++) {
+    const RmPrim& p = desc->prims[i];
+    const int type = p.type & 0xff, op = (p.type >> 8) & 0xff;
+    if (type == RM_PRIM_REPEAT || type == RM_PRIM_FOLD) return;  // a tiled or folded space has no far field
+    const double c = std::sqrt((double)p.center[0] * p.center[0] + (double)p.center[1] * p.center[1] + (double)p.center[2] * p.center[2]);
+    const double extent = type == RM_PRIM_SPHERE ? std::fabs((double)p.size[0])
+                                                 : std::sqrt((double)p.size[0] * p.size[0] + (double)p.size[1] * p.size[1] + (double)p.size[2] * p.size[2]);
+    reach = std::fmax(reach, c + extent);
+    if (first) { d = inf; first = false; continue; }
+    if (op == RM_OP_UNION) d = std::fmin(d, inf);
+    else if (op == RM_OP_SMOOTH_UNION) { d = std::numeric_limits<float>::quiet_NaN(); smooth++; kmax = std::fmax(kmax, std::fabs((double)p.k)); }  // Inf - Inf, or a NaN handed on
+    else if (op == RM_OP_SUBTRACT) d = std::fmax(d, -inf);
+    else d = std::fmax(d, inf);
+  }
+  const double r = 2.0 * (reach + 0.25 * kmax * smooth) + 1.0;
+  if (first || !(r < 1e9)) return;
+  dev->far_r2 = (float)(r * r);
+  dev->far_end = d == inf ? 1 : (d != d ? 2 : 0);
+}
+
 int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out) {
   if (!ctx || !desc || !out) return fail(ctx, RM_ERR_INVALID, "rm_scene_create: NULL argument");
   *out = nullptr;
@@ -430,6 +467,7 @@ int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out) {
       if (one_k) s->dev.table_flags |= RM_TABLE_UNIFORM_K;
     }
   }
+  if (desc->kind == RM_SCENE_TABLE) table_far_field(desc, &s->dev);
   std::memcpy(s->dev.p, desc->params, sizeof s->dev.p);
   if (s->dev.table_flags & RM_TABLE_UNIFORM_K) {
     s->dev.p[0] = desc->prims[1].k;

@@ -439,6 +439,29 @@ struct Sdf<RM_SCENE_TABLE> {
     nx = M::fma(q.z, -s, q.x * c); ny = M::fma(q.z, c, q.x * s); q.x = nx; q.z = ny;
     return q;
   }
+  // ---- the far field of a table, jumped (round 3; fast policy; rm_api.hip table_far_field has the argument) -----------------
+  // A ray outside 2 R' (far_r2) that is not moving inward reaches the overflow of |p|^2 within 64 steps (worst case: it starts
+  // at 2 R' at a right angle, |dir|^2 = 0.98, every step rounded down by 1e-3, d = r - R'), 3 more settle it; its end state is
+  // the scene's far_end.  The +-Inf pattern is only taken for directions without a zero component (0 x Inf = NaN, and what a
+  // NaN coordinate does next depends on the shapes: a box drops it); such rays march on.  Exact, like the Mandelbulb's jump:
+  // tested against RM_RENDER_NO_FAR_JUMP on BASELINE's CSG frames and on random tables through the probe.
+  static constexpr int far_jump_steps = 72;
+  static RM_DEV bool far_jump_applies(const DevScene& sc) { return sc.far_end != 0; }
+  static RM_DEV bool far_jump(const DevScene& sc, v3 p, v3 dir, int left, v3& end) {
+    const float r2 = FM::fma(p.z, p.z, FM::fma(p.y, p.y, p.x * p.x));
+    if (!(r2 > sc.far_r2 && r2 < 1e30f) || left < far_jump_steps) return false;
+    const float s = dot<FM>(p, dir), dd = dot<FM>(dir, dir);
+    if (!(s >= 0.0f && dd > 0.98f && dd < 1.02f)) return false;
+    if (sc.far_end == 2) {
+      const float nan = __builtin_nanf("");
+      end = V(nan, nan, nan);
+      return true;
+    }
+    if (dir.x == 0.0f || dir.y == 0.0f || dir.z == 0.0f) return false;
+    end = dir * __builtin_inff();
+    return true;
+  }
+
   // Which surface the material functions use at p (RM_TABLE_HAS_SURFACES; include/hip_raymarch.h RmSurface): the one the
   // shape row with the smallest distance term names -- the terms of eval()'s fold, row by row, before their operators --
   // the earliest row on a tie; a NaN term never wins (`<` is false), so a point whose terms are all NaN has the first
@@ -757,6 +780,7 @@ struct Sdf<RM_KIND_BULB8> : Sdf<RM_SCENE_MANDELBULB> {
 template <int KIND> struct FarJump { static constexpr bool value = false; };
 template <> struct FarJump<RM_SCENE_MANDELBULB> { static constexpr bool value = true; };
 template <> struct FarJump<RM_KIND_BULB8> { static constexpr bool value = true; };
+template <> struct FarJump<RM_SCENE_TABLE> { static constexpr bool value = true; };
 
 // kernels that may evaluate the power-8 Mandelbulb on the fast policy start with this (FM::omod_mode)
 template <int KIND, bool FAST> RM_DEV void enter_math_mode() {

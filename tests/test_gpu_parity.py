@@ -1440,6 +1440,62 @@ def test_far_jump_end_points_equal_the_stepwise_march(ctx):
         h.destroy()
 
 
+def test_table_far_jump_is_exact_on_the_csg_frames(ctx):
+    """The far-field jump of primitive tables (rm_device.hpp Sdf<RM_SCENE_TABLE>::far_jump, rm_api.hip table_far_field): an
+    escaping ray of a table without domain rows ends at +-Inf by the signs of its direction, or at NaN when a smooth union
+    meets Inf - Inf -- BASELINE's CSG-64.  On C4's own frame (4096 x 4096, [128], the light; 2 samples) and on C5's job
+    ([128, 64, 64], the soft light) at 2048 x 2048, both implementations: every plane equals the stepwise march bit for bit."""
+    for name, size, samples in (("c4", 4096, 2), ("c5", 2048, 2)):
+        sc = S.csg64()
+        lights = GC.LIGHT if name == "c4" else GC.SOFT_LIGHT
+        counts = (128,) if name == "c4" else (128, 64, 64)
+        schema = J.make_schema(sc, size, size, counts=counts, render_mode="full", position=(0, 0, -5.0), lights=lights)
+        noises = GC.halton_pairs(samples)
+        ref = render_gpu(ctx, sc, schema, noises, FAST | MK | abi.RM_RENDER_NO_FAR_JUMP)
+        for impl, label in ((MK, "pixel kernel"), (WF, "wavefront pipeline")):
+            got = render_gpu(ctx, sc, schema, noises, FAST | impl)
+            for k in range(3):
+                assert same_bits(got[k], ref[k]).all(), f"{name}, {label}, plane {k}: {int((~same_bits(got[k], ref[k])).sum())} values differ from the stepwise march"
+        assert (ref[2][..., 3] > 1.5e6).mean() > 0.3  # a good part of the frame is sky: rays did escape
+
+
+def test_table_far_jump_end_points_equal_the_stepwise_march(ctx):
+    """castRay through the probe on 40 random tables without domain rows -- spheres and boxes under every operator, one
+    shape to ten -- fast build, with and without the jump: rays from inside the scene, near it and up to 1e6 away, unit
+    directions, axis-parallel ones and ones with a single zero component (no jump to the +-Inf pattern for those), directions
+    that are not unit, step budgets around the 72 the jump asks for.  Every end point has the stepwise march's bits."""
+    rng = np.random.default_rng(717 + SEED_OFFSET)
+    jumped = 0
+    for it in range(40):
+        sc = S.CsgScene()
+        for i in range(int(rng.integers(1, 11))):
+            if i:
+                op = rng.integers(0, 4)
+                if op == 0: sc.union()
+                elif op == 1: sc.smooth_union(float(rng.uniform(0.05, 0.5)))
+                elif op == 2: sc.subtract()
+                else: sc.intersect()
+            c = tuple(rng.uniform(-1.5, 1.5, 3))
+            if rng.random() < 0.6: sc.sphere(c, float(rng.uniform(0.2, 0.9)))
+            else: sc.box(c, tuple(rng.uniform(0.15, 0.8, 3)))
+        h = ctx.create_scene(sc)
+        n = 2048
+        o = rng.normal(size=(n, 3)) * rng.choice([0.5, 3.0, 10.0, 1e3, 1e6], size=(n, 1))
+        d = rng.normal(size=(n, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        d[: n // 8] = np.eye(3)[rng.integers(0, 3, n // 8)] * rng.choice([-1.0, 1.0], size=(n // 8, 1))
+        d[n // 8: n // 4, int(rng.integers(0, 3))] = 0.0
+        d[n // 4: n // 4 + 128] *= 0.5
+        rays = np.concatenate([o, d], 1).astype(np.float32)
+        for steps in (60.0, 71.0, 72.0, 73.0, 128.0, 256.0):
+            a = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST)
+            b = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST | abi.RM_RENDER_NO_FAR_JUMP)
+            assert same_bits(a, b).all(), f"table {it}, {steps} steps: {int((~same_bits(a, b)).any(-1).sum())} end points differ"
+        jumped += int((~np.isfinite(ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, 256.0, FAST)).all(-1)).sum())
+        h.destroy()
+    assert jumped > 10000  # the rays do escape: the jump had something to do
+
+
 # How far the fast build may be from the parity build, ANCHORED: GLSL leaves the precision of sin / cos / log / pow / acos /
 # atan (and min / max of NaN, fract at the ends) to the implementation, so the reference's own image exists once per GL
 # stack.  This library has two GLSL-legal arithmetics of the parity path: the strict default (IEEE operations, ~0.5 ulp
