@@ -781,6 +781,7 @@ template <int KIND> struct FarJump { static constexpr bool value = false; };
 template <> struct FarJump<RM_SCENE_MANDELBULB> { static constexpr bool value = true; };
 template <> struct FarJump<RM_KIND_BULB8> { static constexpr bool value = true; };
 template <> struct FarJump<RM_SCENE_TABLE> { static constexpr bool value = true; };
+template <> struct FarJump<RM_SCENE_MENGER> { static constexpr bool value = true; };
 
 // kernels that may evaluate the power-8 Mandelbulb on the fast policy start with this (FM::omod_mode)
 template <int KIND, bool FAST> RM_DEV void enter_math_mode() {
@@ -838,6 +839,24 @@ struct Sdf<RM_SCENE_MENGER> {
   static constexpr bool has_cost_classes = false;  // every evaluation costs the same
   static RM_DEV bool nonfinite_normal_is_nan(const DevScene&) { return false; }  // not shown for this kind: always evaluate
   static RM_DEV void stage(const DevScene&, SceneLds& lds) { stage_pow_table(lds, 0.33333333333333f, 1.0f); }
+  // ---- the far field of the sponge, jumped (round 3; fast policy) ----------------------------------------------------------
+  // Beyond |p| = 4 the distance IS the unit box's: the carving terms are distances to crosses at mod(p, 3 sf) - 1.5 sf, i.e.
+  // bounded by 2 plus the rounding of the mod (<= 3e-7 |p|), and max(box, -min(a, b, c)) picks the box, whose distance is
+  // >= |p| - 1.8.  So a ray out there that is not moving inward doubles its distance every step: |p|^2 overflows within 64
+  // steps (the bound of the tables, R' = 2), the box's length is then +Inf while the carving terms are finite: d = +Inf and
+  // the position becomes +-Inf by the signs of the direction.  That is a fixed point: at an infinite coordinate the mod is
+  // Inf - Inf = NaN, sdBox's max(q, 0) drops it and the crosses' distances are 0, max(Inf, -0) = Inf again.  Taken for
+  // directions without a zero component only (0 x Inf = NaN; such rays march on).  Exact: tested against the stepwise march.
+  static constexpr int far_jump_steps = 72;
+  static RM_DEV bool far_jump_applies(const DevScene&) { return true; }
+  static RM_DEV bool far_jump(const DevScene&, v3 p, v3 dir, int left, v3& end) {
+    const float r2 = FM::fma(p.z, p.z, FM::fma(p.y, p.y, p.x * p.x));
+    if (!(r2 > 25.0f && r2 < 1e30f) || left < far_jump_steps) return false;
+    const float s = dot<FM>(p, dir), dd = dot<FM>(dir, dir);
+    if (!(s >= 0.0f && dd > 0.98f && dd < 1.02f) || dir.x == 0.0f || dir.y == 0.0f || dir.z == 0.0f) return false;
+    end = dir * __builtin_inff();
+    return true;
+  }
   template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds& lds, v3 p) {
     const float* tab = reinterpret_cast<const float*>(lds.rows);

@@ -1496,6 +1496,36 @@ def test_table_far_jump_end_points_equal_the_stepwise_march(ctx):
     assert jumped > 10000  # the rays do escape: the jump had something to do
 
 
+def test_menger_far_jump_is_exact(ctx):
+    """The Menger sponge's far field is its unit box's (rm_device.hpp Sdf<RM_SCENE_MENGER>::far_jump): images (both
+    implementations) and castRay probes with the jump equal the stepwise march bit for bit, iterations 1..6, budgets around
+    the 72 steps the jump asks for, axis-parallel and other directions with zero components included."""
+    rng = np.random.default_rng(919 + SEED_OFFSET)
+    for iters in (1.0, 3.0, 4.0, 6.0):
+        sc = S.MengerSponge(iterations=iters)
+        schema = J.make_schema(sc, 512, 320, counts=(128, 96), render_mode="full", position=(0.5, 0.5, -2.0), lights=GC.LIGHT)
+        noises = GC.halton_pairs(2)
+        ref = render_gpu(ctx, sc, schema, noises, FAST | MK | abi.RM_RENDER_NO_FAR_JUMP)
+        for impl in (MK, WF):
+            got = render_gpu(ctx, sc, schema, noises, FAST | impl)
+            for k in range(3):
+                assert same_bits(got[k], ref[k]).all(), f"iterations {iters}, plane {k}: {int((~same_bits(got[k], ref[k])).sum())} values differ"
+        h = ctx.create_scene(sc)
+        n = 4096
+        o = rng.normal(size=(n, 3)) * rng.choice([0.5, 3.0, 10.0, 1e3, 1e6], size=(n, 1))
+        d = rng.normal(size=(n, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        d[: n // 8] = np.eye(3)[rng.integers(0, 3, n // 8)] * rng.choice([-1.0, 1.0], size=(n // 8, 1))
+        d[n // 8: n // 4, int(rng.integers(0, 3))] = 0.0
+        rays = np.concatenate([o, d], 1).astype(np.float32)
+        for steps in (60.0, 71.0, 72.0, 73.0, 128.0, 256.0):
+            a = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST)
+            b = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST | abi.RM_RENDER_NO_FAR_JUMP)
+            assert same_bits(a, b).all(), f"iterations {iters}, {steps} steps: {int((~same_bits(a, b)).any(-1).sum())} end points differ"
+        assert (~np.isfinite(ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, 256.0, FAST)).all(-1)).mean() > 0.3
+        h.destroy()
+
+
 # How far the fast build may be from the parity build, ANCHORED: GLSL leaves the precision of sin / cos / log / pow / acos /
 # atan (and min / max of NaN, fract at the ends) to the implementation, so the reference's own image exists once per GL
 # stack.  This library has two GLSL-legal arithmetics of the parity path: the strict default (IEEE operations, ~0.5 ulp
