@@ -473,7 +473,10 @@ def main():
                     "flops_source": f"profiles/flops_per_pixel.json[{args.workload}] (every {fixture['row_stride']} row(s) of the whole frame; tools/count_flops.py)",
                     "executed_source": counters_file,
                     "kernel_ms": kernel_ms, "kernel_ms_per_rank": kernel_ms_per_rank, "kernel_launches_timed": n_timed, "pixels_per_launch": px_launch,
-                    "hbm_algorithmic_GBs": 96.0 * px_launch / sec / 1e9, "hbm_peak_GBs": PEAK_HBM_GBS}
+                    "hbm_algorithmic_GBs": 96.0 * px_launch / sec / 1e9, "hbm_peak_GBs": PEAK_HBM_GBS,
+                    "note": "frac prices the REFERENCE algorithm (every step of its fixed-count marches, SURVEY 8(d)) at the kernel's time; the kernel skips, "
+                            "exactly, the steps whose outcome is known -- a ray that stopped moving, an escaping ray's way to overflow -- so frac can "
+                            "exceed 1 on frames that are mostly sky; frac_executed is the hardware's own count of the arithmetic done"}
         out = {
             "metric": "Mpixels/sec at 3840x2160 Mandelbulb" if args.workload in ("c3b", "c3a") else "Mpixels/sec",
             "value": value, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

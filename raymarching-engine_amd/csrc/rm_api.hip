@@ -381,6 +381,32 @@ static void table_far_field(const RmSceneDesc* desc, DevScene* dev) {
   dev->far_end = d == inf ? 1 : (d != d ? 2 : 0);
 }
 
+// The far field of the kaleidoscopic kinds (rm_device.hpp Sdf<RM_SCENE_KIFS_BOX>::far_jump, Sdf<RM_SCENE_KIFS_TREE>::eval).
+// A level maps t to rotate(|t / s| - off): norms obey |t'| >= |t| / s - |off|, so after n levels |t_n| s^n >= |p| - |off| s / (1 - s),
+// and sdBox(q, b) >= |q| - |b|: every level's box is >= |p| - R' with R' = |off| s / (1 - s) + |b| (b <= the unit-level box).
+//  * rotation-fractal (one box at the last level): the estimate grows with |p| and a ray that leaves overflows like a table's;
+//    far_end = 1 (the +-Inf pattern is a fixed point whatever the folds make of an infinite point: sdBox drops their NaNs and
+//    returns +Inf or 0), provided the deepest point t_n = p / s^n stays finite up to the overflow of |p|^2 (s^n >= 1e-15).
+//  * tree / smooth-tree: the estimate starts from min_dist = 9999, so beyond |p| = 9999 + R' it IS 9999 -- min(9999, box), and
+//    the smooth union's mix(box, 9999, 1) = box + (9999 - box) is exact while box < 2^24 -- and a ray out there walks 9999 per
+//    step to the end of its budget: far_end = 3 lets the fast evaluation return the constant without its levels.
+static void kifs_far_field(const RmSceneDesc* desc, DevScene* dev) {
+  dev->far_end = 0;
+  dev->far_r2 = 0.0f;
+  const double iters = desc->params[RM_P_KIFS_ITERATIONS], s = desc->params[RM_P_KIFS_SCALE], off = std::fabs((double)desc->params[RM_P_KIFS_OFFSET]);
+  if (!(s > 0.05 && s <= 0.9) || !(iters >= 0.0 && iters <= 64.0) || !(off < 1e6)) return;
+  if (desc->kind == RM_SCENE_KIFS_BOX) {
+    if (std::pow(s, std::ceil(iters)) < 1e-15) return;
+    const double r = 2.0 * std::sqrt(3.0) * (off * s / (1.0 - s) + 1.0) + 1.0;
+    dev->far_r2 = (float)(r * r);
+    dev->far_end = 1;
+  } else {
+    const double r = 9999.0 + 1.01 * (off * s / (1.0 - s) + 1.0) + 2.0;
+    dev->far_r2 = (float)(r * r);
+    dev->far_end = 3;
+  }
+}
+
 int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out) {
   if (!ctx || !desc || !out) return fail(ctx, RM_ERR_INVALID, "rm_scene_create: NULL argument");
   *out = nullptr;
@@ -468,6 +494,12 @@ int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out) {
     }
   }
   if (desc->kind == RM_SCENE_TABLE) table_far_field(desc, &s->dev);
+  if (desc->kind == RM_SCENE_KIFS_BOX || desc->kind == RM_SCENE_KIFS_TREE) kifs_far_field(desc, &s->dev);
+  if (desc->kind == RM_SCENE_SPHERE_GRID) {  // the sphere-grid fractal lives inside its big sphere (Sdf<RM_SCENE_SPHERE_GRID>::far_jump)
+    const float* c = &desc->params[RM_P_GRID_CENTER];
+    const double r = 2.0 * (std::sqrt((double)c[0] * c[0] + (double)c[1] * c[1] + (double)c[2] * c[2]) + std::fabs((double)desc->params[RM_P_GRID_BIG_SIZE])) + 1.0;
+    if (r < 1e9) { s->dev.far_r2 = (float)(r * r); s->dev.far_end = 1; }
+  }
   std::memcpy(s->dev.p, desc->params, sizeof s->dev.p);
   if (s->dev.table_flags & RM_TABLE_UNIFORM_K) {
     s->dev.p[0] = desc->prims[1].k;
@@ -760,6 +792,7 @@ static int build_params(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniform
   P->block_order = nullptr;
   P->block_cost = nullptr;
   P->no_far_jump = (flags & RM_RENDER_NO_FAR_JUMP) ? 1 : 0;
+  if (P->no_far_jump) P->scene.far_end = 0;  // the far-field shortcuts inside an evaluation (KIFS tree) read the scene block
   return RM_OK;
 }
 
@@ -1372,6 +1405,7 @@ int rm_probe(rm_ctx* ctx, rm_scene* scene, int what, const float* in, int n, flo
   if (e == hipSuccess) e = hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
     ProbeParams P{scene->dev, d_in, d_out, n, what, param, (flags & RM_RENDER_FAST) ? ctx->retire_eps : 0.0f, (flags & RM_RENDER_NO_FAR_JUMP) ? 1 : 0};
+    if (P.no_far_jump) P.scene.far_end = 0;
     e = (flags & RM_RENDER_FAST) ? rm::launch_probe_fast(P, ctx->stream) : ctx->gl_stack ? rm_gl_launch_probe(&P, ctx->stream) : rm::launch_probe_strict(P, ctx->stream);
   }
   if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream);

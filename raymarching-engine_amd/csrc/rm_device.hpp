@@ -340,6 +340,22 @@ template <class M> RM_DEV float op_smooth_union(float d1, float d2, float k) {
 template <int KIND>
 struct Sdf;
 
+// Steps an escaping ray needs at most to reach its end state when its distance estimate is bounded below by |p| - R' (the
+// bounded scenes: tables, the sponge, the rotation fractal, the sphere-grid fractal; far_r2 = (2 R')^2): the worst case of
+// the recurrence (r^2, s) -> (r^2 + 2 d s + d^2, s + d), d = r - R', started at a right angle with |dir|^2 = 0.98 and every
+// step rounded down by 1e-3, overflows |p|^2 after 64 steps from r = 2 R', 56 from 100 R', 43 from 1e6 R'; 3 more settle it.
+RM_DEV int far_need(float r2, float far_r2) { return r2 >= far_r2 * 2.5e11f ? 48 : (r2 >= far_r2 * 2500.0f ? 60 : 72); }
+// the conditions all those jumps share: outside, not moving inward, a unit direction without a zero component (0 x Inf = NaN)
+RM_DEV bool far_escape(v3 p, v3 dir, int left, float far_r2, bool need_nonzero_dir, v3& end) {
+  const float r2 = FM::fma(p.z, p.z, FM::fma(p.y, p.y, p.x * p.x));
+  if (!(r2 > far_r2 && r2 < 1e30f) || left < far_need(r2, far_r2)) return false;
+  const float s = FM::fma(p.z, dir.z, FM::fma(p.y, dir.y, p.x * dir.x)), dd = FM::fma(dir.z, dir.z, FM::fma(dir.y, dir.y, dir.x * dir.x));
+  if (!(s >= 0.0f && dd > 0.98f && dd < 1.02f)) return false;
+  if (need_nonzero_dir && (dir.x == 0.0f || dir.y == 0.0f || dir.z == 0.0f)) return false;
+  end = dir * __builtin_inff();
+  return true;
+}
+
 // RM_SCENE_TABLE: left fold over the LDS-resident primitive table.  Rows are
 // read with one address for the whole wave (LDS broadcast); type/operator go
 // through readfirstlane so the per-row switch is a scalar branch.
@@ -440,25 +456,17 @@ struct Sdf<RM_SCENE_TABLE> {
     return q;
   }
   // ---- the far field of a table, jumped (round 3; fast policy; rm_api.hip table_far_field has the argument) -----------------
-  // A ray outside 2 R' (far_r2) that is not moving inward reaches the overflow of |p|^2 within 64 steps (worst case: it starts
-  // at 2 R' at a right angle, |dir|^2 = 0.98, every step rounded down by 1e-3, d = r - R'), 3 more settle it; its end state is
+  // A ray outside 2 R' (far_r2) that is not moving inward reaches the overflow of |p|^2 within far_need() steps; its end state is
   // the scene's far_end.  The +-Inf pattern is only taken for directions without a zero component (0 x Inf = NaN, and what a
   // NaN coordinate does next depends on the shapes: a box drops it); such rays march on.  Exact, like the Mandelbulb's jump:
   // tested against RM_RENDER_NO_FAR_JUMP on BASELINE's CSG frames and on random tables through the probe.
-  static constexpr int far_jump_steps = 72;
   static RM_DEV bool far_jump_applies(const DevScene& sc) { return sc.far_end != 0; }
   static RM_DEV bool far_jump(const DevScene& sc, v3 p, v3 dir, int left, v3& end) {
-    const float r2 = FM::fma(p.z, p.z, FM::fma(p.y, p.y, p.x * p.x));
-    if (!(r2 > sc.far_r2 && r2 < 1e30f) || left < far_jump_steps) return false;
-    const float s = dot<FM>(p, dir), dd = dot<FM>(dir, dir);
-    if (!(s >= 0.0f && dd > 0.98f && dd < 1.02f)) return false;
+    if (!far_escape(p, dir, left, sc.far_r2, sc.far_end != 2, end)) return false;
     if (sc.far_end == 2) {
       const float nan = __builtin_nanf("");
       end = V(nan, nan, nan);
-      return true;
     }
-    if (dir.x == 0.0f || dir.y == 0.0f || dir.z == 0.0f) return false;
-    end = dir * __builtin_inff();
     return true;
   }
 
@@ -704,12 +712,13 @@ struct Sdf<RM_SCENE_MANDELBULB> {
   // headline frame's pixels end their camera ray this way and all of those their shadow ray (the skipped steps were ~5 % of
   // the frame's issue slots).  Exact: the end point has the bits the stepwise march produces (tested on the whole
   // frame against RM_RENDER_NO_FAR_JUMP); both implementations jump (cast_ray / cast_ray_block, wf_march) and stay bit-identical.
+  // (from r = 100 the overflow takes 18 steps, from 1e6 12: the rays a bounce starts a million units out -- :279 -- qualify with 16 left)
   static constexpr int far_jump_steps = 30;
   static RM_DEV bool far_jump_applies(const DevScene& sc) { return sc.p[RM_P_BULB_POWER] == 8.0f && sc.p[RM_P_BULB_ITERATIONS] >= 1.0f; }
   static RM_DEV bool far_jump(const DevScene& sc, v3 p, v3 dir, int left, v3& end) {
     const float bail2 = sc.p[RM_P_BULB_BAILOUT] * sc.p[RM_P_BULB_BAILOUT];
     const float r2 = FM::fma(p.z, p.z, pow8_rho2(p));  // what the evaluation starts with
-    if (!(r2 > gmax(bail2, 4.0f) && r2 < 1e30f) || left < far_jump_steps) return false;
+    if (!(r2 > gmax(bail2, 4.0f) && r2 < 1e30f) || left < (r2 >= 1e12f ? 16 : (r2 >= 1e4f ? 22 : far_jump_steps))) return false;
     const float s = dot<FM>(p, dir), dd = dot<FM>(dir, dir);
     if (!(s >= 0.0f && dd > 0.98f && dd < 1.02f)) return false;
     v3 e = dir * __builtin_inff();
@@ -782,6 +791,8 @@ template <> struct FarJump<RM_SCENE_MANDELBULB> { static constexpr bool value = 
 template <> struct FarJump<RM_KIND_BULB8> { static constexpr bool value = true; };
 template <> struct FarJump<RM_SCENE_TABLE> { static constexpr bool value = true; };
 template <> struct FarJump<RM_SCENE_MENGER> { static constexpr bool value = true; };
+template <> struct FarJump<RM_SCENE_KIFS_BOX> { static constexpr bool value = true; };
+template <> struct FarJump<RM_SCENE_SPHERE_GRID> { static constexpr bool value = true; };
 
 // kernels that may evaluate the power-8 Mandelbulb on the fast policy start with this (FM::omod_mode)
 template <int KIND, bool FAST> RM_DEV void enter_math_mode() {
@@ -801,6 +812,12 @@ struct Sdf<RM_SCENE_SPHERE_GRID> {
   static constexpr bool has_cost_classes = false;  // every evaluation costs the same
   static RM_DEV bool nonfinite_normal_is_nan(const DevScene&) { return false; }  // not shown for this kind: always evaluate
   static RM_DEV void stage(const DevScene& sc, SceneLds& lds) { stage_pow_table(lds, sc.p[RM_P_GRID_SCALE], -1.0f); }
+  // the far field, jumped (round 3; fast policy): the estimate is max(|p - centre| - bigSphereSize, carving), i.e. >= |p| - R' with
+  // R' = |centre| + bigSphereSize whatever the carving terms do; at the overflow of |p|^2 the sphere's distance is +Inf and
+  // max(Inf, x) is +Inf for every x (a NaN is dropped), so the position becomes +-Inf by the signs of the direction, where the
+  // grid's mod is NaN, min(NaN, 9999.9) keeps 9999.9 and max(Inf, -9999.9) is +Inf again: a fixed point (rm_api.hip sets far_r2).
+  static RM_DEV bool far_jump_applies(const DevScene& sc) { return sc.far_end == 1; }
+  static RM_DEV bool far_jump(const DevScene& sc, v3 p, v3 dir, int left, v3& end) { return far_escape(p, dir, left, sc.far_r2, true, end); }
   template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds& lds, v3 p) {
     const float* tab = reinterpret_cast<const float*>(lds.rows);
@@ -847,16 +864,8 @@ struct Sdf<RM_SCENE_MENGER> {
   // the position becomes +-Inf by the signs of the direction.  That is a fixed point: at an infinite coordinate the mod is
   // Inf - Inf = NaN, sdBox's max(q, 0) drops it and the crosses' distances are 0, max(Inf, -0) = Inf again.  Taken for
   // directions without a zero component only (0 x Inf = NaN; such rays march on).  Exact: tested against the stepwise march.
-  static constexpr int far_jump_steps = 72;
   static RM_DEV bool far_jump_applies(const DevScene&) { return true; }
-  static RM_DEV bool far_jump(const DevScene&, v3 p, v3 dir, int left, v3& end) {
-    const float r2 = FM::fma(p.z, p.z, FM::fma(p.y, p.y, p.x * p.x));
-    if (!(r2 > 25.0f && r2 < 1e30f) || left < far_jump_steps) return false;
-    const float s = dot<FM>(p, dir), dd = dot<FM>(dir, dir);
-    if (!(s >= 0.0f && dd > 0.98f && dd < 1.02f) || dir.x == 0.0f || dir.y == 0.0f || dir.z == 0.0f) return false;
-    end = dir * __builtin_inff();
-    return true;
-  }
+  static RM_DEV bool far_jump(const DevScene&, v3 p, v3 dir, int left, v3& end) { return far_escape(p, dir, left, 25.0f, true, end); }  // R' = 2.5 >= 1.8
   template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds& lds, v3 p) {
     const float* tab = reinterpret_cast<const float*>(lds.rows);
@@ -904,6 +913,10 @@ struct Sdf<RM_SCENE_KIFS_TREE> {
     const float* tab = reinterpret_cast<const float*>(lds.rows);
     const float iters = sc.p[RM_P_KIFS_ITERATIONS], scale = sc.p[RM_P_KIFS_SCALE], offset = sc.p[RM_P_KIFS_OFFSET];
     const bool smoothen = sc.p[RM_P_KIFS_SMOOTH] == 1.0f;
+    if (M::fast && sc.far_end == 3) {  // beyond |p| = 9999 + R' the estimate is its starting value (rm_api.hip kifs_far_field): the same bits
+      const float r2 = FM::fma(p.z, p.z, FM::fma(p.y, p.y, p.x * p.x));
+      if (r2 > sc.far_r2 && r2 < 1e14f) return 9999.0f;
+    }
     const KifsTrig g = kifs_trig(sc);
     v3 t = p;
     float min_dist = 9999.0f;
@@ -924,6 +937,9 @@ struct Sdf<RM_SCENE_KIFS_TREE> {
 template <>
 struct Sdf<RM_SCENE_KIFS_BOX> {
   static constexpr bool has_cost_classes = false;  // every evaluation costs the same
+  // the far field, jumped (round 3; fast policy; rm_api.hip kifs_far_field has the argument and sets far_end / far_r2)
+  static RM_DEV bool far_jump_applies(const DevScene& sc) { return sc.far_end == 1; }
+  static RM_DEV bool far_jump(const DevScene& sc, v3 p, v3 dir, int left, v3& end) { return far_escape(p, dir, left, sc.far_r2, true, end); }
   static RM_DEV bool nonfinite_normal_is_nan(const DevScene&) { return false; }  // not shown for this kind: always evaluate
   static RM_DEV void stage(const DevScene&, SceneLds&) {}
   template <class M>

@@ -1431,7 +1431,7 @@ def test_far_jump_end_points_equal_the_stepwise_march(ctx):
         d[n // 8: n // 4, int(rng.integers(0, 3))] = 0.0                                                # one zero component, not renormalised
         d[n // 4: n // 4 + 256] *= 0.5                                                                  # not unit: the jump must not apply
         rays = np.concatenate([o, d], 1).astype(np.float32)
-        for steps in (10.0, 29.0, 30.0, 31.0, 64.0, 256.0):
+        for steps in (10.0, 15.0, 16.0, 17.0, 21.0, 22.0, 23.0, 29.0, 30.0, 31.0, 64.0, 256.0):  # around the 16 / 22 / 30 the jump asks for by distance
             a = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST)
             b = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST | abi.RM_RENDER_NO_FAR_JUMP)
             assert same_bits(a, b).all(), f"scene {it}, {steps} steps: {int((~same_bits(a, b)).any(-1).sum())} end points differ"
@@ -1487,7 +1487,7 @@ def test_table_far_jump_end_points_equal_the_stepwise_march(ctx):
         d[n // 8: n // 4, int(rng.integers(0, 3))] = 0.0
         d[n // 4: n // 4 + 128] *= 0.5
         rays = np.concatenate([o, d], 1).astype(np.float32)
-        for steps in (60.0, 71.0, 72.0, 73.0, 128.0, 256.0):
+        for steps in (40.0, 47.0, 48.0, 49.0, 59.0, 60.0, 61.0, 71.0, 72.0, 73.0, 128.0, 256.0):  # around the 48 / 60 / 72 the jump asks for by distance
             a = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST)
             b = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST | abi.RM_RENDER_NO_FAR_JUMP)
             assert same_bits(a, b).all(), f"table {it}, {steps} steps: {int((~same_bits(a, b)).any(-1).sum())} end points differ"
@@ -1518,12 +1518,85 @@ def test_menger_far_jump_is_exact(ctx):
         d[: n // 8] = np.eye(3)[rng.integers(0, 3, n // 8)] * rng.choice([-1.0, 1.0], size=(n // 8, 1))
         d[n // 8: n // 4, int(rng.integers(0, 3))] = 0.0
         rays = np.concatenate([o, d], 1).astype(np.float32)
-        for steps in (60.0, 71.0, 72.0, 73.0, 128.0, 256.0):
+        for steps in (40.0, 47.0, 48.0, 49.0, 59.0, 60.0, 61.0, 71.0, 72.0, 73.0, 128.0, 256.0):
             a = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST)
             b = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST | abi.RM_RENDER_NO_FAR_JUMP)
             assert same_bits(a, b).all(), f"iterations {iters}, {steps} steps: {int((~same_bits(a, b)).any(-1).sum())} end points differ"
         assert (~np.isfinite(ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, 256.0, FAST)).all(-1)).mean() > 0.3
         h.destroy()
+
+
+def test_sphere_grid_far_jump_is_exact(ctx):
+    """The sphere-grid fractal (the reference's fractal1 / guide example, the scene its page starts with) lives inside its big
+    sphere; a ray that leaves it escapes (Sdf<RM_SCENE_SPHERE_GRID>::far_jump).  Random parameters; castRay end points at
+    budgets around the jump's requirements and the live default job [128, 128, 64, 32, 32] as an image, both
+    implementations: the bits of the stepwise march."""
+    rng = np.random.default_rng(1313 + SEED_OFFSET)
+    for it in range(8):
+        sc = S.SphereGridFractal() if it == 0 else S.SphereGridFractal(big_sphere_size=float(rng.uniform(2.0, 6.0)), iterations=float(rng.integers(1, 9)),
+                                                                      grid_scale=float(rng.uniform(0.2, 0.6)),
+                                                                      big_sphere_center=(float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1)), float(rng.uniform(6.0, 12.0))))
+        h = ctx.create_scene(sc)
+        n = 4096
+        o = rng.normal(size=(n, 3)) * rng.choice([1.0, 10.0, 40.0, 5e3, 1e6, 3e7], size=(n, 1))
+        d = rng.normal(size=(n, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        d[: n // 8] = np.eye(3)[rng.integers(0, 3, n // 8)] * rng.choice([-1.0, 1.0], size=(n // 8, 1))
+        rays = np.concatenate([o, d], 1).astype(np.float32)
+        for steps in (32.0, 47.0, 48.0, 49.0, 59.0, 60.0, 61.0, 64.0, 71.0, 72.0, 73.0, 128.0):
+            a = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST)
+            b = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST | abi.RM_RENDER_NO_FAR_JUMP)
+            assert same_bits(a, b).all(), f"scene {it}, {steps} steps: {int((~same_bits(a, b)).any(-1).sum())} end points differ"
+        h.destroy()
+        if it < 3:
+            schema = J.make_schema(sc, 320, 180, counts=(128, 128, 64, 32, 32), render_mode="full", position=(0.0, 0.0, 0.0))
+            noises = GC.halton_pairs(2)
+            ref = render_gpu(ctx, sc, schema, noises, FAST | MK | abi.RM_RENDER_NO_FAR_JUMP)
+            for impl in (MK, WF):
+                got = render_gpu(ctx, sc, schema, noises, FAST | impl)
+                for k in range(3):
+                    assert same_bits(got[k], ref[k]).all(), f"scene {it}, plane {k}: {int((~same_bits(got[k], ref[k])).sum())} values differ"
+
+
+def test_kifs_far_field_shortcuts_are_exact(ctx):
+    """The kaleidoscopic kinds (rm_api.hip kifs_far_field): the rotation fractal's escaping rays are set to their end state
+    (Sdf<RM_SCENE_KIFS_BOX>::far_jump), and the tree's evaluation returns its starting value 9999 beyond |p| = 9999 + R'
+    without running its levels (plain and smooth).  Random parameters (iterations, scale, angles, offset): the distance at
+    points from the scene out to 1e7, castRay end points at several budgets and whole images, both implementations, equal
+    the unshortened arithmetic (RM_RENDER_NO_FAR_JUMP) bit for bit."""
+    rng = np.random.default_rng(1212 + SEED_OFFSET)
+    for it in range(18):
+        kind = it % 3
+        if kind == 0:
+            sc = S.KifsBox(iterations=float(rng.integers(1, 17)), scale=float(rng.uniform(0.35, 0.7)), angles=tuple(rng.uniform(-1.5, 1.5, 3)), offset=float(rng.uniform(0.7, 1.6)))
+        else:
+            sc = S.KifsTree(iterations=float(rng.integers(1, 15)), scale=float(rng.uniform(0.55, 0.8)), angles=tuple(rng.uniform(-3, 3, 3)),
+                            offset=float(rng.uniform(0.8, 1.5)), smoothen=kind == 2)
+        h = ctx.create_scene(sc)
+        n = 4096
+        o = rng.normal(size=(n, 3)) * rng.choice([1.0, 10.0, 5e3, 1e4, 2e4, 1e6, 1e7], size=(n, 1))
+        a = ctx.probe(h, abi.RM_PROBE_SDF, o.astype(np.float32), 0.0, FAST)
+        b = ctx.probe(h, abi.RM_PROBE_SDF, o.astype(np.float32), 0.0, FAST | abi.RM_RENDER_NO_FAR_JUMP)
+        assert same_bits(a, b).all(), f"scene {it}: {int((~same_bits(a, b)).sum())} distances differ"
+        if kind != 0:
+            assert (a == 9999.0).mean() > 0.3  # the far points do see the starting value
+        d = rng.normal(size=(n, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        d[: n // 8] = np.eye(3)[rng.integers(0, 3, n // 8)] * rng.choice([-1.0, 1.0], size=(n // 8, 1))
+        rays = np.concatenate([rng.normal(size=(n, 3)) * rng.choice([1.0, 5.0, 1e3, 1e6], size=(n, 1)), d], 1).astype(np.float32)
+        for steps in (40.0, 48.0, 49.0, 60.0, 61.0, 72.0, 73.0, 128.0, 256.0):
+            ra = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST)
+            rb = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST | abi.RM_RENDER_NO_FAR_JUMP)
+            assert same_bits(ra, rb).all(), f"scene {it}, {steps} steps: {int((~same_bits(ra, rb)).any(-1).sum())} end points differ"
+        h.destroy()
+        if it < 6:
+            schema = J.make_schema(sc, 320, 192, counts=(128, 80), render_mode="full", position=(0.2, 0.1, -3.5), lights=GC.LIGHT)
+            noises = GC.halton_pairs(2)
+            ref = render_gpu(ctx, sc, schema, noises, FAST | MK | abi.RM_RENDER_NO_FAR_JUMP)
+            for impl in (MK, WF):
+                got = render_gpu(ctx, sc, schema, noises, FAST | impl)
+                for k in range(3):
+                    assert same_bits(got[k], ref[k]).all(), f"scene {it}, plane {k}: {int((~same_bits(got[k], ref[k])).sum())} values differ"
 
 
 # How far the fast build may be from the parity build, ANCHORED: GLSL leaves the precision of sin / cos / log / pow / acos /
