@@ -961,17 +961,22 @@ static hipError_t launch_wavefront(rm_ctx* ctx, const KParams& P, int flags) {
 }
 
 // Which implementation of the per-pixel program runs a job (same results either way).
-// Measured on MI355X in round 2 (bench.py --workload ..., fast build, ms per sample, pixel kernel / wavefront pipeline):
+// Measured on MI355X (fast build, ms per sample, pixel kernel / wavefront pipeline).  Round 2:
 //   Mandelbulb 3840x2160 full      2.49 / 4.5         sphere 1080p preview 0.11 / 1.4
 //   CSG-64 4096x512  (2 Mpx)       6.79 / 7.67        CSG-64 4096x4096 (16.8 Mpx)  47.0 / 40.6
 //   CSG-64 8192x1024 (8.4 Mpx)     60.5 / 54.6        CSG-64 8192x8192 (67 Mpx)    467  / 415
-// The one-kernel form wins everywhere except on large full-mode frames of long primitive tables, where the pipeline's
-// global ray compaction over very many long, uniform evaluations outweighs its per-ray state traffic (10-16 %).
+// Round 3, with the far-field jump in both and the compacting pixel kernel for long tables (RM_KIND_TABLE_BIG; tools/r03_table.py):
+//   Mandelbulb 3840x2160 full      1.98 / 4.0
+//   CSG-64 4096^2, rank 0's 1/8    2.33 / 6.33        CSG-64 4096x4096             15.3 / 14.4
+//   CSG-64 8192^2, rank 0's 1/8    31.5 / 33.1        CSG-64 8192x8192             244  / 229
+// The one-kernel form wins everywhere except on full-mode frames of >= 2^24 pixels over long primitive tables, where the
+// pipeline's global ray compaction still issues ~6 % fewer instructions than the workgroup-level one (it was 10-16 % before
+// the pixel kernel compacted its table rays, and the threshold was 2^23).
 static bool prefer_wavefront(const KParams& P, int flags) {
   (void)flags;
   if (P.u.renderMode == 1) return false;
   if (P.scene.table_flags & RM_TABLE_HAS_SURFACES) return false;  // (see uses_wavefront)
-  if ((long long)P.tw * (long long)P.th < (1ll << 23)) return false;
+  if ((long long)P.tw * (long long)P.th < (1ll << 24)) return false;
   return P.scene.kind == RM_SCENE_TABLE && P.scene.nprims >= 16;
 }
 

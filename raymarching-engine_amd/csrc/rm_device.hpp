@@ -785,11 +785,22 @@ struct Sdf<RM_KIND_BULB8> : Sdf<RM_SCENE_MANDELBULB> {
   static RM_DEV bool far_jump_applies(const DevScene&) { return true; }
 };
 
+// A primitive table of many rows in full mode (rm_params.hpp rm_table_big): the same program as RM_SCENE_TABLE in a pixel kernel
+// that compacts its rays like the Mandelbulb's (8-wave workgroups).  Since the far-field jump an escaping ray leaves its lane
+// at once while its neighbours march on -- lanes active fell to 57 % on BASELINE's CSG-64 frames -- and an evaluation of 64
+// rows is long enough to pay for the barriers: C4's 1/8 stripes 3.19 -> 2.38 ms, C5's 34.7 -> 31.4, C4's frame 19.2 -> 15.3;
+// short tables lose (a single sphere +20 %, a 5-row mixed table +8 %) and keep the plain kernel.  Internal, like RM_KIND_BULB8.
+#define RM_KIND_TABLE_BIG (RM_SCENE_KIND_COUNT + 1)
+template <>
+struct Sdf<RM_KIND_TABLE_BIG> : Sdf<RM_SCENE_TABLE> {};
+template <int KIND> struct IsTable { static constexpr bool value = KIND == RM_SCENE_TABLE || KIND == RM_KIND_TABLE_BIG; };
+
 // kinds whose fast march may jump an escaping ray to its end state (Sdf<RM_SCENE_MANDELBULB>::far_jump)
 template <int KIND> struct FarJump { static constexpr bool value = false; };
 template <> struct FarJump<RM_SCENE_MANDELBULB> { static constexpr bool value = true; };
 template <> struct FarJump<RM_KIND_BULB8> { static constexpr bool value = true; };
 template <> struct FarJump<RM_SCENE_TABLE> { static constexpr bool value = true; };
+template <> struct FarJump<RM_KIND_TABLE_BIG> { static constexpr bool value = true; };
 template <> struct FarJump<RM_SCENE_MENGER> { static constexpr bool value = true; };
 template <> struct FarJump<RM_SCENE_KIFS_BOX> { static constexpr bool value = true; };
 template <> struct FarJump<RM_SCENE_SPHERE_GRID> { static constexpr bool value = true; };

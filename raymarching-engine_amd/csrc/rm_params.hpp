@@ -62,6 +62,12 @@ struct KParams {
   int no_far_jump;  // RM_RENDER_NO_FAR_JUMP: march escaping rays step by step (a measurement / test switch, same bits)
 };
 
+// a table long enough for the compacting pixel kernel (rm_device.hpp RM_KIND_TABLE_BIG); launcher and grid computation agree through this
+#define RM_TABLE_BIG_ROWS 16
+__host__ __device__ inline bool rm_table_big(const KParams& P) {
+  return P.scene.kind == RM_SCENE_TABLE && P.scene.nprims >= RM_TABLE_BIG_ROWS && P.u.renderMode == 0;
+}
+
 // image row of a local (plane) row
 __host__ __device__ inline int rm_global_row(const KParams& P, int local) {
   if (P.stripe_rows <= 0) return P.row_begin + local;

@@ -18,6 +18,7 @@ soft = [J.point_light((2.0, 3.0, -4.0), size=0.3)]
 cases = [("c4 full", S.csg64(), dict(width=4096, height=4096, counts=(128,), render_mode="full", position=(0, 0, -5.0), lights=GC.LIGHT), None, (MK, WF)),
          ("c4 shard/8", S.csg64(), dict(width=4096, height=4096, counts=(128,), render_mode="full", position=(0, 0, -5.0), lights=GC.LIGHT), 8, (MK, WF)),
          ("c5 shard/8", S.csg64(), dict(width=8192, height=8192, counts=(128, 64, 64), render_mode="full", position=(0, 0, -5.0), lights=soft), 8, (MK, WF)),
+         ("c5 full", S.csg64(), dict(width=8192, height=8192, counts=(128, 64, 64), render_mode="full", position=(0, 0, -5.0), lights=soft), None, (MK, WF)),
          ("c2", S.single_sphere(), dict(width=1920, height=1080, counts=(128,), render_mode="preview", position=(0, 0, -3.0)), None, (MK,)),
          ("csg_mixed 1080p", GC.build_scene("csg_mixed"), dict(width=1920, height=1080, counts=(128, 64), render_mode="full", position=(0.3, 0.2, -4.0), lights=GC.LIGHT), None, (MK,))]
 for name, sc, kw, parts, impls in cases:
