@@ -232,6 +232,7 @@ def main():
     ap.add_argument("--dof", action="store_true", help="give the job the live default depth of field (dof.amount 0.01 at 1.5): a sharded present then "
                                                        "gathers the packed (colour, DoF radius) rows and rank 0 runs the blur")
     ap.add_argument("--no-far-jump", action="store_true", help="RM_RENDER_NO_FAR_JUMP: march escaping rays step by step (measurement switch, same bits)")
+    ap.add_argument("--no-cull", action="store_true", help="RM_RENDER_NO_CULL: fold every row of a primitive table at every point (measurement switch, same bits)")
     ap.add_argument("--check-frame", action="store_true",
                     help="sharded runs: after the timed legs rank 0 renders the same samples on ONE framebuffer, presents it and compares "
                          "the bytes with the frame it assembled from the gathered rows (reported as `frame_check`)")
@@ -290,6 +291,8 @@ def main():
         flags |= abi.RM_RENDER_WAVEFRONT
     if args.no_far_jump:
         flags |= abi.RM_RENDER_NO_FAR_JUMP
+    if args.no_cull:
+        flags |= abi.RM_RENDER_NO_CULL
 
     # The job runs through the render-job API (job.do_render_job on a job.RenderJobContext): sharded, the context owns this
     # rank's striped framebuffer and the gatherers, and makes a torch stream of its own current for renders, snapshots, the

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RM_ABI_VERSION 5 /* 3: rm_ctx_set_sample_batch, rm_buffer_*; 4: rm_ctx_set_gl_stack; 5: RmSurface / RmSceneDesc.surfaces (the struct grew), rm_pack_present_rows, rm_present_sharded, rm_ctx_last_pipeline, RM_RENDER_NO_FAR_JUMP (additions only) */
+#define RM_ABI_VERSION 5 /* 3: rm_ctx_set_sample_batch, rm_buffer_*; 4: rm_ctx_set_gl_stack; 5: RmSurface / RmSceneDesc.surfaces (the struct grew), rm_pack_present_rows, rm_present_sharded, rm_ctx_last_pipeline, RM_RENDER_NO_FAR_JUMP, RM_RENDER_NO_CULL (additions only) */
 
 #define RM_MAX_BOUNCES 10 /* raymarchingStepCountsArray[10], raymarcher.frag:31 */
 #define RM_MAX_LIGHTS 10  /* lightPositions[10],             raymarcher.frag:37-39 */
@@ -211,10 +211,16 @@ enum {
                                    point (Mandelbulb); a measurement switch, same results */
   RM_RENDER_NO_OVERLAP = 32, /* this sample runs alone on the context's stream and blends in its own kernel (see
                                 rm_ctx_set_samples_in_flight); for timing one launch.  Same results. */
-  RM_RENDER_NO_FAR_JUMP = 64 /* RM_RENDER_FAST, power-8 Mandelbulb: march an escaping ray step by step instead of setting
+  RM_RENDER_NO_FAR_JUMP = 64, /* RM_RENDER_FAST, bounded scenes (Mandelbulb, tables without domain rows, the sponge, the
+                                rotation and sphere-grid fractals): march an escaping ray step by step instead of setting
                                 it to the end state its remaining steps are known to reach (castRay, raymarcher.frag:163-170,
                                 has no distance bound: such a ray overflows to a fixed +-Inf / NaN pattern).  A measurement
                                 and test switch: the same bits either way. */
+  RM_RENDER_NO_CULL = 128     /* RM_RENDER_FAST, long primitive tables built with union / subtract / intersect: evaluate every row
+                                of the table at every point instead of the rows the point's grid cell lists (a row whose operator
+                                is an exact no-op everywhere in the cell is skipped: min(d, di) with the shape further away than
+                                the running value, max(d, +-di) with the term below it; smooth unions are never skipped).  A
+                                measurement and test switch: the same bits either way. */
 };
 
 enum { RM_PLANE_COLOR = 0, RM_PLANE_NORMAL_DOF = 1, RM_PLANE_ALBEDO_DEPTH = 2 };
@@ -284,6 +290,13 @@ int rm_ctx_set_gl_stack(rm_ctx* ctx, int on);
  * -DRM_WF_STATS (zeros otherwise): out16[8*shadow + 4*pass2 + {0,1,2}] =
  * rays marched, lane-steps, wave-steps since the last reset. */
 int rm_debug_counters(rm_ctx* ctx, unsigned long long* out16, int reset);
+
+/* Debug (tests): the rows of a primitive table (no domain rows) that an evaluation anywhere in the ball (centre, radius) has
+ * to fold -- what the culling grid of RM_RENDER_FAST stores per cell (RM_RENDER_NO_CULL) -- as (nprims + 63) / 64 64-bit words,
+ * bit i = row i stays (row 0 and smooth-union rows always do); `margin` = the allowance for fp32 rounding (0 tests the rule in
+ * exact arithmetic).  Host arithmetic:
+ * needs no GPU and no context.  Returns RM_ERR_INVALID for a table with domain rows. */
+int rm_debug_cull_cell(const RmSceneDesc* desc, const double* centre, double radius, double margin, unsigned long long* out_words);
 /* Which implementation of the per-pixel program the LAST rm_render_sample(s) / rm_render_timed call on this context
  * dispatched (the library picks per job unless a flag forces one; same results either way): what a host reports next to a
  * timing instead of re-deriving the library's rule. */

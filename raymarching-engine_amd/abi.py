@@ -18,6 +18,7 @@ RM_OP_UNION, RM_OP_SMOOTH_UNION, RM_OP_SUBTRACT, RM_OP_INTERSECT = 0, 1, 2, 3
 RM_RENDER_STRICT, RM_RENDER_FAST, RM_RENDER_COLOR_ONLY, RM_RENDER_MEGAKERNEL, RM_RENDER_NO_COST_CLASSES, RM_RENDER_WAVEFRONT = 0, 1, 2, 4, 8, 16
 RM_RENDER_NO_OVERLAP = 32
 RM_RENDER_NO_FAR_JUMP = 64
+RM_RENDER_NO_CULL = 128
 RM_PIPELINE_NONE, RM_PIPELINE_PIXEL_KERNEL, RM_PIPELINE_WAVEFRONT = 0, 1, 2
 RM_PLANE_COLOR, RM_PLANE_NORMAL_DOF, RM_PLANE_ALBEDO_DEPTH = 0, 1, 2
 RM_PROBE_SDF, RM_PROBE_CAST_RAY, RM_PROBE_NORMAL, RM_PROBE_MATERIAL, RM_PROBE_CAST_STEPS = 0, 1, 2, 3, 4

@@ -113,6 +113,7 @@ struct rm_scene {
   DevScene dev{};
   RmPrim* d_prims = nullptr;
   RmSurface* d_surfaces = nullptr;
+  unsigned long long* d_cull = nullptr;
 };
 
 struct rm_fb {
@@ -381,6 +382,77 @@ static void table_far_field(const RmSceneDesc* desc, DevScene* dev) {
   dev->far_end = d == inf ? 1 : (d != d ? 2 : 0);
 }
 
+// The culling grid of a primitive table without domain rows (rm_params.hpp CullGrid; rm_kernels.inc rm_cull_build_kernel has the
+// argument and fills it on the device; fast policy only): nested cubes of RM_CULL_N^3 cells about the shapes' bounding box, each
+// twice as wide as the one before, out to where fp32 no longer tells the rows apart.
+// For tables of at least RM_CULL_MIN_ROWS rows of which at least half stand under union / subtract / intersect.
+#ifndef RM_CULL_MIN_ROWS
+#define RM_CULL_MIN_ROWS 12
+#endif
+#ifndef RM_CULL_N
+#define RM_CULL_N 32
+#endif
+#ifndef RM_CULL_MAX_LEVELS
+#define RM_CULL_MAX_LEVELS 18
+#endif
+static bool table_cull_params(const RmSceneDesc* desc, CullGrid* g, CullBuild* build) {
+  *g = CullGrid{};
+  *build = CullBuild{};
+  const int n = desc->nprims;
+  if (n < RM_CULL_MIN_ROWS) return false;
+  if (const char* v = std::getenv("RM_NO_CULL"))
+    if (v[0] == '1') return false;
+  double lo[3] = {1e30, 1e30, 1e30}, hi[3] = {-1e30, -1e30, -1e30}, kmax = 0.0;
+  int cullable = 0;  // rows under union / subtract / intersect: a smooth union is never dropped (rm_device.hpp smooth_row)
+  for (int i = 0; i < n; i++) {
+    const RmPrim& p = desc->prims[i];
+    const int type = p.type & 0xff;
+    if (type != RM_PRIM_SPHERE && type != RM_PRIM_BOX) return false;  // domain rows: no grid in the table's own space
+    if (i > 0 && ((p.type >> 8) & 0xff) != RM_OP_SMOOTH_UNION) cullable++;
+    for (int a = 0; a < 3; a++) {
+      const double e = std::fabs((double)(type == RM_PRIM_SPHERE ? p.size[0] : p.size[a]));
+      lo[a] = std::fmin(lo[a], p.center[a] - e);
+      hi[a] = std::fmax(hi[a], p.center[a] + e);
+    }
+    if (((p.type >> 8) & 0xff) == RM_OP_SMOOTH_UNION) kmax = std::fmax(kmax, (double)p.k);
+  }
+  if (cullable * 2 < n) return false;  // mostly smooth unions: the grid would cost more than it saves
+  double half = 0.0, reach = 0.0;
+  for (int a = 0; a < 3; a++) {
+    half = std::fmax(half, 0.5 * (hi[a] - lo[a]));
+    reach = std::fmax(reach, std::fmax(std::fabs(lo[a]), std::fabs(hi[a])));
+    build->centre[a] = 0.5 * (lo[a] + hi[a]);
+  }
+  half = 1.1 * half + kmax + 1e-3;
+  if (!(half < 1e6) || !(reach < 1e6)) return false;
+  // levels: out to where the fp32 allowance of the build kernel (1.2e-7 (n + 8) |coordinates|) exceeds the scene's own width
+  int levels = 1;
+  while (levels < RM_CULL_MAX_LEVELS && 1.2e-7 * (n + 8) * 1.74 * std::ldexp(half, levels) < 2.0 * half) levels++;
+  build->half0 = half;
+  build->reach = reach;
+  build->nprims = n;
+  build->n = RM_CULL_N;
+  build->levels = levels;
+  build->words = (n + 63) / 64;
+  for (int a = 0; a < 3; a++) g->centre[a] = (float)build->centre[a];
+  g->inv_half0 = (float)(1.0 / half);
+  g->scale0 = (float)(RM_CULL_N / (2.0 * half));
+  g->n = RM_CULL_N;
+  g->levels = levels;
+  g->words = build->words;
+  return true;
+}
+
+int rm_debug_cull_cell(const RmSceneDesc* desc, const double* centre, double radius, double margin, unsigned long long* out_words) {
+  if (!desc || !centre || !out_words || desc->kind != RM_SCENE_TABLE || desc->nprims < 1 || desc->nprims > RM_MAX_PRIMS || !desc->prims) return RM_ERR_INVALID;
+  for (int i = 0; i < desc->nprims; i++) {
+    const int type = desc->prims[i].type & 0xff;
+    if (type != RM_PRIM_SPHERE && type != RM_PRIM_BOX) return RM_ERR_INVALID;
+  }
+  rm_cull_cell(desc->prims, desc->nprims, (desc->nprims + 63) / 64, centre, radius, margin, out_words);
+  return RM_OK;
+}
+
 // The far field of the kaleidoscopic kinds (rm_device.hpp Sdf<RM_SCENE_KIFS_BOX>::far_jump, Sdf<RM_SCENE_KIFS_TREE>::eval).
 // A level maps t to rotate(|t / s| - off): norms obey |t'| >= |t| / s - |off|, so after n levels |t_n| s^n >= |p| - |off| s / (1 - s),
 // and sdBox(q, b) >= |q| - |b|: every level's box is >= |p| - R' with R' = |off| s / (1 - s) + |b| (b <= the unit-level box).
@@ -518,6 +590,26 @@ int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out) {
     }
     s->dev.prims = s->d_prims;
   }
+  if (desc->kind == RM_SCENE_TABLE) {
+    CullGrid g;
+    CullBuild build;
+    if (table_cull_params(desc, &g, &build)) {
+      const size_t bytes = ((size_t)g.n * g.n * g.n * (size_t)g.levels + 1) * (size_t)g.words * sizeof(unsigned long long);
+      hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_cull), bytes);
+      build.prims = s->d_prims;
+      build.cells = s->d_cull;
+      if (e == hipSuccess) e = rm::launch_cull_build(build, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e != hipSuccess) {
+        if (s->d_cull) (void)hipFree(s->d_cull);
+        if (s->d_prims) (void)hipFree(s->d_prims);
+        delete s;
+        return fail(ctx, RM_ERR_DEVICE, std::string("rm_scene_create: ") + hipGetErrorString(e));
+      }
+      g.cells = s->d_cull;
+      s->dev.cull = g;
+    }
+  }
   if (s->dev.table_flags & RM_TABLE_HAS_SURFACES) {  // entry 0 = the scene's own material block, then the surfaces as given
     RmSurface all[RM_MAX_SURFACES + 1];
     const RmMaterial& m = desc->material;
@@ -529,6 +621,7 @@ int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out) {
     if (e == hipSuccess) e = hipMemcpy(s->d_surfaces, all, bytes, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
       if (s->d_surfaces) (void)hipFree(s->d_surfaces);
+      if (s->d_cull) (void)hipFree(s->d_cull);
       if (s->d_prims) (void)hipFree(s->d_prims);
       delete s;
       return fail(ctx, RM_ERR_DEVICE, std::string("rm_scene_create: ") + hipGetErrorString(e));
@@ -546,6 +639,7 @@ void rm_scene_destroy(rm_scene* scene) {
   (void)hipStreamSynchronize(scene->ctx->stream);
   if (scene->d_prims) (void)hipFree(scene->d_prims);
   if (scene->d_surfaces) (void)hipFree(scene->d_surfaces);
+  if (scene->d_cull) (void)hipFree(scene->d_cull);
   delete scene;
 }
 
@@ -793,6 +887,7 @@ static int build_params(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniform
   P->block_cost = nullptr;
   P->no_far_jump = (flags & RM_RENDER_NO_FAR_JUMP) ? 1 : 0;
   if (P->no_far_jump) P->scene.far_end = 0;  // the far-field shortcuts inside an evaluation (KIFS tree) read the scene block
+  if (flags & RM_RENDER_NO_CULL) P->scene.cull.cells = nullptr;
   return RM_OK;
 }
 
@@ -1411,6 +1506,7 @@ int rm_probe(rm_ctx* ctx, rm_scene* scene, int what, const float* in, int n, flo
   if (e == hipSuccess) {
     ProbeParams P{scene->dev, d_in, d_out, n, what, param, (flags & RM_RENDER_FAST) ? ctx->retire_eps : 0.0f, (flags & RM_RENDER_NO_FAR_JUMP) ? 1 : 0};
     if (P.no_far_jump) P.scene.far_end = 0;
+    if (flags & RM_RENDER_NO_CULL) P.scene.cull.cells = nullptr;
     e = (flags & RM_RENDER_FAST) ? rm::launch_probe_fast(P, ctx->stream) : ctx->gl_stack ? rm_gl_launch_probe(&P, ctx->stream) : rm::launch_probe_strict(P, ctx->stream);
   }
   if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream);

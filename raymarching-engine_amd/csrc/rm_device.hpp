@@ -399,6 +399,11 @@ struct Sdf<RM_SCENE_TABLE> {
   // (Tried: a per-wave branch around the fold for spheres further than k behind the running distance -- h = 1 there
   // and the fold is the single subtraction di - (di - d), same bits.  The branch per row breaks the two-row software
   // pipeline: CSG-64 4096^2 went from 56 to 65 ms.  Not kept.)
+  // (Round 3 tried the same polynomial written from the running value's side, d + g (t - k + k g) with g = 1 - h, which returns
+  // d itself once a shape is further than k away and so lets an evaluation skip such rows exactly: C4 14.2 -> 7.0 ms -- and 14 %
+  // fewer lit pixels, because the rounding of d to the grid of (di - d) that THIS form, like the reference's mix(d2, d1, 1), performs
+  // for every far row is the noise the creeping shadow rays of a smooth-union scene live on.  Not kept:
+  // profiles/r03_row_culling_smooth_union_experiment.txt.  Smooth-union rows are never culled.)
   static RM_DEV float smooth_row(float d, float di, float k, float half_inv_k) {
     const float t = di - d;  // d - di is -t exactly (up to the sign of a zero): one subtraction instead of two
     const float h = gclamp(FM::fma(half_inv_k, t, 0.5f), 0.0f, 1.0f);
@@ -439,6 +444,141 @@ struct Sdf<RM_SCENE_TABLE> {
       const float4 a0 = lds.rows[2 * i], b0 = lds.rows[2 * i + 1];
       d = smooth_row(d, sphere_row(a0, b0, p), a0.y, b0.z);
     }
+    return d;
+  }
+  // ---- row culling (round 3; fast policy; tables without domain rows; rm_params.hpp rm_cull_cell has the rule) ------------------
+  // A row whose operator cannot change the running value of the fold is an exact no-op: min(d, di) with di >= d, max(d, -di) and
+  // max(d, di) with the term below d.  (Not the smooth union: see smooth_row.)  The scene's grid lists, per cell, the rows for which
+  // that cannot be said of every point of the cell; an evaluation folds the rows listed for ITS WAVE's points -- the union of the
+  // lanes' cells, so that the loop stays wave-uniform and the rows come from LDS by one address; a row listed for a neighbour is
+  // a no-op for this lane by construction -- in table order; lanes too far apart for a common set fold their own rows.  Same bits
+  // as the whole table (RM_RENDER_NO_CULL).
+  static RM_DEV const unsigned long long* cull_cell(const CullGrid& g, v3 p) {
+    const float x = p.x - g.centre[0], y = p.y - g.centre[1], z = p.z - g.centre[2];
+    const float t = gmax(fabsf(x), gmax(fabsf(y), fabsf(z))) * g.inv_half0;  // the max-norm in units of level 0's half-width
+    // level: 0 inside level 0's cube, else ceil(log2 t) read off the exponent (t in [2^(l-1), 2^l) -> l); a point with a NaN or an
+    // Inf and anything beyond the last level get the cell that lists every row
+    const int e = (int)((__float_as_uint(t) >> 23) & 0xffu) - 126;
+    const int level = t < 1.0f ? 0 : e;
+    // (v_max drops a NaN, so t does not see one: the 1-norm does -- NaN or Inf for a point with a non-finite coordinate)
+    const bool inside = fabsf(x) + fabsf(y) + fabsf(z) < 3.0e38f && level < g.levels;
+    const float scale = g.scale0 * __uint_as_float((unsigned int)(127 - (inside ? level : 0)) << 23);  // scale0 * 2^-level
+    const float h = 0.5f * (float)g.n;
+    const int top = g.n - 1;
+    const int ix = min(max(__float2int_rd(FM::fma(x, scale, h)), 0), top), iy = min(max(__float2int_rd(FM::fma(y, scale, h)), 0), top),
+              iz = min(max(__float2int_rd(FM::fma(z, scale, h)), 0), top);
+    const int per_level = g.n * g.n * g.n;
+    const int idx = inside ? level * per_level + (iz * g.n + iy) * g.n + ix : g.levels * per_level;
+    return g.cells + (size_t)idx * (size_t)g.words;
+  }
+  // the union of the active lanes' row sets, as a scalar: the first lane's set, then -- a few times -- the set of the first lane that
+  // still has a row outside it (lanes of a wave sit in the same or in neighbouring cells); after that, every row of the word
+  static RM_DEV unsigned long long wave_union(unsigned long long mine, unsigned long long every) {
+    const unsigned int lo = (unsigned int)mine, hi = (unsigned int)(mine >> 32);
+    unsigned long long u = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)hi) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)lo);
+#ifndef RM_CULL_UNION_ROUNDS
+#define RM_CULL_UNION_ROUNDS 3
+#endif
+#pragma unroll
+    for (int it = 0; it < RM_CULL_UNION_ROUNDS; it++) {
+      const unsigned long long more = ballot((mine & ~u) != 0ull);
+      if (more == 0ull) return u;
+      const int src = __builtin_ctzll(more);
+      u |= ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)hi, src) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)lo, src);
+    }
+    return ballot((mine & ~u) != 0ull) != 0ull ? every : u;
+  }
+  // calls row(i, uniform) for the rows 1 .. n-1 this lane has to fold, in table order -- uniform: every lane of the wave is at row
+  // i (two at a time where there are two, rows2(i, j): the LDS reads of both are in flight during the arithmetic); else the lanes
+  // are at rows of their own; row 0 starts the fold and is the caller's
+#ifndef RM_CULL_MODE
+#define RM_CULL_MODE 2  // 0: the wave folds the union of its lanes' rows; 1: every lane folds its own rows; 2: the union when three lanes' sets cover it, else per lane
+#endif
+  // returns false (mode 3, before any row was folded) when the wave's lanes are too far apart for a common row set: the caller
+  // then folds the whole table
+  template <class F1, class F2>
+  static RM_DEV bool culled_rows(const DevScene& sc, v3 p, F1&& row, F2&& rows2) {
+    const unsigned long long* cell = cull_cell(sc.cull, p);
+    const int n = sc.nprims;
+    unsigned long long sets[RM_MAX_PRIMS / 64];
+    if (RM_CULL_MODE == 3) {
+#pragma unroll
+      for (int w = 0; w < RM_MAX_PRIMS / 64; w++) {
+        if (w < sc.cull.words) {
+          sets[w] = wave_union(cell[w], 0ull);
+          if (sets[w] == 0ull && w == 0) return false;  // (word 0 holds row 0: an empty set there is a failed union)
+        }
+      }
+      for (int w = 1; w < sc.cull.words; w++)  // a later word: empty or failed?  failed if some lane has a row in it
+        if (sets[w] == 0ull && ballot(cell[w] != 0ull) != 0ull) return false;
+    }
+    for (int w = 0; w < sc.cull.words; w++) {
+      const int left = n - 64 * w;
+      const unsigned long long every = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+      const unsigned long long mine = RM_CULL_MODE == 3 ? 0ull : cell[w];
+      unsigned long long u = 0ull;  // the wave's rows; a failed union (mode 2) leaves 0: then every lane folds its own
+      if (RM_CULL_MODE == 3) u = sets[w];
+      else if (RM_CULL_MODE != 1) u = wave_union(mine, RM_CULL_MODE == 0 ? every : 0ull);
+      if (RM_CULL_MODE == 1 || (RM_CULL_MODE == 2 && u == 0ull)) {  // per lane: the two halves of the word in turn, a lane's rows in table order
+        unsigned int half[2] = {(unsigned int)mine, (unsigned int)(mine >> 32)};
+        if (w == 0) half[0] &= ~1u;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          unsigned int m = half[h];
+          while (ballot(m != 0u) != 0ull) {
+            if (m != 0u) {
+              const int j = 64 * w + 32 * h + (int)__builtin_ctz(m);
+              m &= m - 1u;
+              row(j, false);
+            }
+          }
+        }
+        continue;
+      }
+      if (w == 0) u &= ~1ull;
+      while (u != 0ull) {
+        const int j0 = 64 * w + __builtin_ctzll(u);
+        u &= u - 1ull;
+        if (u != 0ull) {
+          const int j1 = 64 * w + __builtin_ctzll(u);
+          u &= u - 1ull;
+          rows2(j0, j1);
+        } else {
+          row(j0, true);
+        }
+      }
+    }
+    return true;
+  }
+  // one shape row of the general fold (no domain rows): its distance, operator and k; `uniform`: the wave is at one row (its type is
+  // then a scalar and the dispatch below a scalar branch)
+  template <class M>
+  static RM_DEV float shape_row(const SceneLds& lds, int i, v3 q, bool uniform, int& op, float& k) {
+    const float4 a = lds.rows[2 * i];      // type, k, cx, cy
+    const float4 b = lds.rows[2 * i + 1];  // cz, sx, sy, sz
+    const int type = uniform ? __builtin_amdgcn_readfirstlane(__float_as_int(a.x)) : __float_as_int(a.x);
+    op = (type >> 8) & 0xff;
+    k = a.y;
+    const v3 c = V(a.z, a.w, b.x);
+    return (type & 0xff) == RM_PRIM_SPHERE ? sdf_sphere<M>(q, c, b.y) : sd_box<M>(q - c, V(b.y, b.z, b.w));
+  }
+  template <class M>
+  static RM_DEV float apply_op(float d, float di, int op, float k) {
+    if (op == RM_OP_UNION) return gmin(d, di);
+    if (op == RM_OP_SMOOTH_UNION) return op_smooth_union<M>(d, di, k);
+    if (op == RM_OP_SUBTRACT) return gmax(d, -di);
+    return gmax(d, di);
+  }
+  template <class M>
+  static RM_DEV float eval_general_culled(const DevScene& sc, const SceneLds& lds, v3 p) {
+    int op;
+    float k;
+    float d = shape_row<M>(lds, 0, p, true, op, k);
+    auto one = [&](int i, bool uniform) {
+      const float di = shape_row<M>(lds, i, p, uniform, op, k);
+      d = apply_op<M>(d, di, op, k);
+    };
+    if (!culled_rows(sc, p, one, [&](int i, int j) { one(i, true); one(j, true); })) return eval_general<M>(sc, lds, p);
     return d;
   }
   // one level of a kaleidoscopic fold (RM_PRIM_FOLD): the operations of tree.glsl:24-32 on the running point
@@ -509,6 +649,11 @@ struct Sdf<RM_SCENE_TABLE> {
   template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds& lds, v3 p) {
     if (M::fast && (sc.table_flags & RM_TABLE_SPHERES_SMOOTH)) return eval_spheres_smooth(sc, lds, p);
+    if (M::fast && sc.cull.cells != nullptr) return eval_general_culled<M>(sc, lds, p);  // kernel-uniform
+    return eval_general<M>(sc, lds, p);
+  }
+  template <class M>
+  static RM_DEV float eval_general(const DevScene& sc, const SceneLds& lds, v3 p) {
     const bool domain = (sc.table_flags & RM_TABLE_HAS_DOMAIN) != 0;  // kernel-uniform
     float d = 0.0f, factor = 1.0f;
     bool first = true;
@@ -535,10 +680,7 @@ struct Sdf<RM_SCENE_TABLE> {
       if (domain) di = di * factor;
       if (first) { d = di; first = false; continue; }
       const int op = (type >> 8) & 0xff;
-      if (op == RM_OP_UNION) d = gmin(d, di);
-      else if (op == RM_OP_SMOOTH_UNION) d = op_smooth_union<M>(d, di, a.y);
-      else if (op == RM_OP_SUBTRACT) d = gmax(d, -di);
-      else d = gmax(d, di);
+      d = apply_op<M>(d, di, op, a.y);
     }
     return d;
   }

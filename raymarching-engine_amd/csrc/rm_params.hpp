@@ -14,6 +14,88 @@
 
 #define RM_BATCH_MAX 8  /* samples one pixel-kernel launch can render (KParams::batch) */
 
+// Row culling for primitive tables without domain rows (round 3; fast policy; rm_kernels.inc rm_cull_build_kernel fills it when
+// the scene is created, rm_device.hpp Sdf<RM_SCENE_TABLE>::culled_rows reads it).  Nested uniform grids about the shapes' bounding
+// box: level l is a cube of n^3 cells with half-width half0 * 2^l about `centre`, and a point belongs to the lowest level that
+// holds it.  Per cell one bit per row -- clear = the row's operator cannot change the running value of the fold anywhere in the
+// cell (an exact no-op there), so an evaluation may skip it.  cells = [levels][n^3 cells][words] 64-bit words, then one cell that
+// lists every row (points beyond the last level, non-finite points).
+struct CullGrid {
+  const unsigned long long* cells;  // device pointer; nullptr = no culling
+  float centre[3];
+  float inv_half0;  // 1 / half0
+  float scale0;     // cells per unit length at level 0: n / (2 half0)
+  int n, levels, words;
+};
+struct CullBuild {  // argument block of rm_cull_build_kernel
+  const RmPrim* prims;
+  unsigned long long* cells;
+  int nprims, n, levels, words;
+  double centre[3], half0;
+  double reach;  // the largest |coordinate| of a shape: scale of the fp32 error allowance
+};
+
+// the fp32 allowance of the culling tests: n + 8 roundings at the magnitude of the coordinates involved
+__host__ __device__ inline double rm_cull_margin(int nprims, double magnitude) { return 1e-4 + 1.2e-7 * (nprims + 8) * magnitude; }
+__host__ __device__ inline double rm_cull_shape_distance(const RmPrim& p, const double* c) {
+  const double x = c[0] - p.center[0], y = c[1] - p.center[1], z = c[2] - p.center[2];
+  if ((p.type & 0xff) == RM_PRIM_SPHERE) return sqrt(x * x + y * y + z * z) - p.size[0];
+  const double qx = fabs(x) - p.size[0], qy = fabs(y) - p.size[1], qz = fabs(z) - p.size[2];  // sdBox, raymarcher.frag:108-112
+  const double ox = fmax(qx, 0.0), oy = fmax(qy, 0.0), oz = fmax(qz, 0.0);
+  return sqrt(ox * ox + oy * oy + oz * oz) + fmin(fmax(qx, fmax(qy, qz)), 0.0);
+}
+// The rows of a table (no domain rows) that an evaluation anywhere in the ball (c, rad) has to fold: bit i of out[] set = row i
+// stays.  The argument is with rm_cull_build_kernel (rm_kernels.inc), which calls this once per cell; host-callable so that the
+// CPU tests can check it against the fold itself (rm_debug_cull_cell).
+__host__ __device__ inline void rm_cull_cell(const RmPrim* prims, int nprims, int words, const double* c, double rad, double margin, unsigned long long* out) {
+  for (int w = 0; w < words; w++) out[w] = 0ull;
+  const double d0 = rm_cull_shape_distance(prims[0], c);
+  double L = d0 - rad, U = d0 + rad;
+  int best = 0;  // the nearest earlier row at c that bounds the running value from above (-1: none)
+  double best_d = d0;
+  out[0] |= 1ull;
+  for (int i = 1; i < nprims; i++) {
+    const RmPrim p = prims[i];
+    const int op = (p.type >> 8) & 0xff;
+    const double di = rm_cull_shape_distance(p, c), lo_i = di - rad, hi_i = di + rad;
+    bool keep;
+    if (op == RM_OP_UNION || op == RM_OP_SMOOTH_UNION) {
+      // (a smooth union always stays: even where h clamps, the kernels' form of it rounds the running value -- rm_device.hpp smooth_row)
+      const double k = 0.0;
+      keep = op == RM_OP_SMOOTH_UNION || !(lo_i >= U + margin);
+      if (keep && op == RM_OP_UNION && best >= 0) {
+        const RmPrim q = prims[best];
+        const double sx = (double)p.center[0] - q.center[0], sy = (double)p.center[1] - q.center[1], sz = (double)p.center[2] - q.center[2];
+        // the point the gradient of a shape's distance points away from: a sphere's centre; the nearest point of a box (within its
+        // half-diagonal of the centre, at the distance itself -- which has to be positive over the ball)
+        const bool ps = (p.type & 0xff) == RM_PRIM_SPHERE, qs = (q.type & 0xff) == RM_PRIM_SPHERE;
+        const double pe = ps ? 0.0 : sqrt((double)p.size[0] * p.size[0] + (double)p.size[1] * p.size[1] + (double)p.size[2] * p.size[2]);
+        const double qe = qs ? 0.0 : sqrt((double)q.size[0] * q.size[0] + (double)q.size[1] * q.size[1] + (double)q.size[2] * q.size[2]);
+        const double s = sqrt(sx * sx + sy * sy + sz * sz) + pe + qe;
+        const double a = (ps ? di + p.size[0] : di) - rad, b = (qs ? best_d + q.size[0] : best_d) - rad;
+        if (a > 0.0 && b > 0.0) {
+          const double lip = fmin(2.0, s / sqrt(a * b));
+          keep = !(di - best_d - rad * lip >= k + margin);
+        }
+      }
+      U = fmin(U, hi_i);
+      L = fmin(L, lo_i) - (op == RM_OP_SMOOTH_UNION ? 0.25 * fabs((double)p.k) + margin : 0.0);  // the smooth minimum is at most k / 4 below the minimum
+      if (best < 0 || di < best_d) { best = i; best_d = di; }
+    } else if (op == RM_OP_SUBTRACT) {
+      keep = !(-lo_i <= L - margin);
+      U = fmax(U, -lo_i);
+      L = fmax(L, -hi_i);
+      if (keep) best = -1;  // the value may now exceed every earlier term
+    } else {
+      keep = !(hi_i <= L - margin);
+      U = fmax(U, hi_i);
+      L = fmax(L, lo_i);
+      if (keep) best = -1;  // max(d, di) where di may win: no earlier term bounds the value from above any more
+    }
+    if (keep) out[i >> 6] |= 1ull << (i & 63);
+  }
+}
+
 struct DevScene {
   int kind;
   int nprims;
@@ -30,6 +112,7 @@ struct DevScene {
   int far_end;
   float far_r2;
   int reserved3;
+  CullGrid cull;
 };
 
 struct KParams {
@@ -84,6 +167,7 @@ struct ProbeParams {
   float retire_eps;
   int no_far_jump;
 };
+// (the probe follows RM_RENDER_NO_CULL through scene.cull.cells, which rm_probe clears)
 
 namespace rm {
 enum {
@@ -129,6 +213,7 @@ hipError_t wf_launch_march_strict(const WfParams& W, bool preview, int pass, int
 hipError_t wf_launch_march_fast(const WfParams& W, bool preview, int pass, int blocks, hipStream_t stream);
 hipError_t launch_combine(const KParams& P, hipStream_t stream);
 hipError_t launch_order(unsigned int* cost, unsigned int* order, int n, hipStream_t stream);
+hipError_t launch_cull_build(const CullBuild& B, hipStream_t stream);
 void pixel_grid(const KParams& P, int* gx, int* gy);  // workgroup grid the pixel kernel uses for this job
 hipError_t wf_launch_shade_strict(const WfParams& W, hipStream_t stream);
 hipError_t wf_launch_shade_fast(const WfParams& W, hipStream_t stream);

@@ -22,7 +22,7 @@ const RM = {
   MAX_BOUNCES: 10, MAX_LIGHTS: 10,
   SCENE_TABLE: 0, SCENE_MANDELBULB: 1, SCENE_SPHERE_GRID: 2, SCENE_SPHERE_LATTICE: 3, SCENE_MENGER: 4, SCENE_KIFS_TREE: 5, SCENE_KIFS_BOX: 6,
   PRIM_SPHERE: 0, PRIM_BOX: 1, PRIM_REPEAT: 2, PRIM_FOLD: 3, OP_UNION: 0, OP_SMOOTH_UNION: 1, OP_SUBTRACT: 2, OP_INTERSECT: 3,
-  RENDER_STRICT: 0, RENDER_FAST: 1, RENDER_COLOR_ONLY: 2, RENDER_MEGAKERNEL: 4, RENDER_WAVEFRONT: 16, RENDER_NO_OVERLAP: 32, RENDER_NO_FAR_JUMP: 64,
+  RENDER_STRICT: 0, RENDER_FAST: 1, RENDER_COLOR_ONLY: 2, RENDER_MEGAKERNEL: 4, RENDER_WAVEFRONT: 16, RENDER_NO_OVERLAP: 32, RENDER_NO_FAR_JUMP: 64, RENDER_NO_CULL: 128,
 };
 
 // ---- struct layouts (include/hip_raymarch.h; all fields are 4 bytes) ----------------

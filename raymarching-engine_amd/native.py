@@ -34,8 +34,22 @@ EXPORTS = [
     "rm_abi_version", "rm_material_default", "rm_ctx_create", "rm_ctx_destroy", "rm_last_error", "rm_ctx_set_stream",
     "rm_ctx_set_retire_eps", "rm_ctx_set_samples_in_flight", "rm_ctx_set_cost_order", "rm_debug_counters", "rm_device_memory", "rm_sync", "rm_scene_create", "rm_scene_destroy", "rm_fb_create", "rm_fb_create_striped", "rm_fb_rows", "rm_fb_width", "rm_fb_height", "rm_fb_wrap", "rm_fb_clear", "rm_fb_destroy",
     "rm_fb_download", "rm_fb_upload", "rm_fb_device_ptr", "rm_buffer_create", "rm_buffer_destroy", "rm_buffer_download", "rm_buffer_upload", "rm_render_sample", "rm_render_samples", "rm_ctx_set_sample_batch", "rm_ctx_set_gl_stack", "rm_render_timed",
-    "rm_probe", "rm_probe_camera", "rm_probe_rng", "rm_assemble_striped", "rm_assemble_striped_bytes", "rm_present", "rm_present_planes", "rm_present_device", "rm_present_rows", "rm_pack_present_rows", "rm_ctx_last_pipeline", "rm_present_sharded",
+    "rm_probe", "rm_probe_camera", "rm_probe_rng", "rm_assemble_striped", "rm_assemble_striped_bytes", "rm_present", "rm_present_planes", "rm_present_device", "rm_present_rows", "rm_pack_present_rows", "rm_ctx_last_pipeline", "rm_present_sharded", "rm_debug_cull_cell",
 ]
+
+
+def cull_cell(scene, centre, radius: float, margin: float = 0.0):
+    """Rows of a primitive table that an evaluation anywhere in the ball (centre, radius) has to fold: a bool per row
+    (rm_debug_cull_cell -- the rule behind the culling grid of the fast build; host arithmetic, no GPU)."""
+    lib = load_library()
+    desc = scene.desc()
+    words = (desc.nprims + 63) // 64
+    out = (C.c_ulonglong * words)()
+    c = (C.c_double * 3)(*[float(v) for v in centre])
+    rc = lib.rm_debug_cull_cell(C.byref(desc), c, float(radius), float(margin), out)
+    if rc != abi.RM_OK:
+        raise RmError(rc, "rm_debug_cull_cell: not a table of shapes only")
+    return [bool((out[i >> 6] >> (i & 63)) & 1) for i in range(desc.nprims)]
 
 
 class RmError(RuntimeError):
@@ -103,6 +117,7 @@ def load_library():
         "rm_buffer_upload": (ip, [vp, vp, vp, C.c_size_t]),
         "rm_ctx_set_cost_order": (ip, [vp, C.c_int]),
         "rm_debug_counters": (ip, [vp, C.POINTER(C.c_ulonglong), ip]),
+        "rm_debug_cull_cell": (ip, [C.POINTER(abi.RmSceneDesc), C.POINTER(C.c_double), C.c_double, C.c_double, C.POINTER(C.c_ulonglong)]),
         "rm_sync": (ip, [vp]),
         "rm_scene_create": (ip, [vp, C.POINTER(abi.RmSceneDesc), C.POINTER(vp)]),
         "rm_scene_destroy": (None, [vp]),

@@ -423,6 +423,32 @@ def csg64(material: Optional[Material] = None) -> CsgScene:
     return sc
 
 
+def csg_blocks(material: Optional[Material] = None) -> CsgScene:
+    """Not a BASELINE configuration: a long table of hard operators -- 180 boxes and spheres on a jittered 6x6x5 lattice under
+    unions, then 12 spheres subtracted (fixed LCG seed 7) -- the kind of scene the fast build's row culling is for
+    (include/hip_raymarch.h RM_RENDER_NO_CULL)."""
+    sc = CsgScene(material).union()
+    state = 7
+
+    def lcg():
+        nonlocal state
+        state = (state * 1664525 + 1013904223) & 0xFFFFFFFF
+        return (state >> 8) / float(1 << 24)
+
+    for iz in range(5):
+        for iy in range(6):
+            for ix in range(6):
+                c = [(ix - 2.5) * 0.7 + (lcg() - 0.5) * 0.25, (iy - 2.5) * 0.7 + (lcg() - 0.5) * 0.25, (iz - 2.0) * 0.7 + (lcg() - 0.5) * 0.25]
+                if lcg() < 0.5:
+                    sc.sphere(c, 0.15 + 0.2 * lcg())
+                else:
+                    sc.box(c, [0.1 + 0.2 * lcg(), 0.1 + 0.2 * lcg(), 0.1 + 0.2 * lcg()])
+    sc.subtract()
+    for _ in range(12):
+        sc.sphere([(lcg() - 0.5) * 3.5, (lcg() - 0.5) * 3.5, (lcg() - 0.5) * 3.0], 0.3 + 0.4 * lcg())
+    return sc
+
+
 # ---- specialised kinds -----------------------------------------------------
 
 

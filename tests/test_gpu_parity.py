@@ -1610,6 +1610,71 @@ def test_kifs_far_field_shortcuts_are_exact(ctx):
 FAST_TOLERANCE_K = 1.0
 
 
+def _cull_table(rng, kind, rows=None):
+    """a random table without domain rows, long enough for the culling grid: spheres and boxes under 0 = unions, 1 = unions,
+    subtractions and intersections, 2 = those and smooth unions (which the grid never drops)"""
+    sc = S.CsgScene()
+    p = [[1.0, 0, 0, 0], [0.6, 0, 0.25, 0.15], [0.5, 0.25, 0.15, 0.1]][kind]
+    for _ in range(rows or int(rng.integers(12, 100))):
+        [sc.union, lambda: sc.smooth_union(float(rng.uniform(0.05, 0.5))), sc.subtract, sc.intersect][int(rng.choice(4, p=p))]()
+        c = rng.uniform(-2, 2, 3)
+        if rng.uniform() < 0.6:
+            sc.sphere(c, float(rng.uniform(0.2, 0.7)))
+        else:
+            sc.box(c, rng.uniform(0.1, 0.6, 3))
+    return sc
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_row_culling_is_exact_on_random_tables(ctx, kind):
+    """The fast build folds, at a point of a long table built with union / subtract / intersect, the rows its grid cell lists
+    (rm_device.hpp culled_rows; the rule: rm_params.hpp rm_cull_cell, tests/test_cull_rule_cpu.py): the others are exact no-ops
+    there.  Random tables of 12 .. 200 rows (up to four 64-row words of the grid's cells): the distance at points inside the
+    scene, around it, up to 1e7 away, at points with a NaN or an infinite coordinate, and castRay from random origins have the
+    bits of the fold of every row (RM_RENDER_NO_CULL).  So do whole frames of three of the tables (full mode, two bounces, a
+    light; both implementations)."""
+    NC = abi.RM_RENDER_NO_CULL
+    rng = np.random.default_rng(2024 + 31 * kind + SEED_OFFSET)
+    special = np.array([[np.nan, 0, 0], [0.5, np.nan, 1], [np.inf, 1, 1], [1, 1, -np.inf], [np.nan, np.nan, np.nan], [1e30, 0, 0], [3e38, 3e38, 3e38], [0, 0, 0]])
+    for it in range(10):
+        sc = _cull_table(rng, kind, rows=[None, None, 64, 65, 130, 200, None, None, 12, 13][it])
+        h = ctx.create_scene(sc)
+        pts = np.concatenate([rng.uniform(-3, 3, (20000, 3)), rng.uniform(-12, 12, (6000, 3)), rng.normal(0, 1, (6000, 3)) * 10.0 ** rng.uniform(1, 7, (6000, 1)), special]).astype(np.float32)
+        a = ctx.probe(h, abi.RM_PROBE_SDF, pts, 0.0, FAST)
+        b = ctx.probe(h, abi.RM_PROBE_SDF, pts, 0.0, FAST | NC)
+        assert same_bits(a, b).all(), f"table {it} ({len(sc._nodes)} rows): the distance differs at {int((~same_bits(a, b)).sum())} points, first {pts[np.argmax(~same_bits(a, b))]}"
+        o = rng.uniform(-5, 5, (16384, 3))
+        d = rng.normal(0, 1, (16384, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        rays = np.concatenate([o, d], 1).astype(np.float32)
+        for steps in (24.0, 96.0):
+            ra = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST)
+            rb = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST | NC)
+            assert same_bits(ra, rb).all(), f"table {it}: {int((~same_bits(ra, rb)).any(-1).sum())} end points differ"
+        h.destroy()
+        if it < 3:
+            schema = J.make_schema(sc, 256, 192, counts=(64, 32), render_mode="full", position=(0.3, 0.2, -6.0), lights=GC.LIGHT)
+            noises = GC.halton_pairs(2)
+            ref = render_gpu(ctx, sc, schema, noises, FAST | MK | NC)
+            for impl in (MK, WF):
+                got = render_gpu(ctx, sc, schema, noises, FAST | impl)
+                for k in range(3):
+                    assert same_bits(got[k], ref[k]).all(), f"table {it}, plane {k}"
+
+
+def test_row_culling_leaves_smooth_union_tables_alone(ctx):
+    """BASELINE's CSG-64 is all smooth unions: its rows are never dropped (profiles/r03_row_culling_smooth_union_experiment.txt has
+    the measurement that decided it), so the switch changes nothing -- and the job keeps the bits it had before the grid existed
+    (the fast-against-strict statistics and the far-jump tests of this file run on it)."""
+    sc = S.csg64()
+    schema = J.make_schema(sc, 512, 512, counts=(128,), render_mode="full", position=(0, 0, -5.0), lights=GC.LIGHT)
+    noises = GC.halton_pairs(1)
+    a = render_gpu(ctx, sc, schema, noises, FAST | MK)
+    b = render_gpu(ctx, sc, schema, noises, FAST | MK | abi.RM_RENDER_NO_CULL)
+    for k in range(3):
+        assert same_bits(a[k], b[k]).all()
+
+
 def test_fast_build_tolerance_is_anchored_to_the_spread_between_glsl_legal_arithmetics(ctx):
     """Headline frame (3840x2160, full, [256], the light), 4 samples per pixel, same random stream in all three renders:
     fast against strict, and GL-stack strict against default strict.  For the whole frame, for the pixels that show the

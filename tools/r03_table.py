@@ -5,7 +5,7 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) >= 2 and sys.argv[1] != "--child":
     for lib in sys.argv[1:]:
-        env = dict(os.environ, RM_LIB=os.path.abspath(lib) if lib != "default" else "")
+        env = dict(os.environ, RM_LIB=os.path.abspath(lib) if lib not in ("default", "nocull") else "", RM_NO_CULL="1" if lib == "nocull" else "0")  # nocull: no culling grid for the tables (rm_api.hip table_cull_grid)
         r = subprocess.run([sys.executable, __file__, "--child"], env=env, capture_output=True, text=True)
         print("==", lib); print(r.stdout.strip()); print(r.stderr.strip()[-600:])
     sys.exit(0)
@@ -20,6 +20,8 @@ cases = [("c4 full", S.csg64(), dict(width=4096, height=4096, counts=(128,), ren
          ("c5 shard/8", S.csg64(), dict(width=8192, height=8192, counts=(128, 64, 64), render_mode="full", position=(0, 0, -5.0), lights=soft), 8, (MK, WF)),
          ("c5 full", S.csg64(), dict(width=8192, height=8192, counts=(128, 64, 64), render_mode="full", position=(0, 0, -5.0), lights=soft), None, (MK, WF)),
          ("c2", S.single_sphere(), dict(width=1920, height=1080, counts=(128,), render_mode="preview", position=(0, 0, -3.0)), None, (MK,)),
+         ("csg_blocks (192 rows, hard operators) 1080p", S.csg_blocks(), dict(width=1920, height=1080, counts=(128, 64), render_mode="full", position=(0.3, 0.2, -6.0), lights=GC.LIGHT), None, (MK, WF)),
+         ("csg_blocks preview 1080p", S.csg_blocks(), dict(width=1920, height=1080, counts=(128,), render_mode="preview", position=(0.3, 0.2, -6.0)), None, (MK,)),
          ("csg_mixed 1080p", GC.build_scene("csg_mixed"), dict(width=1920, height=1080, counts=(128, 64), render_mode="full", position=(0.3, 0.2, -4.0), lights=GC.LIGHT), None, (MK,))]
 for name, sc, kw, parts, impls in cases:
     schema = J.make_schema(sc, **kw); h = ctx.create_scene(sc)
