@@ -108,7 +108,7 @@ struct DevScene {
   int nsurfaces;
   // The far field of a primitive table without domain rows (rm_device.hpp Sdf<RM_SCENE_TABLE>::far_jump; set by rm_scene_create):
   // far_end = 0: no jump; 1: an escaping ray ends at +-Inf by the sign of its direction components; 2: at (NaN, NaN, NaN).
-  // far_r2 = (2 R')^2 with R' = the radius of a sphere about the origin that holds every shape, plus k / 4 per smooth union.
+  // far_r2 = (2 R')^2 with R' = the radius of a sphere about the origin that holds every shape, plus the largest smooth-union radius k (a chain of smooth unions stays within k of the minimum).
   int far_end;
   float far_r2;
   int reserved3;
