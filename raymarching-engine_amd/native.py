@@ -149,6 +149,8 @@ def load_library():
         "rm_present_planes": (ip, [vp, vp, vp, ip, ip, ip, C.POINTER(C.c_uint8)]),
     }
     for name, (res, args) in sig.items():
+        if name.startswith("rm_debug_") and not hasattr(lib, name) and os.environ.get("RM_LIB"):
+            continue  # an experiment build of an older source tree (tools/): the debug entries are not part of what it measures
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
     _lib = lib
