@@ -80,7 +80,7 @@ for it in range(n):
         for a in range(3): u.lightPositions[j][a] = nasty(0.2, -4.0, 4.0); u.lightColors[j][a] = nasty(0.2, 0.0, 3.0)
         u.lightSizes[j] = nasty(0.3, 0.0, 1.0)
     u.showDofFocalPlane = int(rng.choice([0, 1, 5]))
-    flags = int(rng.choice([0, 1])) | int(rng.choice([0, 4, 16])) | int(rng.choice([0, 0, 2])) | int(rng.choice([0, 0, 64]))
+    flags = int(rng.choice([0, 1])) | int(rng.choice([0, 4, 16])) | int(rng.choice([0, 0, 2])) | int(rng.choice([0, 0, 64])) | int(rng.choice([0, 0, 128]))
     tile = abi.RmRect(int(rng.integers(-5, 30)), int(rng.integers(-5, 20)), int(rng.integers(-3, 40)), int(rng.integers(-3, 30)))
     print(f"render mode {u.renderMode} refl {u.reflections} lights {u.lightCount} flags {flags}", end=" ", flush=True)
     rc = lib.rm_render_sample(ctx.h, h, fb.h, C.byref(u), C.byref(tile) if rng.random() < 0.5 else None, flags)
