@@ -205,8 +205,9 @@ enum {
   RM_RENDER_COLOR_ONLY = 2,  /* do not read/write the two G-buffer planes (benchmark "single colour frame" mode) */
   RM_RENDER_MEGAKERNEL = 4,  /* force the one-thread-one-pixel kernel (whole main() per thread) */
   RM_RENDER_WAVEFRONT = 16,  /* force the wavefront pipeline (ray-compacting persistent march).  With neither flag the
-                                library picks per job from a measured table: the single kernel, except for
-                                full-mode tiles of >= 16 M pixels over primitive tables of >= 16 rows.  Same results either way. */
+                                library picks per job from a measured table: the single kernel -- in the strict
+                                build except for full-mode tiles of >= 16 M pixels over primitive tables of >= 16 rows.  Same
+                                results either way. */
   RM_RENDER_NO_COST_CLASSES = 8, /* wavefront march in one pass even for scene kinds whose sdf cost depends on the
                                    point (Mandelbulb); a measurement switch, same results */
   RM_RENDER_NO_OVERLAP = 32, /* this sample runs alone on the context's stream and blends in its own kernel (see

@@ -1069,11 +1069,15 @@ static hipError_t launch_wavefront(rm_ctx* ctx, const KParams& P, int flags) {
 //   Mandelbulb 3840x2160 full      1.98 / 4.0
 //   CSG-64 4096^2, rank 0's 1/8    2.33 / 6.33        CSG-64 4096x4096             15.3 / 14.4
 //   CSG-64 8192^2, rank 0's 1/8    31.5 / 33.1        CSG-64 8192x8192             244  / 229
-// The one-kernel form wins everywhere except on full-mode frames of >= 2^24 pixels over long primitive tables, where the
-// pipeline's global ray compaction still issues ~6 % fewer instructions than the workgroup-level one (it was 10-16 % before
-// the pixel kernel compacted its table rays, and the threshold was 2^23).
+// and at the end of round 3, with the tighter far field and CSG-64's own pixel kernel (RM_KIND_TABLE_SMOOTH):
+//   CSG-64 4096^2, rank 0's 1/8    2.19 / 5.79        CSG-64 4096x4096             12.9 / 13.2
+//   CSG-64 8192^2, rank 0's 1/8    29.2 / 32.7        CSG-64 8192x8192             225.7 / 225.6
+// The fast build's one-kernel form now wins or ties everywhere -- the pipeline's global ray compaction bought 10-16 % on the two
+// full CSG frames in round 2, 6 % after the pixel kernel compacted its table rays, nothing now -- and it needs no 240 bytes of
+// workspace per pixel: the fast build never picks the pipeline by itself any more (RM_RENDER_WAVEFRONT still forces it; it remains
+// the second implementation the tests hold the pixel kernel to).  The strict build keeps round 3's rule (165 against 170 ms on C4).
 static bool prefer_wavefront(const KParams& P, int flags) {
-  (void)flags;
+  if (flags & RM_RENDER_FAST) return false;
   if (P.u.renderMode == 1) return false;
   if (P.scene.table_flags & RM_TABLE_HAS_SURFACES) return false;  // (see uses_wavefront)
   if ((long long)P.tw * (long long)P.th < (1ll << 24)) return false;

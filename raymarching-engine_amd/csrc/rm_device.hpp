@@ -433,22 +433,25 @@ struct Sdf<RM_SCENE_TABLE> {
     const v3 q = p - V(r.x, r.y, r.z);
     return FM::sqrt(FM::fma(q.z, q.z, FM::fma(q.y, q.y, q.x * q.x))) - r.w;
   }
+  // one smooth-union radius for the whole table (RM_TABLE_UNIFORM_K): the fold is as much LDS-bound as VALU-bound -- half the LDS traffic
+  static RM_DEV float eval_spheres_one_k(const DevScene& sc, const SceneLds& lds, v3 p) {
+    const int n = sc.nprims;
+    const float k = sc.p[0], half_inv_k = sc.p[1];
+    const float4* rows = &lds.rows[2 * n];  // the compact image (stage)
+    float d = sphere_row1(rows[0], p);
+    int i = 1;
+    for (; i + 1 < n; i += 2) {
+      const float4 r0 = rows[i], r1 = rows[i + 1];
+      const float d0 = sphere_row1(r0, p), d1 = sphere_row1(r1, p);
+      d = smooth_row(d, d0, k, half_inv_k);
+      d = smooth_row(d, d1, k, half_inv_k);
+    }
+    if (i < n) d = smooth_row(d, sphere_row1(rows[i], p), k, half_inv_k);
+    return d;
+  }
   static RM_DEV float eval_spheres_smooth(const DevScene& sc, const SceneLds& lds, v3 p) {
     const int n = sc.nprims;
-    if (sc.table_flags & RM_TABLE_UNIFORM_K) {  // kernel-uniform; the fold is as much LDS-bound as VALU-bound: half the LDS traffic
-      const float k = sc.p[0], half_inv_k = sc.p[1];
-      const float4* rows = &lds.rows[2 * n];  // the compact image (stage)
-      float d = sphere_row1(rows[0], p);
-      int i = 1;
-      for (; i + 1 < n; i += 2) {
-        const float4 r0 = rows[i], r1 = rows[i + 1];
-        const float d0 = sphere_row1(r0, p), d1 = sphere_row1(r1, p);
-        d = smooth_row(d, d0, k, half_inv_k);
-        d = smooth_row(d, d1, k, half_inv_k);
-      }
-      if (i < n) d = smooth_row(d, sphere_row1(rows[i], p), k, half_inv_k);
-      return d;
-    }
+    if (sc.table_flags & RM_TABLE_UNIFORM_K) return eval_spheres_one_k(sc, lds, p);  // kernel-uniform
     float d = sphere_row(lds.rows[0], lds.rows[1], p);
     int i = 1;
     for (; i + 1 < n; i += 2) {
@@ -952,7 +955,19 @@ struct Sdf<RM_KIND_BULB8> : Sdf<RM_SCENE_MANDELBULB> {
 #define RM_KIND_TABLE_BIG (RM_SCENE_KIND_COUNT + 1)
 template <>
 struct Sdf<RM_KIND_TABLE_BIG> : Sdf<RM_SCENE_TABLE> {};
-template <int KIND> struct IsTable { static constexpr bool value = KIND == RM_SCENE_TABLE || KIND == RM_KIND_TABLE_BIG; };
+// ... and the long table of spheres under ONE smooth-union radius, without surfaces (BASELINE's CSG-64), has that kernel to itself
+// in the fast build: without the general fold, its per-row dispatch, the row culling and the surface lookups in the same function
+// the compiler spills less around the march (C4's frame 13.9 -> 12.9 ms, its stripes 2.39 -> 2.19, C5's 30.8 -> 29.2)
+#define RM_KIND_TABLE_SMOOTH (RM_SCENE_KIND_COUNT + 2)
+template <>
+struct Sdf<RM_KIND_TABLE_SMOOTH> : Sdf<RM_SCENE_TABLE> {
+  template <class M>
+  static RM_DEV float eval(const DevScene& sc, const SceneLds& lds, v3 p) {
+    if constexpr (M::fast) return eval_spheres_one_k(sc, lds, p);
+    else return Sdf<RM_SCENE_TABLE>::template eval<M>(sc, lds, p);
+  }
+};
+template <int KIND> struct IsTable { static constexpr bool value = KIND == RM_SCENE_TABLE || KIND == RM_KIND_TABLE_BIG || KIND == RM_KIND_TABLE_SMOOTH; };
 
 // kinds whose fast march may jump an escaping ray to its end state (Sdf<RM_SCENE_MANDELBULB>::far_jump)
 template <int KIND> struct FarJump { static constexpr bool value = false; };
@@ -960,6 +975,7 @@ template <> struct FarJump<RM_SCENE_MANDELBULB> { static constexpr bool value = 
 template <> struct FarJump<RM_KIND_BULB8> { static constexpr bool value = true; };
 template <> struct FarJump<RM_SCENE_TABLE> { static constexpr bool value = true; };
 template <> struct FarJump<RM_KIND_TABLE_BIG> { static constexpr bool value = true; };
+template <> struct FarJump<RM_KIND_TABLE_SMOOTH> { static constexpr bool value = true; };
 template <> struct FarJump<RM_SCENE_MENGER> { static constexpr bool value = true; };
 template <> struct FarJump<RM_SCENE_KIFS_BOX> { static constexpr bool value = true; };
 template <> struct FarJump<RM_SCENE_SPHERE_GRID> { static constexpr bool value = true; };

@@ -3,7 +3,7 @@
 #   bash tools/r03_collect.sh [names...]
 # frames of a PMC pass (--steps 2 --warmup 1 --repeats 1): 1 + 2 + 2 + 3 = 8
 set -u
-ALL="c3b c3a c2 c4_mk c4_wf c4shard c5shard_wf c5shard_mk c5"
+ALL="c3b c3a c2 c4_mk c4_wf c4shard c5shard_wf c5shard_mk c5_mk c5_wf"
 for w in ${@:-$ALL}; do
   S=gpurun_out/prof_r03_$w/summary.txt
   [ -f $S ] || { echo "no $S"; continue; }
@@ -18,6 +18,7 @@ for w in ${@:-$ALL}; do
     c4shard)    python3 tools/update_counters.py c4_shard_fast $S $K 8 $((4096*512)) megakernel;;
     c5shard_wf) python3 tools/update_counters.py c5_shard_fast_wavefront $S $K 8 $((8192*1024)) wavefront;;
     c5shard_mk) python3 tools/update_counters.py c5_shard_fast_megakernel $S $K 8 $((8192*1024)) megakernel;;
-    c5)         python3 tools/update_counters.py c5_fast $S $K 8 $((8192*8192)) wavefront;;
+    c5_mk)      python3 tools/update_counters.py c5_fast_megakernel $S $K 8 $((8192*8192)) megakernel;;
+    c5_wf)      python3 tools/update_counters.py c5_fast_wavefront $S $K 8 $((8192*8192)) wavefront;;
   esac
 done

@@ -4,7 +4,7 @@
 # Each: kernel trace (--stats) + six PMC passes of the same bench command, summary -> gpurun_out/prof_r03_<name>/summary.txt.
 # Afterwards, in the build container: tools/r03_collect.sh copies the summaries to profiles/ and fills profiles/r03_counters.json.
 set -u
-ALL="c3b c3a c2 c4_mk c4_wf c4shard c5shard_wf c5shard_mk c5"
+ALL="c3b c3a c2 c4_mk c4_wf c4shard c5shard_wf c5shard_mk c5_mk c5_wf"
 for w in ${@:-$ALL}; do
   case $w in
     c3b)        T="--steps 30 --warmup 5";               P="--steps 2 --warmup 1";;
@@ -15,7 +15,8 @@ for w in ${@:-$ALL}; do
     c4shard)    T="--workload c4 --stripe-of 8 --steps 10 --warmup 2"; P="--workload c4 --stripe-of 8 --steps 2 --warmup 1";;
     c5shard_wf) T="--workload c5 --stripe-of 8 --wavefront --steps 4 --warmup 1";  P="--workload c5 --stripe-of 8 --wavefront --steps 2 --warmup 1";;
     c5shard_mk) T="--workload c5 --stripe-of 8 --megakernel --steps 4 --warmup 1"; P="--workload c5 --stripe-of 8 --megakernel --steps 2 --warmup 1";;
-    c5)         T="--workload c5 --steps 2 --warmup 1";   P="--workload c5 --steps 2 --warmup 1";;
+    c5_mk)      T="--workload c5 --megakernel --steps 2 --warmup 1"; P="--workload c5 --megakernel --steps 2 --warmup 1";;
+    c5_wf)      T="--workload c5 --wavefront --steps 2 --warmup 1";  P="--workload c5 --wavefront --steps 2 --warmup 1";;
   esac
   echo "######## $w"
   bash tools/profile_gpu.sh r03_$w "$T --repeats 1 --no-cpu-baseline" "$P --repeats 1 --no-cpu-baseline" > gpurun_out/prof_r03_$w.log 2>&1
