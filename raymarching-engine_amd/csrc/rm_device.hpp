@@ -492,13 +492,14 @@ struct Sdf<RM_SCENE_TABLE> {
     return g.cells + (size_t)idx * (size_t)g.words;
   }
   // the union of the active lanes' row sets, as a scalar: the first lane's set, then -- a few times -- the set of the first lane that
-  // still has a row outside it (lanes of a wave sit in the same or in neighbouring cells); after that, every row of the word
-  static RM_DEV unsigned long long wave_union(unsigned long long mine, unsigned long long every) {
-    const unsigned int lo = (unsigned int)mine, hi = (unsigned int)(mine >> 32);
-    unsigned long long u = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)hi) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)lo);
+  // still has a row outside it (lanes of a wave sit in the same or in neighbouring cells); 0 when that does not cover the wave (the
+  // word that holds row 0 is never 0 otherwise)
 #ifndef RM_CULL_UNION_ROUNDS
 #define RM_CULL_UNION_ROUNDS 3
 #endif
+  static RM_DEV unsigned long long wave_union(unsigned long long mine) {
+    const unsigned int lo = (unsigned int)mine, hi = (unsigned int)(mine >> 32);
+    unsigned long long u = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)hi) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)lo);
 #pragma unroll
     for (int it = 0; it < RM_CULL_UNION_ROUNDS; it++) {
       const unsigned long long more = ballot((mine & ~u) != 0ull);
@@ -506,40 +507,20 @@ struct Sdf<RM_SCENE_TABLE> {
       const int src = __builtin_ctzll(more);
       u |= ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)hi, src) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)lo, src);
     }
-    return ballot((mine & ~u) != 0ull) != 0ull ? every : u;
+    return ballot((mine & ~u) != 0ull) != 0ull ? 0ull : u;
   }
   // calls row(i, uniform) for the rows 1 .. n-1 this lane has to fold, in table order -- uniform: every lane of the wave is at row
   // i (two at a time where there are two, rows2(i, j): the LDS reads of both are in flight during the arithmetic); else the lanes
-  // are at rows of their own; row 0 starts the fold and is the caller's
-#ifndef RM_CULL_MODE
-#define RM_CULL_MODE 2  // 0: the wave folds the union of its lanes' rows; 1: every lane folds its own rows; 2: the union when three lanes' sets cover it, else per lane
-#endif
-  // returns false (mode 3, before any row was folded) when the wave's lanes are too far apart for a common row set: the caller
-  // then folds the whole table
+  // are at rows of their own; row 0 starts the fold and is the caller's.  (Measured on a 64-row table, tools/r03_table.py: folding
+  // the union when it exists and per lane otherwise beats the union alone by 4 %, per lane alone loses 10 %, and falling back to the
+  // whole table when the union fails loses 14 %.)
   template <class F1, class F2>
-  static RM_DEV bool culled_rows(const DevScene& sc, v3 p, F1&& row, F2&& rows2) {
+  static RM_DEV void culled_rows(const DevScene& sc, v3 p, F1&& row, F2&& rows2) {
     const unsigned long long* cell = cull_cell(sc.cull, p);
-    const int n = sc.nprims;
-    unsigned long long sets[RM_MAX_PRIMS / 64];
-    if (RM_CULL_MODE == 3) {
-#pragma unroll
-      for (int w = 0; w < RM_MAX_PRIMS / 64; w++) {
-        if (w < sc.cull.words) {
-          sets[w] = wave_union(cell[w], 0ull);
-          if (sets[w] == 0ull && w == 0) return false;  // (word 0 holds row 0: an empty set there is a failed union)
-        }
-      }
-      for (int w = 1; w < sc.cull.words; w++)  // a later word: empty or failed?  failed if some lane has a row in it
-        if (sets[w] == 0ull && ballot(cell[w] != 0ull) != 0ull) return false;
-    }
     for (int w = 0; w < sc.cull.words; w++) {
-      const int left = n - 64 * w;
-      const unsigned long long every = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
-      const unsigned long long mine = RM_CULL_MODE == 3 ? 0ull : cell[w];
-      unsigned long long u = 0ull;  // the wave's rows; a failed union (mode 2) leaves 0: then every lane folds its own
-      if (RM_CULL_MODE == 3) u = sets[w];
-      else if (RM_CULL_MODE != 1) u = wave_union(mine, RM_CULL_MODE == 0 ? every : 0ull);
-      if (RM_CULL_MODE == 1 || (RM_CULL_MODE == 2 && u == 0ull)) {  // per lane: the two halves of the word in turn, a lane's rows in table order
+      const unsigned long long mine = cell[w];
+      unsigned long long u = wave_union(mine);
+      if (u == 0ull) {  // no common set (or no row of this word at all): every lane folds its own rows, the two halves of the word in turn
         unsigned int half[2] = {(unsigned int)mine, (unsigned int)(mine >> 32)};
         if (w == 0) half[0] &= ~1u;
 #pragma unroll
@@ -568,7 +549,6 @@ struct Sdf<RM_SCENE_TABLE> {
         }
       }
     }
-    return true;
   }
   // one shape row of the general fold (no domain rows): its distance, operator and k; `uniform`: the wave is at one row (its type is
   // then a scalar and the dispatch below a scalar branch)
@@ -598,7 +578,7 @@ struct Sdf<RM_SCENE_TABLE> {
       const float di = shape_row<M>(lds, i, p, uniform, op, k);
       d = apply_op<M>(d, di, op, k);
     };
-    if (!culled_rows(sc, p, one, [&](int i, int j) { one(i, true); one(j, true); })) return eval_general<M>(sc, lds, p);
+    culled_rows(sc, p, one, [&](int i, int j) { one(i, true); one(j, true); });
     return d;
   }
   // one level of a kaleidoscopic fold (RM_PRIM_FOLD): the operations of tree.glsl:24-32 on the running point
