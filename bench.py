@@ -279,6 +279,8 @@ def main():
         else:
             dist.init_process_group(backend)
     sharded = world > 1 or force_dist
+    if not sharded:
+        backend = None
 
     wl, sc, schema = make_workload(args.workload)
     W, H = wl["width"], wl["height"]
@@ -491,7 +493,7 @@ def main():
                        "host": "job.do_render_job on a job.RenderJobContext" + (" (sharded: dist.ShardGroup)" if sharded else ""),
                        "sharding": (f"{shard.STRIPE_ROWS}-row stripes round-robin over ranks; a step = one sample of every pixel, plus -- every {yield_interval} sample(s) "
                                     f"(render.sampleYieldInterval) -- one present: each rank {'packs (colour, DoF radius) of' if payload == 'f32dof' else 'tone-maps'} its rows, the {payload} "
-                                    f"rows are gathered to rank 0 over RCCL (overlapped with the next samples' render) and put back in image order"
+                                    f"rows are gathered to rank 0 over {'RCCL' if backend == 'nccl' else backend + ' (testing aid: through host memory)'} (overlapped with the next samples' render) and put back in image order"
                                     + (", and rank 0 runs the present pass with its blur on the assembled frame" if payload == "f32dof" else ""))
                        if sharded else "none",
                        "planes": "color+normal_dof+albedo_depth fp32, accumulated in place", "samples_in_flight": in_flight,
