@@ -378,6 +378,11 @@ def main():
 
     run(args.warmup, yield_interval)
     drain()
+    if sharded and args.warmup <= 0:
+        # no warm-up step, so no frame has been presented yet: one untimed gather of the (empty) frame, so that RCCL sets up its
+        # point-to-point connections outside the timed region (a job's last sample always presents: RenderJobExecutor.tsx:338)
+        fb.start_present(1)
+        fb.finish_present()
     # EXACTLY K steps per timed region; three regions, `value` from the median (the spread says what one region is worth)
     regions = sorted(timed(args.steps, yield_interval) for _ in range(max(1, args.repeats)))
     elapsed = regions[len(regions) // 2]
