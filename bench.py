@@ -510,8 +510,16 @@ def main():
     scene.destroy()
     ctx.close()
     if sharded:
+        # RCCL writes a version banner to C stdout when it starts; on a pipe or a file that buffer is flushed when the process exits,
+        # i.e. AFTER the line below.  Every rank empties it before the last barrier, so that rank 0's JSON is the last line of the
+        # job's output whichever way a reader picks it.
+        import ctypes
+
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
         dist.barrier()
         dist.destroy_process_group()
+        ctypes.CDLL(None).fflush(None)
     if out is not None:
         print(json.dumps(out), flush=True)
 
