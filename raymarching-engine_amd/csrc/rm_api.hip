@@ -385,6 +385,17 @@ static void table_far_field(const RmSceneDesc* desc, DevScene* dev) {
   if (first || !(r < 1e9)) return;
   dev->far_r2 = (float)(r * r);
   dev->far_end = d == inf ? 1 : (d != d ? 2 : 0);
+  // A ray that passes every shape at a distance (Sdf<RM_SCENE_TABLE>::clear_miss): if it stays K = k_max + b0 clear of every shape's
+  // bounding sphere, the fold is >= b0 all along it (a chain of smooth unions is within k_max of the nearest term): the march never
+  // settles.  How long can it take to leave?  Let rho hold every shape's sphere and K (rho = 1.15 (reach + k_max), b0 <= rho / 8).
+  // Inside that sphere a step is >= b0, outside >= |x| - rho + b0; two steps bring a ray from up to 60 Rp away to it, and the worst
+  // chord (through the centre) is crossed and the ray out at 2.6 rho -- beyond the jump's 2 Rp, moving outward -- within
+  // 2 rho / (0.99 b0) + 6 steps (tools: the recurrence iterated over every closest approach).  Then the jump's first case: 72 steps.
+  // So a march with `left` steps may take b0 = 2.05 rho / (left - 84): 128 steps -> b0 = rho / 21 (C4: 0.16, clearance 0.37).
+  if (dev->far_end != 0 && reach + kmax >= 1.05) {
+    dev->clear_k = (float)((smooth ? 1.01 * kmax : 0.0) + 1e-3 * (1.0 + reach));
+    dev->clear_rho = (float)(1.15 * (reach + (smooth ? kmax : 0.0)));
+  }
 }
 
 // The culling grid of a primitive table without domain rows (rm_params.hpp CullGrid; rm_kernels.inc rm_cull_build_kernel has the
@@ -891,7 +902,7 @@ static int build_params(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniform
   P->block_order = nullptr;
   P->block_cost = nullptr;
   P->no_far_jump = (flags & RM_RENDER_NO_FAR_JUMP) ? 1 : 0;
-  if (P->no_far_jump) P->scene.far_end = 0;  // the far-field shortcuts inside an evaluation (KIFS tree) read the scene block
+  if (P->no_far_jump) P->scene.far_end = 0, P->scene.clear_rho = 0.0f;  // the far-field shortcuts inside an evaluation (KIFS tree) read the scene block
   if (flags & RM_RENDER_NO_CULL) P->scene.cull.cells = nullptr;
   return RM_OK;
 }
@@ -1514,7 +1525,7 @@ int rm_probe(rm_ctx* ctx, rm_scene* scene, int what, const float* in, int n, flo
   if (e == hipSuccess) e = hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
     ProbeParams P{scene->dev, d_in, d_out, n, what, param, (flags & RM_RENDER_FAST) ? ctx->retire_eps : 0.0f, (flags & RM_RENDER_NO_FAR_JUMP) ? 1 : 0};
-    if (P.no_far_jump) P.scene.far_end = 0;
+    if (P.no_far_jump) P.scene.far_end = 0, P.scene.clear_rho = 0.0f;
     if (flags & RM_RENDER_NO_CULL) P.scene.cull.cells = nullptr;
     e = (flags & RM_RENDER_FAST) ? rm::launch_probe_fast(P, ctx->stream) : ctx->gl_stack ? rm_gl_launch_probe(&P, ctx->stream) : rm::launch_probe_strict(P, ctx->stream);
   }

@@ -111,7 +111,12 @@ struct DevScene {
   // far_r2 = (2 R')^2 with R' = the radius of a sphere about the origin that holds every shape, plus the largest smooth-union radius k (a chain of smooth unions stays within k of the minimum).
   int far_end;
   float far_r2;
-  int reserved3;
+  // a ray that passes every shape of a table at a distance (rm_device.hpp Sdf<RM_SCENE_TABLE>::clear_miss): the clearance beyond a
+  // shape's bounding sphere is clear_k (the largest smooth-union radius) + the step b0 the march is then sure of, which the steps it
+  // has left decide: b0 = 2.05 clear_rho / (left - 84), clear_rho = the radius of a sphere about the origin that holds every
+  // shape's sphere with 15 % to spare.  clear_rho = 0: no such test
+  float clear_k;
+  float clear_rho;
   CullGrid cull;
 };
 

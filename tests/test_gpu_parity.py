@@ -1494,7 +1494,7 @@ def test_table_far_jump_end_points_equal_the_stepwise_march(ctx):
         d[n // 2:] = aim - o[n // 2:]
         d[n // 2:] /= np.linalg.norm(d[n // 2:], axis=1, keepdims=True)
         rays = np.concatenate([o, d], 1).astype(np.float32)
-        for steps in (40.0, 47.0, 48.0, 49.0, 59.0, 60.0, 61.0, 71.0, 72.0, 73.0, 89.0, 90.0, 91.0, 128.0, 256.0):  # around the 48 / 60 / 72 the jump asks for by distance, and the 90 of a ray that is going to miss
+        for steps in (40.0, 47.0, 48.0, 49.0, 59.0, 60.0, 61.0, 71.0, 72.0, 73.0, 89.0, 90.0, 91.0, 99.0, 100.0, 101.0, 128.0, 256.0):  # around the 48 / 60 / 72 the jump asks for by distance, the 90 of a ray that is going to miss the scene's sphere and the 100 from which one that passes every shape at a distance is looked for
             a = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST)
             b = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST | abi.RM_RENDER_NO_FAR_JUMP)
             assert same_bits(a, b).all(), f"table {it}, {steps} steps: {int((~same_bits(a, b)).any(-1).sum())} end points differ"
