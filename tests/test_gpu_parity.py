@@ -1617,6 +1617,33 @@ def test_kifs_far_field_shortcuts_are_exact(ctx):
 FAST_TOLERANCE_K = 1.0
 
 
+@pytest.mark.parametrize("scene", ["bulb", "csg64", "fractal1", "csg_mixed"])
+def test_kernel_variants_by_job_shape_leave_the_same_bits(ctx, scene):
+    """The fast pixel kernel has variants for jobs with exactly one light (its term is computed before its shadow march) and for
+    one light and one bounce (nothing of the bounce lives across the shadow march: no scratch), rm_kernels.inc ONE_LIGHT.  Every
+    job shape -- 0..3 lights (one of them soft), 1..3 bounces -- on the headline kind, CSG-64's kind, a kind without compaction
+    and a short table: all three planes equal the wavefront pipeline's, which has no variants, bit for bit; and the kernel the job
+    selected is the one the shape asks for (the same job with a second light of zero colour takes the general kernel: the same
+    colour plane as the one-light job up to that light's zero term)."""
+    sc = {"bulb": S.Mandelbulb, "csg64": S.csg64, "fractal1": S.SphereGridFractal, "csg_mixed": lambda: GC.build_scene("csg_mixed")}[scene]()
+    pos = {"bulb": (0, 0, -2.5), "csg64": (0, 0, -5.0), "fractal1": (0.0, 0.0, 0.0), "csg_mixed": (0.3, 0.2, -4.0)}[scene]
+    lights3 = [J.point_light((2.0, 3.0, -4.0)), J.point_light((-3.0, 1.0, -2.0), size=0.3), J.sun_light((0.3, 1.0, -0.2))]
+    for nl in (0, 1, 2, 3):
+        for counts in ((48,), (48, 24), (40, 24, 16)):
+            schema = J.make_schema(sc, 160, 96, counts=counts, render_mode="full", position=pos, lights=lights3[:nl])
+            noises = GC.halton_pairs(2)
+            a = render_gpu(ctx, sc, schema, noises, FAST | MK)
+            b = render_gpu(ctx, sc, schema, noises, FAST | WF)
+            for k in range(3):
+                assert same_bits(a[k], b[k]).all(), f"{scene}, {nl} lights, {counts}: plane {k} differs from the pipeline in {int((~same_bits(a[k], b[k])).sum())} values"
+    # one light + a second light without colour: the general kernel; the G-buffer planes do not depend on lights at all
+    one = J.make_schema(sc, 160, 96, counts=(48,), render_mode="full", position=pos, lights=lights3[:1])
+    two = J.make_schema(sc, 160, 96, counts=(48,), render_mode="full", position=pos, lights=[lights3[0], J.point_light((1.0, 1.0, 1.0), color=(0.0, 0.0, 0.0))])
+    noises = GC.halton_pairs(1)
+    a, b = render_gpu(ctx, sc, one, noises, FAST | MK), render_gpu(ctx, sc, two, noises, FAST | MK)
+    assert same_bits(a[1], b[1]).all() and same_bits(a[2], b[2]).all()
+
+
 def _cull_table(rng, kind, rows=None):
     """a random table without domain rows, long enough for the culling grid: spheres and boxes under 0 = unions, 1 = unions,
     subtractions and intersections, 2 = those and smooth unions (which the grid never drops)"""
