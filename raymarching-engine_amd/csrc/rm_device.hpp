@@ -373,6 +373,39 @@ RM_DEV bool far_escape(v3 p, v3 dir, int left, float far_r2, bool need_nonzero_d
   return true;
 }
 
+// A SHADOW ray of a table that escapes with too few steps left for the overflow (far_need) -- the 64-step bounces of BASELINE's C5: a
+// sky pixel's shadow ray, cast from 10^6 away, is past the scene after five steps and has 59 to go -- marches on to the end of its
+// budget, doubling its distance every step, and ends finite and very far away.  Its end point is only ever compared:
+// `distance(result, adj) >= distance(pos, adj)` (raymarcher.frag:362-363).  Once that comparison is certain the march may stop:
+// outside (r^2 > far_r2) and not moving inward, as for the jump, and with `left` steps to go
+//  * the end point stays finite: d <= |p| + rho for a table (rho holds every shape: each term is, and min / max / the smooth minimum
+//    keep it) and |dir| <= 1.01, so r + rho at most grows by 2.01 per step: asked for log2(2.01) left + log2(r + rho) <= 63.9, i.e.
+//    r_end < 1.73e19 and r_end^2 < 3.0e38 (rho <= r / 2 out there: log2(r + rho) <= log2 r + 0.585);
+//  * and it is far enough: the worst case of the jump's own recurrence (started at a right angle, d = r - R', |dir|^2 = 0.98, every
+//    step rounded down) has r_n >= 1.25 r_0 2^(n - 3) from n = 6 on: asked for left >= 8 and log2 r + left - 3 >= need_e, where
+//    2^need_e >= distance(pos, adj) + |adj| -- then |result - adj| >= r_end - |adj| >= distance(pos, adj).
+// The march then ends at dir * 2^(need_e + 2), for which the comparison holds as well.  The first condition is (nearly) invariant
+// along an escape -- a step takes one from `left` and adds one to log2 r -- so it has to be sharp: with the bound 2^(left + 3) r of
+// a first attempt the rays that escape early never met it, and the shortcut did nothing (C5 -1.5 %).
+RM_DEV bool far_shadow_escape(v3 p, v3 dir, int left, float far_r2, int need_e, v3& end) {
+  const float r2 = FM::fma(p.z, p.z, FM::fma(p.y, p.y, p.x * p.x));
+  if (!(r2 > far_r2 && r2 < 1e30f) || left < 8 || need_e > 100) return false;
+  const float s = FM::fma(p.z, dir.z, FM::fma(p.y, dir.y, p.x * dir.x)), dd = FM::fma(dir.z, dir.z, FM::fma(dir.y, dir.y, dir.x * dir.x));
+  if (!(s >= 0.0f && dd > 0.98f && dd < 1.02f)) return false;
+  const float log2_r = 0.5f * __builtin_amdgcn_logf(r2);  // v_log_f32: log2, to an ulp
+  if (FM::fma(1.00716f, (float)left, log2_r) > 63.9f - 0.585f - 0.02f) return false;
+  if (log2_r - 0.01f + (float)(left - 3) < (float)need_e) return false;
+  end = dir * __uint_as_float((unsigned int)(127 + need_e + 2) << 23);
+  return true;
+}
+// need_e for a shadow ray from pos to adj (1000: not a shadow ray, or nothing that can be promised)
+RM_DEV int shadow_need_exponent(float dist_pos_adj, v3 adj) {
+  const float n = dist_pos_adj + (fabsf(adj.x) + fabsf(adj.y) + fabsf(adj.z));  // >= distance + |adj|
+  if (!(n < 1e30f)) return 1000;
+  const int e = (int)((__float_as_uint(n) >> 23) & 0xffu) - 126;  // n < 2^e
+  return e < -20 ? -20 : e;
+}
+
 // RM_SCENE_TABLE: left fold over the LDS-resident primitive table.  Rows are
 // read with one address for the whole wave (LDS broadcast); type/operator go
 // through readfirstlane so the per-row switch is a scalar branch.
