@@ -1462,21 +1462,23 @@ def test_table_far_jump_is_exact_on_the_csg_frames(ctx):
 def test_shadow_rays_with_short_budgets_stop_when_their_test_is_certain(ctx):
     """A table's shadow ray that escapes with too few steps left for the overflow (the 64-step bounces of C5) ends finite and far
     away, and its end point is only compared (raymarcher.frag:362-363): the fast pixel kernel stops such a march once the
-    comparison is certain (rm_device.hpp far_shadow_escape).  Random tables of 1..30 rows under every operator, jobs with step
-    budgets of 24..100 per bounce -- 57..63 among them, where an escaping ray's r^2 does or does not overflow within the budget --,
+    comparison is certain (rm_device.hpp far_shadow_escape); and a ray that passes every shape of a table at a distance is set to
+    its end state where it starts (clear_miss: from 100 steps on).  Random tables of 1..40 rows under every operator, jobs with step
+    budgets of 24..128 per bounce -- 57..63 among them, where an escaping ray's r^2 does or does not overflow within the budget, and
+    99..101 --,
     one to three lights (soft ones, one far away, one at the origin, a sun), cameras inside and outside the scene, with and
     without fog: every plane equals the stepwise march (RM_RENDER_NO_FAR_JUMP) and the wavefront pipeline, bit for bit.  And C5's
     own job at 1024 x 1024."""
     rng = np.random.default_rng(4242 + SEED_OFFSET)
     jobs = []
-    for it in range(24):
-        sc = _cull_table(rng, 2, rows=int(rng.integers(1, 31)))
+    for it in range(32):
+        sc = _cull_table(rng, 2, rows=int(rng.integers(1, 41)))  # from 16 rows on the long tables' kernels, which have these exits
         lights = [J.point_light(tuple(rng.uniform(-5, 5, 3)), size=float(rng.choice([0.0, 0.3])))]
         if it % 3 == 1:
             lights.append(J.point_light((300.0, -200.0, 100.0)))
         if it % 3 == 2:
             lights += [J.point_light((0.0, 0.0, 0.0), size=0.1), J.sun_light((0.3, 1.0, -0.2))]
-        counts = tuple(int(c) for c in rng.choice([24, 40, 56, 57, 58, 59, 60, 61, 62, 63, 64, 71, 72, 80, 100], size=int(rng.integers(1, 4))))
+        counts = tuple(int(c) for c in rng.choice([24, 40, 56, 57, 58, 59, 60, 61, 62, 63, 64, 71, 72, 80, 99, 100, 101, 128], size=int(rng.integers(1, 4))))
         schema = J.make_schema(sc, 192, 128, counts=counts, render_mode="full", position=tuple(rng.uniform(-1, 1, 3) * rng.choice([0.5, 6.0])), lights=lights,
                                fog_density=float(rng.choice([0.0, 0.0, 0.05])))
         jobs.append((f"job {it} {counts}", sc, schema))
