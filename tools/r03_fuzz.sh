@@ -7,7 +7,7 @@ date
 RM_RANDOM_JOBS=12000 timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -s -k "random_jobs_strict" 2>&1 | grep "random jobs\|passed\|failed"
 RM_RANDOM_SCENES=12000 timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "random_scenes_probes" 2>&1 | tail -1
 RM_RANDOM_JOBS2=6000 timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "random_jobs_partitions" 2>&1 | tail -1
-for seed in 1 2 3 4 5 6; do RM_RANDOM_SEED=$seed timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "far_jump_end_points or row_culling" 2>&1 | tail -1; done
+for seed in 1 2 3 4 5 6; do RM_RANDOM_SEED=$seed timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "far_jump_end_points or row_culling or shadow_rays" 2>&1 | tail -1; done
 date
 } | tee gpurun_out/r3fuzz/log.txt
 for seed in 1 2 3; do
