@@ -8,7 +8,7 @@ F, MK = abi.RM_RENDER_FAST, abi.RM_RENDER_MEGAKERNEL
 soft = [J.point_light((2.0, 3.0, -4.0), size=0.3)]
 sc = S.csg64(); h = ctx.create_scene(sc)
 fb = ctx.create_striped_framebuffer(8192, 8192, shard.STRIPE_ROWS, 8, 0)
-for counts in ((128, 64, 64), (128, 128, 128), (128, 96, 96), (128, 80, 80), (128, 72, 72), (128,), (128, 64), (128, 128)):
+for counts in ((128, 64, 64), (128, 128, 128), (128, 96, 96), (128, 80, 80), (128, 72, 72), (128, 56, 56), (128, 48, 48), (128, 32, 32), (64, 64, 64), (128,), (96,), (72,), (64,), (128, 64), (128, 128)):
     schema = J.make_schema(sc, 8192, 8192, counts=counts, render_mode="full", position=(0, 0, -5.0), lights=soft)
     u = J.uniforms_from_schema(schema, (0.5, 1 / 3))
     ctx.render_timed(h, fb, u, 1, None, F | MK | abi.RM_RENDER_NO_OVERLAP)
