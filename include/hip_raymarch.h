@@ -215,8 +215,11 @@ enum {
   RM_RENDER_NO_FAR_JUMP = 64, /* RM_RENDER_FAST, bounded scenes (Mandelbulb, tables without domain rows, the sponge, the
                                 rotation and sphere-grid fractals): march an escaping ray step by step instead of setting
                                 it to the end state its remaining steps are known to reach (castRay, raymarcher.frag:163-170,
-                                has no distance bound: such a ray overflows to a fixed +-Inf / NaN pattern).  A measurement
-                                and test switch: the same bits either way. */
+                                has no distance bound: such a ray overflows to a fixed +-Inf / NaN pattern) -- also a ray that
+                                is certain to miss the scene, or every shape of a long table -- and a long table's shadow ray
+                                that escapes with too few steps left for the overflow is marched to the end instead of being
+                                stopped once its comparison (raymarcher.frag:362-363) is certain.  A measurement and test
+                                switch: the same bits in every plane either way. */
   RM_RENDER_NO_CULL = 128     /* RM_RENDER_FAST, long primitive tables built with union / subtract / intersect: evaluate every row
                                 of the table at every point instead of the rows the point's grid cell lists (a row whose operator
                                 is an exact no-op everywhere in the cell is skipped: min(d, di) with the shape further away than
