@@ -341,13 +341,19 @@ template <int KIND>
 struct Sdf;
 
 // Steps an escaping ray needs at most to reach its end state when its distance estimate is bounded below by |p| - R' (the
-// bounded scenes: tables, the sponge, the rotation fractal, the sphere-grid fractal; far_r2 = (2 R')^2): the worst case of
-// the recurrence (r^2, s) -> (r^2 + 2 d s + d^2, s + d), d = r - R', started at a right angle with |dir|^2 = 0.98 and every
-// step rounded down by 1e-3, overflows |p|^2 after 64 steps from r = 2 R', 56 from 100 R', 43 from 1e6 R'; 3 more settle it.
-RM_DEV int far_need(float r2, float far_r2) { return r2 >= far_r2 * 2.5e11f ? 48 : (r2 >= far_r2 * 2500.0f ? 60 : 72); }
+// bounded scenes: tables, the sponge, the rotation fractal, the sphere-grid fractal; far_r2 = (2 R' + 1)^2 >= 1): the worst case of
+// the recurrence (r^2, s) -> (r^2 + 2 d s + d^2 |dir|^2, s + d |dir|^2), d = r - R', started at a right angle with |dir|^2 = 0.98
+// and every step shortened by 1e-3, overflows r^2 within 64 - log2 r + 3.5 steps from any r >= 2 R' + 1 (iterated over r = 1 .. 2^50
+// and every R' the start allows); 3 more settle the end state.  The overflow is ABSOLUTE -- r has to reach 1.8e19 -- so for a
+// given r / R' the SMALL scenes need the most steps: from the jump's radius 66 + 3 (R' -> 0), from 50 times it 60 + 3, from 5e5
+// times it 47 + 3.  Three tiers: 71, 63, 50.  (They were 72, 60 and 48 until the end of round 3, from a derivation on CSG-64's
+// scale, R' ~ 3: for scenes of R' <= 1 the two far tiers were up to 3 steps short of this worst case.  No test ray realised it --
+// real directions are unit and rarely tangential -- but the jump is only exact if the bound is.  The count taken exactly per step,
+// 71 - floor(log2 r), would let a few more budgets jump and costs the sphere-grid kernel, whose march is short, 12 %.)
+RM_DEV int far_need(float r2, float far_r2) { return r2 >= far_r2 * 2.5e11f ? 50 : (r2 >= far_r2 * 2500.0f ? 63 : 71); }
 // The conditions all those jumps share: a unit direction without a zero component (0 x Inf = NaN), and a ray that is certain to
 // escape with steps to spare --
-//  * outside (r^2 > far_r2 = (2 Rp)^2, Rp = R' + 1/2) and not moving inward, far_need() steps left; or
+//  * outside (r^2 > far_r2 = (2 Rp)^2, Rp = R' + 1/2) and not moving inward, far_need() steps left (at most 71); or
 //  * about to MISS the scene: the ray's line ahead stays m >= 1.25 Rp from the origin.  All along it d >= |x| - Rp >= Rp / 4, so
 //    the march never settles: one step brings a ray from far inside to within Rp of its closest point (d >= the distance still to
 //    go, minus Rp), 12 steps of >= Rp / 4 (13 with |dir|^2 = 0.98 and the rounding) take it from there to 2 Rp beyond, where
@@ -358,7 +364,7 @@ RM_DEV int far_need(float r2, float far_r2) { return r2 >= far_r2 * 2.5e11f ? 48
 RM_DEV bool far_escape(v3 p, v3 dir, int left, float far_r2, bool need_nonzero_dir, v3& end) {
   const float r2 = FM::fma(p.z, p.z, FM::fma(p.y, p.y, p.x * p.x));
   const float miss_m2 = FM::fma(0.4f, far_r2, 0.05f);
-  if (!(r2 >= miss_m2 && r2 < 1e30f) || left < 48) return false;  // (most steps of most rays: inside -- one compare and out)
+  if (!(r2 >= miss_m2 && r2 < 1e30f) || left < 50) return false;  // (most steps of most rays: inside -- one compare and out)
   const float s = FM::fma(p.z, dir.z, FM::fma(p.y, dir.y, p.x * dir.x)), dd = FM::fma(dir.z, dir.z, FM::fma(dir.y, dir.y, dir.x * dir.x));
   if (!(dd > 0.98f && dd < 1.02f)) return false;
   const bool outside = r2 > far_r2 && s >= 0.0f && left >= far_need(r2, far_r2);

@@ -1528,7 +1528,7 @@ def test_table_far_jump_end_points_equal_the_stepwise_march(ctx):
         d[n // 2:] = aim - o[n // 2:]
         d[n // 2:] /= np.linalg.norm(d[n // 2:], axis=1, keepdims=True)
         rays = np.concatenate([o, d], 1).astype(np.float32)
-        for steps in (40.0, 47.0, 48.0, 49.0, 59.0, 60.0, 61.0, 71.0, 72.0, 73.0, 89.0, 90.0, 91.0, 99.0, 100.0, 101.0, 128.0, 256.0):  # around the 48 / 60 / 72 the jump asks for by distance, the 90 of a ray that is going to miss the scene's sphere and the 100 from which one that passes every shape at a distance is looked for
+        for steps in (24.0, 40.0, 47.0, 48.0, 49.0, 50.0, 51.0, 59.0, 60.0, 61.0, 62.0, 63.0, 64.0, 69.0, 70.0, 71.0, 72.0, 73.0, 89.0, 90.0, 91.0, 99.0, 100.0, 101.0, 128.0, 256.0):  # around the 50 / 63 / 71 the jump asks for by distance, the 90 of a ray that is going to miss the scene's sphere and the 100 from which one that passes every shape at a distance is looked for
             a = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST)
             b = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST | abi.RM_RENDER_NO_FAR_JUMP)
             assert same_bits(a, b).all(), f"table {it}, {steps} steps: {int((~same_bits(a, b)).any(-1).sum())} end points differ"
@@ -1559,7 +1559,7 @@ def test_menger_far_jump_is_exact(ctx):
         d[: n // 8] = np.eye(3)[rng.integers(0, 3, n // 8)] * rng.choice([-1.0, 1.0], size=(n // 8, 1))
         d[n // 8: n // 4, int(rng.integers(0, 3))] = 0.0
         rays = np.concatenate([o, d], 1).astype(np.float32)
-        for steps in (40.0, 47.0, 48.0, 49.0, 59.0, 60.0, 61.0, 71.0, 72.0, 73.0, 89.0, 90.0, 91.0, 128.0, 256.0):
+        for steps in (24.0, 40.0, 47.0, 48.0, 49.0, 50.0, 51.0, 59.0, 60.0, 61.0, 62.0, 63.0, 64.0, 69.0, 70.0, 71.0, 72.0, 73.0, 89.0, 90.0, 91.0, 128.0, 256.0):
             a = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST)
             b = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST | abi.RM_RENDER_NO_FAR_JUMP)
             assert same_bits(a, b).all(), f"iterations {iters}, {steps} steps: {int((~same_bits(a, b)).any(-1).sum())} end points differ"
@@ -1584,7 +1584,7 @@ def test_sphere_grid_far_jump_is_exact(ctx):
         d /= np.linalg.norm(d, axis=1, keepdims=True)
         d[: n // 8] = np.eye(3)[rng.integers(0, 3, n // 8)] * rng.choice([-1.0, 1.0], size=(n // 8, 1))
         rays = np.concatenate([o, d], 1).astype(np.float32)
-        for steps in (32.0, 47.0, 48.0, 49.0, 59.0, 60.0, 61.0, 64.0, 71.0, 72.0, 73.0, 89.0, 90.0, 91.0, 128.0):
+        for steps in (24.0, 32.0, 47.0, 48.0, 49.0, 52.0, 55.0, 59.0, 60.0, 61.0, 64.0, 66.0, 69.0, 70.0, 71.0, 72.0, 73.0, 89.0, 90.0, 91.0, 128.0):
             a = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST)
             b = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST | abi.RM_RENDER_NO_FAR_JUMP)
             assert same_bits(a, b).all(), f"scene {it}, {steps} steps: {int((~same_bits(a, b)).any(-1).sum())} end points differ"
@@ -1625,7 +1625,7 @@ def test_kifs_far_field_shortcuts_are_exact(ctx):
         d /= np.linalg.norm(d, axis=1, keepdims=True)
         d[: n // 8] = np.eye(3)[rng.integers(0, 3, n // 8)] * rng.choice([-1.0, 1.0], size=(n // 8, 1))
         rays = np.concatenate([rng.normal(size=(n, 3)) * rng.choice([1.0, 5.0, 1e3, 1e6], size=(n, 1)), d], 1).astype(np.float32)
-        for steps in (40.0, 48.0, 49.0, 60.0, 61.0, 72.0, 73.0, 89.0, 90.0, 91.0, 128.0, 256.0):
+        for steps in (24.0, 40.0, 48.0, 49.0, 52.0, 55.0, 60.0, 61.0, 66.0, 69.0, 70.0, 72.0, 73.0, 89.0, 90.0, 91.0, 128.0, 256.0):
             ra = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST)
             rb = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST | abi.RM_RENDER_NO_FAR_JUMP)
             assert same_bits(ra, rb).all(), f"scene {it}, {steps} steps: {int((~same_bits(ra, rb)).any(-1).sum())} end points differ"
