@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RM_ABI_VERSION 5 /* 3: rm_ctx_set_sample_batch, rm_buffer_*; 4: rm_ctx_set_gl_stack; 5: RmSurface / RmSceneDesc.surfaces (the struct grew), rm_pack_present_rows, rm_present_sharded, rm_ctx_last_pipeline, RM_RENDER_NO_FAR_JUMP, RM_RENDER_NO_CULL (additions only) */
+#define RM_ABI_VERSION 6 /* 6: rm_present_striped_rows, rm_present_sharded_start / _finish, RM_PROBE_CAST_SHADOW (additions only); 3: rm_ctx_set_sample_batch, rm_buffer_*; 4: rm_ctx_set_gl_stack; 5: RmSurface / RmSceneDesc.surfaces (the struct grew), rm_pack_present_rows, rm_present_sharded, rm_ctx_last_pipeline, RM_RENDER_NO_FAR_JUMP, RM_RENDER_NO_CULL (additions only) */
 
 #define RM_MAX_BOUNCES 10 /* raymarchingStepCountsArray[10], raymarcher.frag:31 */
 #define RM_MAX_LIGHTS 10  /* lightPositions[10],             raymarcher.frag:37-39 */
@@ -411,8 +411,12 @@ int rm_render_timed(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* u
  *   RM_PROBE_CAST_STEPS in: n x (float3 p, float3 dir)  out: n x float   number of castRay steps after which the ray's
  *                                                       position no longer changes bitwise (= steps if it never settles);
  *                                                       a measurement aid for the wave-retire, not a reference function
+ *   RM_PROBE_CAST_SHADOW in: n x (float3 p, float3 dir, float3 light)  out: n x float  1 if the light is seen, else 0: the shadow
+ *                                                       test of one light, distance(castRay(p, dir, steps), light) >= distance(p, light)
+ *                                                       (raymarcher.frag:362-363), marched as the pixel kernel marches a shadow ray
+ * A table of 16 rows or more is marched as its pixel kernels march it (the long tables' far-field exits included).
  */
-enum { RM_PROBE_SDF = 0, RM_PROBE_CAST_RAY = 1, RM_PROBE_NORMAL = 2, RM_PROBE_MATERIAL = 3, RM_PROBE_CAST_STEPS = 4 };
+enum { RM_PROBE_SDF = 0, RM_PROBE_CAST_RAY = 1, RM_PROBE_NORMAL = 2, RM_PROBE_MATERIAL = 3, RM_PROBE_CAST_STEPS = 4, RM_PROBE_CAST_SHADOW = 5 };
 int rm_probe(rm_ctx* ctx, rm_scene* scene, int what, const float* in, int n, float param,
              int flags, float* out);
 
@@ -475,16 +479,37 @@ int rm_present_rows(rm_ctx* ctx, rm_fb* fb, int samples, void* out_rgba8_device,
  * the other): the bytes are those rm_present gives for the unsharded frame (raymarching_engine_amd/dist.py,
  * index.tsx:25-59 is the caller this serves). */
 int rm_pack_present_rows(rm_ctx* ctx, rm_fb* fb, void* out_float4_device, void* hip_stream);
+/* The present pass (display.frag:16-64) of ONE PART of a striped frame: `color` / `normal_dof` are DEVICE pointers to the WHOLE
+ * frame in image order (height x width float4 each; with depth of field the gathered and assembled rows of
+ * rm_pack_present_rows serve as both), out_rgba8_device receives the rows part `part` of `parts` holds (stripes of
+ * stripe_rows rows dealt round-robin, packed as in rm_fb_create_striped: rows(part) x width x 4 bytes).  The taps,
+ * their order and the arithmetic are rm_present_device's: assembled (rm_assemble_striped_bytes) the parts' bytes are
+ * rm_present's.  This is how a sharded frame WITH depth of field is shown without one GPU blurring all of it: every
+ * GPU gets the packed frame (an all-gather), blurs the stripes it holds -- 1 / parts of the pass -- and only RGBA8
+ * travels to the GPU that shows the frame.  Asynchronous on hip_stream (NULL = the context's stream). */
+int rm_present_striped_rows(rm_ctx* ctx, const void* color, const void* normal_dof, int width, int height, int samples, int stripe_rows, int parts, int part,
+                            void* out_rgba8_device, void* hip_stream);
+
 /* The present of a frame that ONE process renders on several GPUs -- the shape of the reference's own host: one
  * thread, one render loop (index.tsx:120), here with a context per GPU, each holding one part of the frame's stripes
  * (rm_fb_create_striped with parts = `parts`, part = p on ctxs[p]; the host hands every sample to each context in turn
- * and the GPUs render concurrently, launches being asynchronous).  Every context tone-maps (dof == 0, rm_present_rows) or
- * packs (dof != 0, rm_pack_present_rows) the rows it holds on its own stream, the rows travel to ctxs[0]'s GPU by
- * peer copies over xGMI (hipMemcpyPeerAsync; no collective library, no second process), are put in image order there
- * and -- with depth of field -- blurred and tone-mapped there (display.frag:16-64).  out_rgba8 = height*width*4 bytes of
- * HOST memory, row 0 = bottom: the bytes rm_present gives for the same samples on one framebuffer.  Synchronous.
- * (Hosts with a process per GPU -- bench.py, job.RenderJobContext(group=...) -- gather the same rows over RCCL instead:
+ * and the GPUs render concurrently, launches being asynchronous).
+ *   rm_present_sharded_start: every context snapshots the rows it holds on its own stream -- tone-mapped (dof == 0,
+ *     rm_present_rows) or packed (dof != 0, rm_pack_present_rows) -- and everything after that is enqueued on streams of
+ *     the present's own, so the host can hand out the next samples at once (RenderJobExecutor.tsx:163-166 yields after a
+ *     present; here the frame travels WHILE the next samples render).  dof == 0: the RGBA8 rows go to ctxs[0]'s GPU by
+ *     peer copies over xGMI (hipMemcpyPeerAsync; no collective library, no second process) and are put in image order
+ *     there.  dof != 0: the packed rows go to EVERY GPU, each puts the frame together, blurs and tone-maps the stripes
+ *     it holds (rm_present_striped_rows: 1 / parts of the pass per GPU) and sends those bytes to ctxs[0]'s GPU.  The
+ *     canvas is copied to pinned host memory.  Nothing is waited for.  One present at a time: finish before the next start.
+ *   rm_present_sharded_finish: waits for THAT present only (an event; renders enqueued since keep running) and copies
+ *     the canvas to out_rgba8 = height*width*4 bytes of HOST memory, row 0 = bottom: the bytes rm_present gives for the
+ *     same samples on one framebuffer.
+ *   rm_present_sharded: both, one after the other (synchronous).
+ * (Hosts with a process per GPU -- bench.py, job.RenderJobContext(group=...) -- move the same rows over RCCL instead:
  * raymarching_engine_amd/dist.py.) */
+int rm_present_sharded_start(rm_ctx* const* ctxs, rm_fb* const* fbs, int parts, int samples, int dof);
+int rm_present_sharded_finish(rm_ctx* const* ctxs, int parts, uint8_t* out_rgba8);
 int rm_present_sharded(rm_ctx* const* ctxs, rm_fb* const* fbs, int parts, int samples, int dof, uint8_t* out_rgba8);
 
 #ifdef __cplusplus

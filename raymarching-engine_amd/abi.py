@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-RM_ABI_VERSION = 5
+RM_ABI_VERSION = 6
 RM_MAX_BOUNCES = 10
 RM_MAX_LIGHTS = 10
 RM_MAX_PRIMS = 256
@@ -21,7 +21,7 @@ RM_RENDER_NO_FAR_JUMP = 64
 RM_RENDER_NO_CULL = 128
 RM_PIPELINE_NONE, RM_PIPELINE_PIXEL_KERNEL, RM_PIPELINE_WAVEFRONT = 0, 1, 2
 RM_PLANE_COLOR, RM_PLANE_NORMAL_DOF, RM_PLANE_ALBEDO_DEPTH = 0, 1, 2
-RM_PROBE_SDF, RM_PROBE_CAST_RAY, RM_PROBE_NORMAL, RM_PROBE_MATERIAL, RM_PROBE_CAST_STEPS = 0, 1, 2, 3, 4
+RM_PROBE_SDF, RM_PROBE_CAST_RAY, RM_PROBE_NORMAL, RM_PROBE_MATERIAL, RM_PROBE_CAST_STEPS, RM_PROBE_CAST_SHADOW = 0, 1, 2, 3, 4, 5
 
 
 class RmUniforms(C.Structure):

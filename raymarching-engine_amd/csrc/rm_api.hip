@@ -27,6 +27,8 @@ hipError_t rm_gl_launch_pixels(const void* kparams, hipStream_t stream);
 hipError_t rm_gl_launch_probe(const void* probe_params, hipStream_t stream);
 hipError_t rm_gl_launch_camera_rng(const RmUniforms* u, int W, int H, int what, int count, float* out, hipStream_t stream);
 hipError_t rm_gl_launch_present(const float4* color, const float4* normal_dof, int W, int H, float brightness, uchar4* out, hipStream_t stream);
+hipError_t rm_gl_launch_present_striped(const float4* color, const float4* normal_dof, int W, int H, float brightness, uchar4* out, int stripe_rows, int parts,
+                                        int part, int local_rows, hipStream_t stream);
 hipError_t rm_gl_launch_present_rows(const float4* color, long long pixels, float brightness, uchar4* out, hipStream_t stream);
 hipError_t rm_gl_set_native_tan(int on, hipStream_t stream);
 }
@@ -100,10 +102,17 @@ struct rm_ctx {
   size_t present_cap = 0;          // pixels
   // rm_present_sharded (one process driving several GPUs): this context's rows of the payload, and on the context that
   // shows the frame the gathered parts and the frame in image order; grown on demand, freed with the context
-  void* shard_rows = nullptr;  size_t shard_rows_cap = 0;
-  void* shard_recv = nullptr;  size_t shard_recv_cap = 0;
-  void* shard_frame = nullptr; size_t shard_frame_cap = 0;
-  hipEvent_t shard_ev = nullptr;
+  void* shard_rows = nullptr;  size_t shard_rows_cap = 0;    // this context's rows of the payload (packed float4 or RGBA8)
+  void* shard_rows8 = nullptr; size_t shard_rows8_cap = 0;   // depth of field: this context's rows after ITS blur (RGBA8)
+  void* shard_all = nullptr;   size_t shard_all_cap = 0;     // depth of field: every part's packed rows (the all-gather's receive side)
+  void* shard_recv = nullptr;  size_t shard_recv_cap = 0;    // root: every part's RGBA8 rows
+  void* shard_frame = nullptr; size_t shard_frame_cap = 0;   // depth of field: the packed frame in image order (every context); root: the canvas
+  void* shard_canvas = nullptr; size_t shard_canvas_cap = 0; // root: the RGBA8 canvas in image order
+  void* shard_host = nullptr;  size_t shard_host_cap = 0;    // root: pinned host copy of the canvas (rm_present_sharded_finish reads it)
+  hipStream_t shard_stream = nullptr;                        // copies, assembly and blur of a present travel here, next to the renders
+  hipEvent_t shard_snap = nullptr, shard_ev = nullptr, shard_done = nullptr;  // snapshot written; this context's part delivered; root: canvas on the host
+  bool shard_pending = false;                                // root: a start without its finish
+  int shard_w = 0, shard_h = 0;                              // root: the canvas of the pending present
   unsigned long long peer_enabled = 0;  // devices this context's GPU has been given peer access to
   std::string error;
 };
@@ -231,6 +240,13 @@ void rm_ctx_destroy(rm_ctx* ctx) {
   if (ctx->shard_rows) (void)hipFree(ctx->shard_rows);
   if (ctx->shard_recv) (void)hipFree(ctx->shard_recv);
   if (ctx->shard_frame) (void)hipFree(ctx->shard_frame);
+  if (ctx->shard_rows8) (void)hipFree(ctx->shard_rows8);
+  if (ctx->shard_all) (void)hipFree(ctx->shard_all);
+  if (ctx->shard_canvas) (void)hipFree(ctx->shard_canvas);
+  if (ctx->shard_host) (void)hipHostFree(ctx->shard_host);
+  if (ctx->shard_stream) { (void)hipStreamSynchronize(ctx->shard_stream); (void)hipStreamDestroy(ctx->shard_stream); }
+  if (ctx->shard_snap) (void)hipEventDestroy(ctx->shard_snap);
+  if (ctx->shard_done) (void)hipEventDestroy(ctx->shard_done);
   if (ctx->shard_ev) (void)hipEventDestroy(ctx->shard_ev);
   for (auto& b : ctx->buffers) (void)hipFree(b.first);  // rm_buffer_create'd memory the host did not destroy
   if (ctx->switch_ev) (void)hipEventDestroy(ctx->switch_ev);
@@ -1442,24 +1458,57 @@ int rm_present(rm_ctx* ctx, rm_fb* fb, int samples, uint8_t* out_rgba8) {
 
 // ---- present of a frame sharded over the GPUs of ONE process ----------------------------------------
 
-static int grow(rm_ctx* ctx, void** p, size_t* cap, size_t bytes) {
+static int grow(rm_ctx* ctx, void** p, size_t* cap, size_t bytes, bool pinned_host = false) {
   if (*cap >= bytes) return RM_OK;
   RM_HIP(ctx, hipSetDevice(ctx->device));
   if (*p) {
     RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(*p);
+    if (ctx->shard_stream) RM_HIP(ctx, hipStreamSynchronize(ctx->shard_stream));
+    (void)(pinned_host ? hipHostFree(*p) : hipFree(*p));
     *p = nullptr;
     *cap = 0;
   }
-  if (hipMalloc(p, bytes) != hipSuccess) { (void)hipGetLastError(); return fail(ctx, RM_ERR_DEVICE, "rm_present_sharded: out of device memory"); }
+  if ((pinned_host ? hipHostMalloc(p, bytes, hipHostMallocDefault) : hipMalloc(p, bytes)) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(ctx, RM_ERR_DEVICE, "rm_present_sharded: out of memory");
+  }
   *cap = bytes;
   return RM_OK;
 }
 
-int rm_present_sharded(rm_ctx* const* ctxs, rm_fb* const* fbs, int parts, int samples, int dof, uint8_t* out_rgba8) {
+int rm_present_striped_rows(rm_ctx* ctx, const void* color, const void* normal_dof, int width, int height, int samples, int stripe_rows, int parts, int part,
+                            void* out_rgba8_device, void* hip_stream) {
+  if (!ctx || !color || !out_rgba8_device) return fail(ctx, RM_ERR_INVALID, "rm_present_striped_rows: NULL argument");
+  if (width < 1 || height < 1 || samples < 1 || stripe_rows < 1 || parts < 1 || part < 0 || part >= parts)
+    return fail(ctx, RM_ERR_INVALID, "rm_present_striped_rows: width, height, samples, stripe_rows and parts must be >= 1, 0 <= part < parts");
+  RM_HIP(ctx, hipSetDevice(ctx->device));
+  RM_HIP(ctx, (ctx->gl_stack ? rm_gl_launch_present_striped : rm::launch_present_striped)(
+                  static_cast<const float4*>(color), static_cast<const float4*>(normal_dof), width, height, 1.0f / (float)samples, static_cast<uchar4*>(out_rgba8_device),
+                  stripe_rows, parts, part, striped_rows_below(height, stripe_rows, parts, part), hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream));
+  return RM_OK;
+}
+
+// device-to-device, over xGMI between two GPUs (direct access where the topology has it; the copy works either way)
+static int shard_copy(rm_ctx* root, rm_ctx* from, rm_ctx* to, void* dst, const void* src, size_t bytes, hipStream_t stream) {
+  if (from->device == to->device) {
+    RM_HIP(root, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream));
+    return RM_OK;
+  }
+  if (!(from->peer_enabled & (1ull << (to->device & 63)))) {
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, from->device, to->device) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(to->device, 0);
+    (void)hipGetLastError();  // "already enabled" is fine
+    from->peer_enabled |= 1ull << (to->device & 63);
+  }
+  RM_HIP(root, hipMemcpyPeerAsync(dst, to->device, src, from->device, bytes, stream));
+  return RM_OK;
+}
+
+int rm_present_sharded_start(rm_ctx* const* ctxs, rm_fb* const* fbs, int parts, int samples, int dof) {
   rm_ctx* root = (ctxs && parts >= 1) ? ctxs[0] : nullptr;
-  if (!root || !fbs || !out_rgba8) return fail(root, RM_ERR_INVALID, "rm_present_sharded: NULL argument");
+  if (!root || !fbs) return fail(root, RM_ERR_INVALID, "rm_present_sharded: NULL argument");
   if (samples < 1) return fail(root, RM_ERR_INVALID, "rm_present_sharded: samples must be >= 1");
+  if (root->shard_pending) return fail(root, RM_ERR_INVALID, "rm_present_sharded_start: the previous present has not been finished (rm_present_sharded_finish)");
   const rm_fb* f0 = fbs[0];
   for (int p = 0; p < parts; p++) {
     const rm_fb* f = fbs[p];
@@ -1470,53 +1519,108 @@ int rm_present_sharded(rm_ctx* const* ctxs, rm_fb* const* fbs, int parts, int sa
   }
   const int W = f0->width, H = f0->height, stripe = f0->stripe_rows;
   const int max_rows = striped_rows_below(H, stripe, parts, 0);  // part 0 holds the most rows
-  const size_t px_bytes = dof ? sizeof(float4) : sizeof(uchar4);  // packed (colour, DoF radius) rows, or tone-mapped RGBA8 rows
-  const size_t row_bytes = (size_t)W * px_bytes, part_bytes = (size_t)max_rows * row_bytes;
-  if (int rc = grow(root, &root->shard_recv, &root->shard_recv_cap, part_bytes * (size_t)parts)) return rc;
-  if (int rc = grow(root, &root->shard_frame, &root->shard_frame_cap, (size_t)H * row_bytes)) return rc;
+  const size_t part8 = (size_t)max_rows * (size_t)W * sizeof(uchar4), part32 = (size_t)max_rows * (size_t)W * sizeof(float4);
+  const size_t canvas_bytes = (size_t)H * (size_t)W * sizeof(uchar4);
+  if (int rc = grow(root, &root->shard_recv, &root->shard_recv_cap, part8 * (size_t)parts)) return rc;
+  if (int rc = grow(root, &root->shard_canvas, &root->shard_canvas_cap, canvas_bytes)) return rc;
+  if (int rc = grow(root, &root->shard_host, &root->shard_host_cap, canvas_bytes, true)) return rc;
+  for (int p = 0; p < parts; p++) {
+    rm_ctx* c = ctxs[p];
+    int rc = grow(c, &c->shard_rows, &c->shard_rows_cap, dof ? part32 : part8);
+    if (!rc && dof) rc = grow(c, &c->shard_rows8, &c->shard_rows8_cap, part8);
+    if (!rc && dof) rc = grow(c, &c->shard_all, &c->shard_all_cap, part32 * (size_t)parts);
+    if (!rc && dof) rc = grow(c, &c->shard_frame, &c->shard_frame_cap, (size_t)H * (size_t)W * sizeof(float4));
+    if (rc) return c == root ? rc : fail(root, rc, rm_last_error(c));
+    RM_HIP(root, hipSetDevice(c->device));
+    if (!c->shard_stream) RM_HIP(root, hipStreamCreateWithFlags(&c->shard_stream, hipStreamNonBlocking));
+    if (!c->shard_snap) RM_HIP(root, hipEventCreateWithFlags(&c->shard_snap, hipEventDisableTiming));
+    if (!c->shard_ev) RM_HIP(root, hipEventCreateWithFlags(&c->shard_ev, hipEventDisableTiming));
+  }
+  if (!root->shard_done) { RM_HIP(root, hipSetDevice(root->device)); RM_HIP(root, hipEventCreateWithFlags(&root->shard_done, hipEventDisableTiming)); }
+  // 1. every context snapshots what it holds, on the stream its renders are ordered on: the next samples may start at once (the planes
+  //    are accumulated in place).  (The previous present was finished -- checked above -- so its buffers are free.)
   for (int p = 0; p < parts; p++) {
     rm_ctx* c = ctxs[p];
     rm_fb* f = fbs[p];
-    const size_t bytes = (size_t)f->row_count * row_bytes;
-    if (int rc = grow(c, &c->shard_rows, &c->shard_rows_cap, part_bytes)) return rc == RM_OK ? rc : fail(root, rc, rm_last_error(c));
     RM_HIP(root, hipSetDevice(c->device));
-    if (!c->shard_ev) RM_HIP(root, hipEventCreateWithFlags(&c->shard_ev, hipEventDisableTiming));
     const long long pixels = (long long)W * (long long)f->row_count;
     if (dof) RM_HIP(root, rm::launch_pack_rows(f->plane[0], f->plane[1], pixels, static_cast<float4*>(c->shard_rows), c->stream));
     else RM_HIP(root, (c->gl_stack ? rm_gl_launch_present_rows : rm::launch_present_rows)(f->plane[0], pixels, 1.0f / (float)samples, static_cast<uchar4*>(c->shard_rows), c->stream));
-    // this part's rows to the root's GPU, on the stream that wrote them: a peer copy over xGMI (a plain copy on one device)
-    void* dst = static_cast<char*>(root->shard_recv) + part_bytes * (size_t)p;
-    if (c->device == root->device) RM_HIP(root, hipMemcpyAsync(dst, c->shard_rows, bytes, hipMemcpyDeviceToDevice, c->stream));
-    else {
-      if (!(c->peer_enabled & (1ull << (root->device & 63)))) {  // direct access over xGMI where the topology has it (the copy works either way)
-        int can = 0;
-        if (hipDeviceCanAccessPeer(&can, c->device, root->device) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(root->device, 0);
-        (void)hipGetLastError();  // "already enabled" is fine
-        c->peer_enabled |= 1ull << (root->device & 63);
-      }
-      RM_HIP(root, hipMemcpyPeerAsync(dst, root->device, c->shard_rows, c->device, bytes, c->stream));
+    RM_HIP(root, hipEventRecord(c->shard_snap, c->stream));
+    RM_HIP(root, hipStreamWaitEvent(c->shard_stream, c->shard_snap, 0));
+  }
+  // 2. everything else travels on the contexts' present streams, beside the renders
+  if (dof) {
+    // all-gather: every context's packed rows to every context (display.frag:44-55 reads up to 16 rows either side of a pixel, and with
+    // 8-row stripes those are other GPUs' rows) ...
+    for (int p = 0; p < parts; p++) {
+      rm_ctx* c = ctxs[p];
+      RM_HIP(root, hipSetDevice(c->device));
+      for (int q = 0; q < parts; q++)
+        if (int rc = shard_copy(root, c, ctxs[q], static_cast<char*>(ctxs[q]->shard_all) + part32 * (size_t)p, c->shard_rows, (size_t)fbs[p]->row_count * (size_t)W * sizeof(float4), c->shard_stream)) return rc;
+      RM_HIP(root, hipEventRecord(c->shard_ev, c->shard_stream));
     }
-    RM_HIP(root, hipEventRecord(c->shard_ev, c->stream));
+    // ... then every context puts the frame in image order, blurs and tone-maps ITS stripes (1 / parts of the pass each) and sends
+    // the bytes to the root
+    for (int q = 0; q < parts; q++) {
+      rm_ctx* c = ctxs[q];
+      RM_HIP(root, hipSetDevice(c->device));
+      for (int p = 0; p < parts; p++) RM_HIP(root, hipStreamWaitEvent(c->shard_stream, ctxs[p]->shard_ev, 0));
+      RM_HIP(root, rm::launch_assemble(c->shard_all, parts, max_rows, (long long)W * (long long)sizeof(float4), H, stripe, c->shard_frame, c->shard_stream));
+      RM_HIP(root, (c->gl_stack ? rm_gl_launch_present_striped : rm::launch_present_striped)(static_cast<const float4*>(c->shard_frame), static_cast<const float4*>(c->shard_frame), W, H,
+                                                                                                1.0f / (float)samples, static_cast<uchar4*>(c->shard_rows8), stripe, parts, q,
+                                                                                                fbs[q]->row_count, c->shard_stream));
+    }
+    for (int q = 0; q < parts; q++) {
+      rm_ctx* c = ctxs[q];
+      RM_HIP(root, hipSetDevice(c->device));
+      if (int rc = shard_copy(root, c, root, static_cast<char*>(root->shard_recv) + part8 * (size_t)q, c->shard_rows8, (size_t)fbs[q]->row_count * (size_t)W * sizeof(uchar4), c->shard_stream)) return rc;
+      RM_HIP(root, hipEventRecord(c->shard_ev, c->shard_stream));  // (the root waited for the first record above; this one is the next in stream order)
+    }
+  } else {
+    for (int p = 0; p < parts; p++) {
+      rm_ctx* c = ctxs[p];
+      RM_HIP(root, hipSetDevice(c->device));
+      if (int rc = shard_copy(root, c, root, static_cast<char*>(root->shard_recv) + part8 * (size_t)p, c->shard_rows, (size_t)fbs[p]->row_count * (size_t)W * sizeof(uchar4), c->shard_stream)) return rc;
+      RM_HIP(root, hipEventRecord(c->shard_ev, c->shard_stream));
+    }
   }
+  // 3. the root puts the bytes in image order and brings the canvas to the host (pinned: the copy is asynchronous)
   RM_HIP(root, hipSetDevice(root->device));
-  for (int p = 0; p < parts; p++) RM_HIP(root, hipStreamWaitEvent(root->stream, ctxs[p]->shard_ev, 0));
-  RM_HIP(root, rm::launch_assemble(root->shard_recv, parts, max_rows, (long long)row_bytes, H, stripe, root->shard_frame, root->stream));
-  if (!dof) {
-    RM_HIP(root, hipMemcpyAsync(out_rgba8, root->shard_frame, (size_t)H * row_bytes, hipMemcpyDeviceToHost, root->stream));
-    RM_HIP(root, hipStreamSynchronize(root->stream));
-    return RM_OK;
-  }
-  // the assembled (colour.rgb, DoF radius) buffer is both planes of the present pass
-  return rm_present_planes(root, root->shard_frame, root->shard_frame, W, H, samples, out_rgba8);
+  for (int p = 0; p < parts; p++) RM_HIP(root, hipStreamWaitEvent(root->shard_stream, ctxs[p]->shard_ev, 0));
+  RM_HIP(root, rm::launch_assemble(root->shard_recv, parts, max_rows, (long long)W * (long long)sizeof(uchar4), H, stripe, root->shard_canvas, root->shard_stream));
+  RM_HIP(root, hipMemcpyAsync(root->shard_host, root->shard_canvas, canvas_bytes, hipMemcpyDeviceToHost, root->shard_stream));
+  RM_HIP(root, hipEventRecord(root->shard_done, root->shard_stream));
+  root->shard_pending = true;
+  root->shard_w = W;
+  root->shard_h = H;
+  return RM_OK;
+}
+
+int rm_present_sharded_finish(rm_ctx* const* ctxs, int parts, uint8_t* out_rgba8) {
+  rm_ctx* root = (ctxs && parts >= 1) ? ctxs[0] : nullptr;
+  if (!root || !out_rgba8) return fail(root, RM_ERR_INVALID, "rm_present_sharded_finish: NULL argument");
+  if (!root->shard_pending) return fail(root, RM_ERR_INVALID, "rm_present_sharded_finish: no present was started");
+  root->shard_pending = false;
+  RM_HIP(root, hipSetDevice(root->device));
+  RM_HIP(root, hipEventSynchronize(root->shard_done));  // the present's own work only: the renders enqueued since go on
+  std::memcpy(out_rgba8, root->shard_host, (size_t)root->shard_h * (size_t)root->shard_w * sizeof(uchar4));
+  return RM_OK;
+}
+
+int rm_present_sharded(rm_ctx* const* ctxs, rm_fb* const* fbs, int parts, int samples, int dof, uint8_t* out_rgba8) {
+  if (!out_rgba8) return fail((ctxs && parts >= 1) ? ctxs[0] : nullptr, RM_ERR_INVALID, "rm_present_sharded: NULL argument");
+  if (int rc = rm_present_sharded_start(ctxs, fbs, parts, samples, dof)) return rc;
+  return rm_present_sharded_finish(ctxs, parts, out_rgba8);
 }
 
 // ---- probes ----------------------------------------------------------------------
 
 int rm_probe(rm_ctx* ctx, rm_scene* scene, int what, const float* in, int n, float param, int flags, float* out) {
   if (!ctx || !scene || !in || !out) return fail(ctx, RM_ERR_INVALID, "rm_probe: NULL argument");
-  if (what < RM_PROBE_SDF || what > RM_PROBE_CAST_STEPS) return fail(ctx, RM_ERR_INVALID, "rm_probe: unknown probe");
+  if (what < RM_PROBE_SDF || what > RM_PROBE_CAST_SHADOW) return fail(ctx, RM_ERR_INVALID, "rm_probe: unknown probe");
   if (n <= 0) return RM_OK;
-  static const int in_w[5] = {3, 6, 3, 3, 6}, out_w[5] = {1, 3, 3, 12, 1};
+  static const int in_w[6] = {3, 6, 3, 3, 6, 9}, out_w[6] = {1, 3, 3, 12, 1, 1};
   RM_HIP(ctx, hipSetDevice(ctx->device));
   float *d_in = nullptr, *d_out = nullptr;
   const size_t in_bytes = sizeof(float) * (size_t)in_w[what] * (size_t)n, out_bytes = sizeof(float) * (size_t)out_w[what] * (size_t)n;

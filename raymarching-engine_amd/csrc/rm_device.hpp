@@ -340,6 +340,12 @@ template <class M> RM_DEV float op_smooth_union(float d1, float d2, float k) {
 template <int KIND>
 struct Sdf;
 
+// The exact far-field exits of the march -- the jump, the miss, the clear miss, the shadow ray's certain comparison -- are arguments
+// about the scene's distance bound with a 1e-3 rounding allowance per product: they do not depend on the arithmetic policy, and
+// since round 4 the parity build takes them too (round 3 compiled them into the fast build only).  Not the GL stack's arithmetic:
+// its min / max keep a NaN where IEEE's drop it, which the end states lean on.
+template <class M> struct ExactExits { static constexpr bool value = !RM_GL_STACK; };
+
 // Steps an escaping ray needs at most to reach its end state when its distance estimate is bounded below by |p| - R' (the
 // bounded scenes: tables, the sponge, the rotation fractal, the sphere-grid fractal; far_r2 = (2 R' + 1)^2 >= 1): the worst case of
 // the recurrence (r^2, s) -> (r^2 + 2 d s + d^2 |dir|^2, s + d |dir|^2), d = r - R', started at a right angle with |dir|^2 = 0.98
@@ -812,14 +818,21 @@ struct Sdf<RM_SCENE_MANDELBULB> {
   // rounding; 1 sqrt + 1 rsq per iteration instead of 12 transcendentals.
   // x^2 + y^2 of a round, plus 1e-30 (the same float unless it is below 1e-23): see pow8_round
   static RM_DEV float pow8_rho2(v3 z) { return FM::fma(z.y, z.y, FM::fma(z.x, z.x, 1e-30f)); }
+  // One round z -> z^8 + pos, dr -> 8 r^7 dr + 1.
+  // 2 transcendentals and 29 other instructions per round (it was 40 before the output modifiers).
+  // r = sqrt(r2) and q = 1/rho = rsq(rho2); rho = rho2 * q.
+  // (z.z + i rho)^8 = r^8 (cos 8theta + i sin 8theta) =: A + iB is taken as it stands; the azimuth comes from the
+  // UNIT vector (z.x + i z.y) / rho, whose 8th power is cos 8phi + i sin 8phi =: C + iD with no rho^8 to divide
+  // out again.  On the axis x = y = 0 and rsq(0) = Inf would turn 0 * q into NaN: rho2 carries 1e-30 (pow8_rho2,
+  // folded into its first fma), so there q is finite, C + iD = 0 and B = 0 anyway (sin 8theta = 0), and the new z
+  // is (pos.x, pos.y, A + pos.z) as it should be.
+  // (Round 4, tried: the whole round as ONE hand-scheduled asm statement.  hipcc's hazard recogniser assumes that the result of an asm
+  // statement may be forwarded like an SDWA / op_sel write and puts an `s_nop 0` before an instruction that reads one straight away:
+  // four per round with the one-instruction statements below, 530 in the headline kernel; a VOP3 output modifier has no such hazard.
+  // One statement per round leaves one s_nop and 2 % fewer VALU instructions -- and the headline frame 6 % SLOWER, 1.93 against
+  // 1.82 ms, with the two transcendentals next to each other or four instructions apart: the no-ops are not what the round waits
+  // for, and the compiler's interleaving of the round with the code around it is worth more than they cost.  Not kept.)
   static RM_DEV void pow8_round(v3& z, float& dr, v3 pos, float rho2, float r2) {
-    // 2 transcendentals and 29 other instructions per round (it was 40 before the output modifiers).
-    // r = sqrt(r2) and q = 1/rho = rsq(rho2); rho = rho2 * q.
-    // (z.z + i rho)^8 = r^8 (cos 8theta + i sin 8theta) =: A + iB is taken as it stands; the azimuth comes from the
-    // UNIT vector (z.x + i z.y) / rho, whose 8th power is cos 8phi + i sin 8phi =: C + iD with no rho^8 to divide
-    // out again.  On the axis x = y = 0 and rsq(0) = Inf would turn 0 * q into NaN: rho2 carries 1e-30 (pow8_rho2,
-    // folded into its first fma), so there q is finite, C + iD = 0 and B = 0 anyway (sin 8theta = 0), and the new z
-    // is (pos.x, pos.y, A + pos.z) as it should be.
     const float r = FM::sqrt(r2);
     const float q = __builtin_amdgcn_rsqf(rho2);
     const float rho = rho2 * q;
@@ -838,6 +851,14 @@ struct Sdf<RM_SCENE_MANDELBULB> {
     // was 2.80 ms against 2.69 on the headline frame: a packed instruction takes two issue slots of a busy SIMD.)
     z = V(FM::fma(B, C, pos.x), FM::fma(B, D, pos.y), A + pos.z);
   }
+  // ... and the NEXT round's rho2 and r2
+  static RM_DEV void pow8_round_next(v3& z, float& dr, v3 pos, float& rho2, float& r2) {
+    pow8_round(z, dr, pos, rho2, r2);
+    rho2 = pow8_rho2(z);
+    r2 = FM::fma(z.z, z.z, rho2);
+  }
+  // the last of a fixed number of rounds: only its dr is read
+  static RM_DEV float pow8_round_dr(float dr, float r2) { return FM::fma_x2(FM::mul_x4((r2 * r2) * r2, FM::sqrt(r2)), dr, 0.5f); }
   // 0.5 log(r) r / dr with r = sqrt(r2): log2(r2) and sqrt(r2) both start from r2 (no chain through r), and the
   // constants fold: 0.5 * ln 2 * 0.5 = 0.17328680
   // (Tried: skipping the reciprocal in waves whose lanes all bailed out before the first round -- dr = 1 everywhere,
@@ -861,42 +882,46 @@ struct Sdf<RM_SCENE_MANDELBULB> {
   template <int ITERS>
   static RM_DEV float eval_pow8_n(const DevScene& sc, v3 pos) {
     const float bail2 = sc.p[RM_P_BULB_BAILOUT] * sc.p[RM_P_BULB_BAILOUT];
-    v3 z = pos;
-    float dr = 1.0f;
-    float rho2 = pow8_rho2(z);
-    float r2 = FM::fma(z.z, z.z, rho2);
-    const int iterations = ITERS == 8 ? 8 : (int)sc.p[RM_P_BULB_ITERATIONS];
-    if (ITERS != 8 && iterations < 1) return pow8_distance(0.0f, 1.0f);  // no round at all: r stays 0 (as in eval_generic)
-#ifdef RM_LANE_STATS
-    int rounds = 0;
-#endif
+    const float rho2 = pow8_rho2(pos);
+    const float r2 = FM::fma(pos.z, pos.z, rho2);
+    if (ITERS != 8 && (int)sc.p[RM_P_BULB_ITERATIONS] < 1) return pow8_distance(0.0f, 1.0f);  // no round at all: r stays 0 (as in eval_generic)
     if (r2 > bail2) {  // the far field: no round, dr = 1
 #ifdef RM_LANE_STATS
-      lane_stats(rounds);
+      lane_stats(0);
 #endif
       return pow8_distance_far(r2);
     }
-    pow8_round(z, dr, pos, rho2, r2);
+    return pow8_near<ITERS>(sc, pos, rho2, r2, bail2);
+  }
+  // the rounds of a point inside the bailout sphere (at least one), and its distance
+  template <int ITERS>
+  static RM_DEV float pow8_near(const DevScene& sc, v3 pos, float rho2, float r2, float bail2) {
+    v3 z = pos;
+    float dr = 1.0f;
+    const int iterations = ITERS == 8 ? 8 : (int)sc.p[RM_P_BULB_ITERATIONS];
+#ifdef RM_LANE_STATS
+    int rounds = 0;
+#endif
+    if (ITERS != 8 && iterations == 1) return pow8_distance(r2, pow8_round_dr(dr, r2));  // (the distance reads the r2 its last round started from)
+    pow8_round_next(z, dr, pos, rho2, r2);
 #ifdef RM_LANE_STATS
     rounds++;
 #endif
     if (ITERS == 8) {
 #pragma unroll
       for (int i = 1; i < 8; i++) {
-        rho2 = pow8_rho2(z);
-        r2 = FM::fma(z.z, z.z, rho2);
         if (r2 > bail2) break;
-        pow8_round(z, dr, pos, rho2, r2);
+        if (i == 7) dr = pow8_round_dr(dr, r2);  // (what the compiler's dead-code elimination left of the C++ round)
+        else pow8_round_next(z, dr, pos, rho2, r2);
 #ifdef RM_LANE_STATS
         rounds++;
 #endif
       }
     } else {
       for (int i = 1; i < iterations; i++) {
-        rho2 = pow8_rho2(z);
-        r2 = FM::fma(z.z, z.z, rho2);
         if (r2 > bail2) break;
-        pow8_round(z, dr, pos, rho2, r2);
+        if (i == iterations - 1) dr = pow8_round_dr(dr, r2);
+        else pow8_round_next(z, dr, pos, rho2, r2);
       }
     }
 #ifdef RM_LANE_STATS
@@ -943,10 +968,16 @@ struct Sdf<RM_SCENE_MANDELBULB> {
   // frame against RM_RENDER_NO_FAR_JUMP); both implementations jump (cast_ray / cast_ray_block, wf_march) and stay bit-identical.
   // (from r = 100 the overflow takes 18 steps, from 1e6 12: the rays a bounce starts a million units out -- :279 -- qualify with 16 left)
   static constexpr int far_jump_steps = 30;
-  static RM_DEV bool far_jump_applies(const DevScene& sc) { return sc.p[RM_P_BULB_POWER] == 8.0f && sc.p[RM_P_BULB_ITERATIONS] >= 1.0f; }
+  // (Round 4: any power.  Outside the bailout sphere no round runs, so the estimate is 0.5 ln(r) r whatever the power, in eval_generic
+  // on either policy as in the power-8 form.  The generic evaluation compares r = sqrt(x^2 + y^2 + z^2) with the bailout in its own
+  // rounding, so there the jump asks for 0.1 % more than the bailout sphere: the evaluations it replaces are certain to be far ones.)
+  static RM_DEV bool far_jump_applies(const DevScene& sc) { return sc.p[RM_P_BULB_ITERATIONS] >= 1.0f && sc.p[RM_P_BULB_BAILOUT] >= 0.0f; }
   static RM_DEV bool far_jump(const DevScene& sc, v3 p, v3 dir, int left, v3& end) {
     const float bail2 = sc.p[RM_P_BULB_BAILOUT] * sc.p[RM_P_BULB_BAILOUT];
-    const float r2 = FM::fma(p.z, p.z, pow8_rho2(p));  // what the evaluation starts with
+    const float r2 = FM::fma(p.z, p.z, pow8_rho2(p));  // what the power-8 evaluation starts with
+    return far_jump_at(p, dir, left, r2, RM_BUILD_FAST && sc.p[RM_P_BULB_POWER] == 8.0f ? bail2 : 1.001f * bail2, end);
+  }
+  static RM_DEV bool far_jump_at(v3 p, v3 dir, int left, float r2, float bail2, v3& end) {
     if (!(r2 > gmax(bail2, 4.0f) && r2 < 1e30f) || left < (r2 >= 1e12f ? 16 : (r2 >= 1e4f ? 22 : far_jump_steps))) return false;
     const float s = dot<FM>(p, dir), dd = dot<FM>(dir, dir);
     if (!(s >= 0.0f && dd > 0.98f && dd < 1.02f)) return false;
@@ -954,6 +985,27 @@ struct Sdf<RM_SCENE_MANDELBULB> {
     if (e.x != e.x || e.y != e.y || e.z != e.z) e = V(e.x + e.y + e.z, e.x + e.y + e.z, e.x + e.y + e.z);
     end = e;
     return true;
+  }
+  // One step's evaluation with the jump's test inside it (round 4; the block march of the pixel kernel): the jump can only apply
+  // where the evaluation takes its far branch (r2 > bail2), so a ray inside the bailout sphere -- most steps of the rays that show
+  // the fractal -- does not compute r2 twice and does not see the test at all.  The same decisions on the same values as
+  // far_jump() followed by eval(): true and `end`, or false and `d`.
+  template <int ITERS>
+  static RM_DEV bool pow8_eval_or_jump(const DevScene& sc, v3 p, v3 dir, int left, bool jump, float& d, v3& end) {
+    const float bail2 = sc.p[RM_P_BULB_BAILOUT] * sc.p[RM_P_BULB_BAILOUT];
+    const float rho2 = pow8_rho2(p);
+    const float r2 = FM::fma(p.z, p.z, rho2);
+    if (ITERS != 8 && (int)sc.p[RM_P_BULB_ITERATIONS] < 1) { d = pow8_distance(0.0f, 1.0f); return false; }  // (far_jump_applies: never with jump)
+    if (r2 > bail2) {
+      if (jump && far_jump_at(p, dir, left, r2, bail2, end)) return true;
+#ifdef RM_LANE_STATS
+      lane_stats(0);
+#endif
+      d = pow8_distance_far(r2);
+      return false;
+    }
+    d = pow8_near<ITERS>(sc, p, rho2, r2, bail2);
+    return false;
   }
 
   // Cost classes.  The evaluation runs 0..`iterations` rounds of z -> z^n + c
@@ -1012,6 +1064,10 @@ struct Sdf<RM_KIND_BULB8> : Sdf<RM_SCENE_MANDELBULB> {
   template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds&, v3 p) { return eval_pow8_n<8>(sc, p); }
   static RM_DEV bool far_jump_applies(const DevScene&) { return true; }
+  template <class M>
+  static RM_DEV bool eval_or_jump(const DevScene& sc, const SceneLds&, v3 p, v3 dir, int left, bool jump, float& d, v3& end) {
+    return pow8_eval_or_jump<8>(sc, p, dir, left, jump, d, end);
+  }
 };
 
 // A primitive table of many rows in full mode (rm_params.hpp rm_table_big): the same program as RM_SCENE_TABLE in a pixel kernel
@@ -1049,6 +1105,11 @@ template <> struct FarJump<RM_KIND_TABLE_SMOOTH> { static constexpr bool value =
 template <> struct FarJump<RM_SCENE_MENGER> { static constexpr bool value = true; };
 template <> struct FarJump<RM_SCENE_KIFS_BOX> { static constexpr bool value = true; };
 template <> struct FarJump<RM_SCENE_SPHERE_GRID> { static constexpr bool value = true; };
+
+// kinds whose evaluation carries the jump's test itself (Sdf<KIND>::eval_or_jump; the generic Mandelbulb kernel only at power 8:
+// far_jump_applies says so, and then eval() is the power-8 evaluation)
+template <int KIND> struct FusedJump { static constexpr bool value = false; };
+template <> struct FusedJump<RM_KIND_BULB8> { static constexpr bool value = true; };
 
 // kernels that may evaluate the power-8 Mandelbulb on the fast policy start with this (FM::omod_mode)
 template <int KIND, bool FAST> RM_DEV void enter_math_mode() {
@@ -1169,7 +1230,7 @@ struct Sdf<RM_SCENE_KIFS_TREE> {
     const float* tab = reinterpret_cast<const float*>(lds.rows);
     const float iters = sc.p[RM_P_KIFS_ITERATIONS], scale = sc.p[RM_P_KIFS_SCALE], offset = sc.p[RM_P_KIFS_OFFSET];
     const bool smoothen = sc.p[RM_P_KIFS_SMOOTH] == 1.0f;
-    if (M::fast && sc.far_end == 3) {  // beyond |p| = 9999 + R' the estimate is its starting value (rm_api.hip kifs_far_field): the same bits
+    if (ExactExits<M>::value && sc.far_end == 3) {  // beyond |p| = 9999 + R' the estimate is its starting value (rm_api.hip kifs_far_field): the same bits
       const float r2 = FM::fma(p.z, p.z, FM::fma(p.y, p.y, p.x * p.x));
       if (r2 > sc.far_r2 && r2 < 1e14f) return 9999.0f;
     }

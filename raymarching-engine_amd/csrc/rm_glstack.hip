@@ -22,6 +22,10 @@ hipError_t rm_gl_launch_camera_rng(const RmUniforms* u, int W, int H, int what, 
 hipError_t rm_gl_launch_present(const float4* color, const float4* normal_dof, int W, int H, float brightness, uchar4* out, hipStream_t stream) {
   return rm_gl::launch_present(color, normal_dof, W, H, brightness, out, stream);
 }
+hipError_t rm_gl_launch_present_striped(const float4* color, const float4* normal_dof, int W, int H, float brightness, uchar4* out, int stripe_rows, int parts,
+                                        int part, int local_rows, hipStream_t stream) {
+  return rm_gl::launch_present_striped(color, normal_dof, W, H, brightness, out, stripe_rows, parts, part, local_rows, stream);
+}
 hipError_t rm_gl_set_native_tan(int on, hipStream_t) {  // synchronous: the source is the caller's stack
   return hipMemcpyToSymbol(HIP_SYMBOL(rm_gl::g_native_tan), &on, sizeof on, 0, hipMemcpyHostToDevice);
 }

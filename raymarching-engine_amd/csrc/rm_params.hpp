@@ -227,6 +227,8 @@ hipError_t launch_assemble(const void* src, int parts, int max_rows, long long r
 hipError_t launch_pack_rows(const float4* color, const float4* normal_dof, long long pixels, float4* out, hipStream_t stream);
 hipError_t launch_present_rows(const float4* color, long long pixels, float brightness, uchar4* out, hipStream_t stream);
 hipError_t launch_present(const float4* color, const float4* normal_dof, int W, int H, float brightness, uchar4* out, hipStream_t stream);
+hipError_t launch_present_striped(const float4* color, const float4* normal_dof, int W, int H, float brightness, uchar4* out, int stripe_rows, int parts, int part,
+                                  int local_rows, hipStream_t stream);
 hipError_t wf_launch_stage(const WfParams& W, int stage, hipStream_t stream);
 hipError_t launch_pixels_strict(const KParams& P, hipStream_t stream);
 hipError_t launch_pixels_fast(const KParams& P, hipStream_t stream);

@@ -14,14 +14,17 @@ textures to the canvas (index.tsx:25-59, display.frag:16-64).  Three payloads:
   per presented frame.
 * "f32dof" -- jobs WITH depth of field.  The blur reads up to 16 rows either side
   of a pixel; with 8-row stripes those rows live on other GPUs (a halo would be
-  four stripes each way, i.e. most of the frame), so the present pass runs where
-  the whole frame is: every rank packs what display.frag reads of its rows --
-  (colour.rgb, normalAndDofRadius.w), one float4 per pixel, rm_pack_present_rows --
-  the rows are gathered and put in image order, and rank 0 runs rm_present_device
-  on the assembled buffer, which serves as both of its input planes.  16 bytes per
-  pixel: 133 MB per presented 4K frame, 116 MB into rank 0 at 8 GPUs over seven
-  xGMI links (~0.11 ms at 153 GB/s each, overlapped with the next samples); the
-  bytes are those of rm_present on the unsharded frame.
+  four stripes each way, i.e. most of the frame).  Round 3 gathered the packed
+  rows -- (colour.rgb, normalAndDofRadius.w), one float4 per pixel,
+  rm_pack_present_rows -- to rank 0 and let rank 0 blur the whole frame alone:
+  correct, and serial (18 ms per present at the 16-pixel cap on 4K, ~145 ms at
+  8192^2 against a 20 ms shard step).  Since round 4 the packed rows go to EVERY
+  rank (all-gather: 16 bytes per pixel into each GPU over its seven links, 1 GB at
+  8192^2 = ~1 ms), every rank puts the frame in image order and blurs and
+  tone-maps the stripes IT holds (rm_present_striped_rows: 1 / N of the pass),
+  and the RGBA8 rows are gathered to rank 0 like those of a job without depth of
+  field.  The all-gather travels while the next samples render; the bytes are
+  those of rm_present on the unsharded frame.
 * "f32" -- the accumulated colour plane itself, for hosts that want the radiance.
 
 The fp32 planes never move otherwise: they stay where they are accumulated.
@@ -61,7 +64,7 @@ class FrameGatherer:
 
     def __init__(self, height: int, width: int, world: int, rank: int, device, dst: int = 0, channels: int = 4,
                  stripe_rows: int = shard.STRIPE_ROWS, force: bool = False, ctx=None, payload: str = "f32", side_stream: bool = False,
-                 render_stream: Optional[int] = None):
+                 render_stream: Optional[int] = None, to_all: bool = False):
         import torch
 
         assert payload in self.PAYLOADS
@@ -69,6 +72,7 @@ class FrameGatherer:
         self.height, self.width, self.world, self.rank, self.dst = height, width, world, rank, dst
         self.stripe_rows = stripe_rows
         self.force = force  # run the collective even with one rank (testing aid)
+        self.to_all = to_all  # all-gather: EVERY rank receives every part and assembles the frame (the depth-of-field present)
         self.payload = payload
         self.dtype = torch.uint8 if payload == "rgba8" else torch.float32
         self.channels = channels if payload == "f32" else 4
@@ -89,7 +93,7 @@ class FrameGatherer:
         self.device = torch.device(device)
         self.shape = (self.max_rows, width, self.channels)
         self.collective = world > 1 or force  # otherwise nothing is gathered and nothing is allocated
-        if rank == dst and self.collective:
+        if (rank == dst or to_all) and self.collective:
             self.recv_all = torch.empty((world,) + self.shape, dtype=self.dtype, device=device)
             self.recv = [self.recv_all[p] for p in range(world)]  # gather's output list: views of one buffer
             self.frame = torch.empty((height, width, self.channels), dtype=self.dtype, device=device)
@@ -98,6 +102,16 @@ class FrameGatherer:
             self.aux = torch.cuda.Stream(device=device) if side_stream else None
             self.snaps = [torch.zeros(self.shape, dtype=self.dtype, device=device) for _ in range(2)]
             self.snap_free = [None, None]  # events: the collective that sent snaps[k] is done
+
+    @property
+    def receives(self) -> bool:
+        return self.to_all or self.rank == self.dst
+
+    def _collect(self, dist, send, recv):
+        """the collective: gather to dst, or all-gather (to_all); asynchronous"""
+        if self.to_all:
+            return dist.all_gather(recv, send, async_op=True)
+        return dist.gather(send, recv if self.rank == self.dst else None, dst=self.dst, async_op=True)
 
     @property
     def row_bytes(self) -> int:
@@ -143,22 +157,22 @@ class FrameGatherer:
             if dist.get_backend() == "gloo":
                 # testing aid (several ranks sharing ONE GPU cannot use RCCL): the rows travel through host memory
                 host = snap.cpu()
-                recv_host = [torch.empty_like(host) for _ in range(self.world)] if self.rank == self.dst else None
-                work = dist.gather(host, recv_host, dst=self.dst, async_op=True)
+                recv_host = [torch.empty_like(host) for _ in range(self.world)] if self.receives else None
+                work = self._collect(dist, host, recv_host)
                 self.pending = (work, k, recv_host)
                 return self.pending
             with torch.cuda.stream(self.aux if self.aux is not None else cur):
-                work = dist.gather(snap, self.recv if self.rank == self.dst else None, dst=self.dst, async_op=True)
+                work = self._collect(dist, snap, self.recv)
             self.pending = (work, k)
         else:  # CPU (gloo)
             snap = torch.empty(self.shape, dtype=self.dtype)
             fill(snap, None)
-            work = dist.gather(snap, self.recv if self.rank == self.dst else None, dst=self.dst, async_op=True)
+            work = self._collect(dist, snap, self.recv)
             self.pending = (work, snap)
         return self.pending
 
     def finish(self, handle=None):
-        """Wait for start()'s gather and put the stripes in image order (on dst; None elsewhere).  On a GPU the
+        """Wait for start()'s gather and put the stripes in image order (on dst -- on every rank with to_all; None elsewhere).  On a GPU the
         returned frame is ordered on the stream the gatherer works on (self.stream(): the current stream, or aux)."""
         if not self.collective:
             return handle
@@ -177,11 +191,11 @@ class FrameGatherer:
                 ev = torch.cuda.Event()
                 ev.record(on)
                 self.snap_free[k] = ev
-                if self.rank == self.dst:
+                if self.receives:
                     self._assemble(on.cuda_stream)
             return self.frame
         work.wait()
-        return self._assemble() if self.rank == self.dst else None
+        return self._assemble() if self.receives else None
 
     def stream(self):
         """The stream the collective and the assembly are ordered on."""
@@ -256,7 +270,6 @@ class ShardedFramebuffer:
         self.dof = False  # does the job that renders into this framebuffer have depth of field (set by do_render_job)
         self._gatherers = {}
         self._pending = None  # (gatherer, samples) of the present in flight
-        self._canvas = None   # rank 0: the device tensor the f32dof present writes
 
     # what the render calls and the framebuffer cache of job.RenderJobContext use
     @property
@@ -278,7 +291,7 @@ class ShardedFramebuffer:
         if g is None:
             gr = self.group
             g = FrameGatherer(self.height, self.width, gr.world, gr.rank, gr.device, stripe_rows=gr.stripe_rows, force=gr.force,
-                              ctx=self.ctx, payload=payload, render_stream=self.render_stream)
+                              ctx=self.ctx, payload=payload, render_stream=self.render_stream, to_all=payload == "f32dof")
             assert g.rows == self.row_count
             self._gatherers[payload] = g
         return g
@@ -298,17 +311,17 @@ class ShardedFramebuffer:
         g, samples = self._pending
         self._pending = None
         frame = g.finish()
-        if self.group.rank != g.dst:
-            return None
         if g.payload == "rgba8":
-            return frame
-        torch = self.torch
-        if self._canvas is None:
-            self._canvas = torch.empty((self.height, self.width, 4), dtype=torch.uint8, device=frame.device)
-        stream = g.stream().cuda_stream if frame.is_cuda else None
-        # the assembled (colour.rgb, dofRadius) buffer is both planes of the present pass (display.frag reads .rgb of one, .w of the other)
-        self.ctx.present_device(frame.data_ptr(), frame.data_ptr(), self.width, self.height, samples, self._canvas.data_ptr(), stream)
-        return self._canvas
+            return frame if self.group.rank == g.dst else None
+        # depth of field: every rank holds the packed frame now (the all-gather) and runs the present pass for ITS stripes -- the
+        # assembled (colour.rgb, dofRadius) buffer is both of its planes (display.frag reads .rgb of one, .w of the other) --
+        # straight into the snapshot of an RGBA8 gather, which then is the one of a job without depth of field
+        gr = self.group
+        g8 = self.gatherer("rgba8")
+        g8.start(None, gr.dist, fill=lambda snap, stream: self.ctx.present_striped_rows(frame.data_ptr(), frame.data_ptr(), self.width, self.height, samples,
+                                                                                        gr.stripe_rows, gr.world, gr.rank, snap.data_ptr(), stream))
+        canvas = g8.finish()
+        return canvas if gr.rank == g8.dst else None
 
     def present(self, samples: int, dof: Optional[bool] = None):
         self.start_present(samples, dof)

@@ -62,6 +62,8 @@ export class RenderJobContext {
 export type ShardedFramebufferInfo = {
   width: number; height: number; frameid: number; sharded: true; dof: boolean; rows(): number[];
   present(samples: number, dof?: boolean): Uint8Array; toDataURL(samples: number): string;
+  /** the present in two halves (rm_present_sharded_start / _finish): the frame travels while the next samples render; one at a time */
+  startPresent(samples: number, dof?: boolean): void; finishPresent(): Uint8Array; pendingPresent: boolean;
 };
 export class ShardedRenderJobContext {
   constructor(devices?: number[], flags?: number, samplesInFlight?: number);

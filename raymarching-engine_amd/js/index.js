@@ -293,6 +293,12 @@ class ShardedRenderJobContext {
                    rows: () => fbs.map((fb) => addon.fbRows(fb)),
                    // the canvas of the assembled frame (display.frag, with its blur when the job has depth of field): RGBA8, row 0 = bottom
                    present: (samples, dof = info.dof) => { const out = new Uint8Array(w * h * 4); addon.presentSharded(this.ctxs, fbs, samples, !!dof, out); return out; },
+                   // the same in two halves (rm_present_sharded_start / _finish): startPresent snapshots and sends and returns at once, so a
+                   // `present` callback that calls it lets doRenderJob hand out the next samples while the frame travels; finishPresent
+                   // (at the next callback, or whenever the canvas is wanted) returns the canvas of THAT present.  One at a time.
+                   startPresent: (samples, dof = info.dof) => { addon.presentShardedStart(this.ctxs, fbs, samples, !!dof); info.pendingPresent = true; },
+                   finishPresent: () => { const out = new Uint8Array(w * h * 4); addon.presentShardedFinish(this.ctxs, out); info.pendingPresent = false; return out; },
+                   pendingPresent: false,
                    toDataURL: (samples) => "data:image/png;base64," + encodePng(info.present(samples), w, h).toString("base64") };
     this.live.set(key, info);
     return info;
@@ -327,7 +333,10 @@ async function doRenderJob(schema, context) {  // RenderJobExecutor.tsx:77
   const fbs = framebuffers.sharded ? framebuffers.fbs : [framebuffers.fb];
   const scenes = framebuffers.sharded ? scene.handles : [scene];
   if (framebuffers.sharded) framebuffers.dof = schema.dof.amount !== 0;  // what a present gathers (rm_present_sharded)
-  const syncAll = () => { for (const c of ctxs) addon.sync(c); };
+  // (a sharded set's present is ordered on the contexts' streams behind the samples: no host-side wait before it, so that a
+  // callback using startPresent overlaps the travelling frame with the next samples; the single context waits as it always did)
+  const syncAll = () => { if (!framebuffers.sharded) for (const c of ctxs) addon.sync(c); };
+  const syncEnd = () => { for (const c of ctxs) addon.sync(c); };
   return function* (present) {
     for (let yp = 0; yp < r.subdivisions; yp++) for (let xp = 0; xp < r.subdivisions; xp++) {
       const tile = tileRect(schema, xp, yp);
@@ -346,7 +355,7 @@ async function doRenderJob(schema, context) {  // RenderJobExecutor.tsx:77
       }
     }
     context.fboDelete(r.width, r.height, r.frameid);
-    syncAll();
+    syncEnd();  // the job's last word: an asynchronous failure becomes this call's exception (the caller's {success: false})
     present(schema, context, framebuffers, samples);
     return { success: true };
   };

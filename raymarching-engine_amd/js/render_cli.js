@@ -106,7 +106,22 @@ const rm = require("./index.js");
       const b = await run(many);
       const rows = many.fboCreate(96, 52, sch.render.frameid).rows();
       many.close();
-      result[name] = { one: a, many: b, rows };
+      // the present in two halves: the callback starts frame k and collects frame k - 1 (which travelled while the samples between
+      // the two callbacks rendered); the last one is collected after the job
+      const lapped = new rm.ShardedRenderJobContext(new Array(n).fill(0), rm.RM.RENDER_STRICT);
+      rm.resetHalton();
+      const shown = [];
+      let last = 0, set = null;
+      const gen = (await rm.doRenderJob(sch, lapped))((s, c, fb, k) => {
+        if (k === 0) return;
+        if (fb.pendingPresent) shown.push([last, Buffer.from(fb.finishPresent()).toString("base64")]);
+        fb.startPresent(k); last = k; set = fb;
+      });
+      let it = gen.next();
+      while (!it.done) it = gen.next();
+      shown.push([last, Buffer.from(set.finishPresent()).toString("base64")]);
+      lapped.close();
+      result[name] = { one: a, many: b, lapped: { res: it.value, shown }, rows };
     }
     fs.writeFileSync(out, JSON.stringify(result));
     return;

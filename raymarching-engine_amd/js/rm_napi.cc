@@ -295,49 +295,73 @@ static napi_value SetSamplesInFlight(napi_env env, napi_callback_info info) {
   return nullptr;
 }
 
-// presentSharded(ctxs: ctx[], fbs: fb[], samples, dof: boolean, out: Uint8Array(width * height * 4)) = rm_present_sharded:
-// the canvas of a frame whose stripes this process renders on several GPUs (part p on ctxs[p]); RGBA8, row 0 = bottom
-static napi_value PresentSharded(napi_env env, napi_callback_info info) {
+// The present of a frame whose stripes this process renders on several GPUs (part p on ctxs[p]); RGBA8, row 0 = bottom.
+//   presentSharded(ctxs: ctx[], fbs: fb[], samples, dof: boolean, out: Uint8Array(width * height * 4)) = rm_present_sharded
+//   presentShardedStart(ctxs, fbs, samples, dof)   = rm_present_sharded_start: snapshot and send, returns at once
+//   presentShardedFinish(ctxs, out: Uint8Array)     = rm_present_sharded_finish: the canvas of the present that was started
+static bool handle_arrays(napi_env env, napi_value a_ctxs, napi_value a_fbs, rm_ctx** ctxs, rm_fb** fbs, uint32_t* count, const char* who) {
+  uint32_t n = 0, m = 0;
+  bool is_a = false, is_b = true;
+  if (napi_is_array(env, a_ctxs, &is_a) != napi_ok || !is_a || napi_get_array_length(env, a_ctxs, &n) != napi_ok || n == 0 || n > 64 ||
+      (fbs && (napi_is_array(env, a_fbs, &is_b) != napi_ok || !is_b || napi_get_array_length(env, a_fbs, &m) != napi_ok || n != m))) {
+    napi_throw_type_error(env, nullptr, (std::string(who) + ": ctxs (and fbs) must be arrays of the same length (1..64)").c_str());
+    return false;
+  }
+  for (uint32_t i = 0; i < n; i++) {
+    napi_value a, b;
+    if (napi_get_element(env, a_ctxs, i, &a) != napi_ok) return false;
+    ctxs[i] = get_external<rm_ctx>(env, a);
+    if (fbs) {
+      if (napi_get_element(env, a_fbs, i, &b) != napi_ok) return false;
+      fbs[i] = get_external<rm_fb>(env, b);
+    }
+    if (!ctxs[i] || (fbs && !fbs[i])) {
+      napi_throw_type_error(env, nullptr, (std::string(who) + ": wrong or destroyed handle in ctxs / fbs").c_str());
+      return false;
+    }
+  }
+  *count = n;
+  return true;
+}
+
+static napi_value PresentShardedImpl(napi_env env, napi_callback_info info, bool start, bool finish) {
   size_t argc = 5;
   napi_value argv[5];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
-  uint32_t n = 0, m = 0;
-  bool is_a = false, is_b = false;
-  if (argc < 5 || napi_is_array(env, argv[0], &is_a) != napi_ok || !is_a || napi_is_array(env, argv[1], &is_b) != napi_ok || !is_b ||
-      napi_get_array_length(env, argv[0], &n) != napi_ok || napi_get_array_length(env, argv[1], &m) != napi_ok || n == 0 || n != m || n > 64) {
-    napi_throw_type_error(env, nullptr, "presentSharded(ctxs: ctx[], fbs: fb[], samples, dof, out: Uint8Array): the two arrays must have the same length (1..64)");
+  const char* who = start && finish ? "presentSharded" : start ? "presentShardedStart" : "presentShardedFinish";
+  const size_t need = start && finish ? 5 : start ? 4 : 2;
+  if (argc < need) {
+    napi_throw_type_error(env, nullptr, (std::string(who) + ": too few arguments").c_str());
     return nullptr;
   }
   rm_ctx* ctxs[64];
   rm_fb* fbs[64];
-  for (uint32_t i = 0; i < n; i++) {
-    napi_value a, b;
-    NAPI_OK(napi_get_element(env, argv[0], i, &a));
-    NAPI_OK(napi_get_element(env, argv[1], i, &b));
-    ctxs[i] = get_external<rm_ctx>(env, a);
-    fbs[i] = get_external<rm_fb>(env, b);
-    if (!ctxs[i] || !fbs[i]) {
-      napi_throw_type_error(env, nullptr, "presentSharded: wrong or destroyed handle in ctxs / fbs");
-      return nullptr;
-    }
-  }
-  int32_t samples = 1;
-  napi_get_value_int32(env, argv[2], &samples);
-  bool dof = false;
-  napi_get_value_bool(env, argv[3], &dof);
+  uint32_t n = 0;
+  if (!handle_arrays(env, argv[0], start ? argv[1] : nullptr, ctxs, start ? fbs : nullptr, &n, who)) return nullptr;
   void* d = nullptr;
   size_t len = 0;
-  if (!get_buffer(env, argv[4], &d, &len)) {
-    napi_throw_type_error(env, nullptr, "presentSharded: out must be a Uint8Array");
+  if (finish && !get_buffer(env, argv[start ? 4 : 1], &d, &len)) {
+    napi_throw_type_error(env, nullptr, (std::string(who) + ": out must be a Uint8Array").c_str());
     return nullptr;
   }
-  if (len < (size_t)rm_fb_width(fbs[0]) * (size_t)rm_fb_height(fbs[0]) * 4) {
+  if (start && finish && len < (size_t)rm_fb_width(fbs[0]) * (size_t)rm_fb_height(fbs[0]) * 4) {
     napi_throw_range_error(env, nullptr, "presentSharded: out is smaller than width * height * 4 bytes");
     return nullptr;
   }
-  if (rm_present_sharded(ctxs, fbs, (int)n, samples, dof ? 1 : 0, static_cast<uint8_t*>(d)) != RM_OK) return throw_rm(env, ctxs[0], "rm_present_sharded");
+  if (start) {
+    int32_t samples = 1;
+    napi_get_value_int32(env, argv[2], &samples);
+    bool dof = false;
+    napi_get_value_bool(env, argv[3], &dof);
+    if (rm_present_sharded_start(ctxs, fbs, (int)n, samples, dof ? 1 : 0) != RM_OK) return throw_rm(env, ctxs[0], "rm_present_sharded_start");
+  }
+  // (presentShardedFinish: the library knows the canvas of the pending present; index.js allocates `out` from the framebuffer set's size)
+  if (finish && rm_present_sharded_finish(ctxs, (int)n, static_cast<uint8_t*>(d)) != RM_OK) return throw_rm(env, ctxs[0], "rm_present_sharded_finish");
   return nullptr;
 }
+static napi_value PresentSharded(napi_env env, napi_callback_info info) { return PresentShardedImpl(env, info, true, true); }
+static napi_value PresentShardedStart(napi_env env, napi_callback_info info) { return PresentShardedImpl(env, info, true, false); }
+static napi_value PresentShardedFinish(napi_env env, napi_callback_info info) { return PresentShardedImpl(env, info, false, true); }
 
 // renderSample(ctx, scene, fb, uniforms: ArrayBuffer(sizeof RmUniforms), tile: Int32Array(4) | null, flags)
 static napi_value RenderSample(napi_env env, napi_callback_info info) {
@@ -428,7 +452,7 @@ static napi_value Init(napi_env env, napi_value exports) {
   const struct { const char* name; napi_callback fn; } fns[] = {
       {"ctxCreate", CtxCreate}, {"ctxDestroy", CtxDestroy}, {"sync", Sync}, {"sceneCreate", SceneCreate}, {"sceneDestroy", SceneDestroy},
       {"fbCreate", FbCreate}, {"fbClear", FbClear}, {"fbDestroy", FbDestroy}, {"fbDownload", FbDownload}, {"present", Present}, {"renderSample", RenderSample}, {"renderSamples", RenderSamples},
-      {"fbCreateStriped", FbCreateStriped}, {"fbRows", FbRows}, {"setSamplesInFlight", SetSamplesInFlight}, {"presentSharded", PresentSharded},
+      {"fbCreateStriped", FbCreateStriped}, {"fbRows", FbRows}, {"setSamplesInFlight", SetSamplesInFlight}, {"presentSharded", PresentSharded}, {"presentShardedStart", PresentShardedStart}, {"presentShardedFinish", PresentShardedFinish},
       {"sizes", Sizes}};
   for (const auto& f : fns) {
     napi_value fn;

@@ -34,7 +34,7 @@ EXPORTS = [
     "rm_abi_version", "rm_material_default", "rm_ctx_create", "rm_ctx_destroy", "rm_last_error", "rm_ctx_set_stream",
     "rm_ctx_set_retire_eps", "rm_ctx_set_samples_in_flight", "rm_ctx_set_cost_order", "rm_debug_counters", "rm_device_memory", "rm_sync", "rm_scene_create", "rm_scene_destroy", "rm_fb_create", "rm_fb_create_striped", "rm_fb_rows", "rm_fb_width", "rm_fb_height", "rm_fb_wrap", "rm_fb_clear", "rm_fb_destroy",
     "rm_fb_download", "rm_fb_upload", "rm_fb_device_ptr", "rm_buffer_create", "rm_buffer_destroy", "rm_buffer_download", "rm_buffer_upload", "rm_render_sample", "rm_render_samples", "rm_ctx_set_sample_batch", "rm_ctx_set_gl_stack", "rm_render_timed",
-    "rm_probe", "rm_probe_camera", "rm_probe_rng", "rm_assemble_striped", "rm_assemble_striped_bytes", "rm_present", "rm_present_planes", "rm_present_device", "rm_present_rows", "rm_pack_present_rows", "rm_ctx_last_pipeline", "rm_present_sharded", "rm_debug_cull_cell",
+    "rm_probe", "rm_probe_camera", "rm_probe_rng", "rm_assemble_striped", "rm_assemble_striped_bytes", "rm_present", "rm_present_planes", "rm_present_device", "rm_present_rows", "rm_pack_present_rows", "rm_ctx_last_pipeline", "rm_present_sharded", "rm_present_sharded_start", "rm_present_sharded_finish", "rm_present_striped_rows", "rm_debug_cull_cell",
 ]
 
 
@@ -145,6 +145,9 @@ def load_library():
         "rm_pack_present_rows": (ip, [vp, vp, vp, vp]),
         "rm_ctx_last_pipeline": (ip, [vp]),
         "rm_present_sharded": (ip, [C.POINTER(vp), C.POINTER(vp), ip, ip, ip, C.POINTER(C.c_uint8)]),
+        "rm_present_sharded_start": (ip, [C.POINTER(vp), C.POINTER(vp), ip, ip, ip]),
+        "rm_present_sharded_finish": (ip, [C.POINTER(vp), ip, C.POINTER(C.c_uint8)]),
+        "rm_present_striped_rows": (ip, [vp, vp, vp, ip, ip, ip, ip, ip, ip, vp, vp]),
         "rm_present": (ip, [vp, vp, ip, C.POINTER(C.c_uint8)]),
         "rm_present_planes": (ip, [vp, vp, vp, ip, ip, ip, C.POINTER(C.c_uint8)]),
     }
@@ -166,6 +169,24 @@ def present_sharded(contexts, framebuffers, samples: int, dof: bool) -> np.ndarr
     fs = (C.c_void_p * n)(*[f.h for f in framebuffers])
     out = np.empty((framebuffers[0].height, framebuffers[0].width, 4), np.uint8)
     contexts[0]._check(contexts[0].lib.rm_present_sharded(cs, fs, n, int(samples), 1 if dof else 0, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+    return out
+
+
+def present_sharded_start(contexts, framebuffers, samples: int, dof: bool):
+    """rm_present_sharded_start: snapshot and send; returns at once (the next samples can be handed out while the frame travels)."""
+    n = len(contexts)
+    assert n == len(framebuffers) and n >= 1
+    cs = (C.c_void_p * n)(*[c.h for c in contexts])
+    fs = (C.c_void_p * n)(*[f.h for f in framebuffers])
+    contexts[0]._check(contexts[0].lib.rm_present_sharded_start(cs, fs, n, int(samples), 1 if dof else 0))
+
+
+def present_sharded_finish(contexts, width: int, height: int) -> np.ndarray:
+    """rm_present_sharded_finish: the canvas [H, W, 4] of the present that was started."""
+    n = len(contexts)
+    cs = (C.c_void_p * n)(*[c.h for c in contexts])
+    out = np.empty((height, width, 4), np.uint8)
+    contexts[0]._check(contexts[0].lib.rm_present_sharded_finish(cs, n, out.ctypes.data_as(C.POINTER(C.c_uint8))))
     return out
 
 
@@ -284,6 +305,13 @@ class Context:
         self._check(self.lib.rm_present_device(self.h, C.c_void_p(color_ptr), C.c_void_p(normal_dof_ptr or 0), width, height, int(samples),
                                                C.c_void_p(out_ptr), C.c_void_p(stream) if stream else None))
 
+    def present_striped_rows(self, color_ptr: int, normal_dof_ptr: Optional[int], width: int, height: int, samples: int, stripe_rows: int, parts: int,
+                             part: int, out_ptr: int, stream: Optional[int] = None):
+        """display.frag for the rows part `part` of `parts` holds, read from the WHOLE frame in DEVICE memory, into DEVICE memory
+        (that part's packed rows x width x 4 bytes), asynchronous: each rank's share of a sharded frame's blur."""
+        self._check(self.lib.rm_present_striped_rows(self.h, C.c_void_p(color_ptr), C.c_void_p(normal_dof_ptr or 0), width, height, int(samples), stripe_rows,
+                                                     parts, part, C.c_void_p(out_ptr), C.c_void_p(stream) if stream else None))
+
     def present_rows(self, fb: "Framebuffer", samples: int, out_ptr: int, stream: Optional[int] = None):
         """Tone-map the rows `fb` holds (no depth of field) into DEVICE memory (rows*width*4 bytes), asynchronous."""
         self._check(self.lib.rm_present_rows(self.h, fb.h, int(samples), C.c_void_p(out_ptr), C.c_void_p(stream) if stream else None))
@@ -341,8 +369,8 @@ class Context:
         return float(ms.value)
 
     def probe(self, scene: "SceneHandle", what: int, inputs: np.ndarray, param: float = 0.0, flags: int = abi.RM_RENDER_STRICT) -> np.ndarray:
-        in_w = {abi.RM_PROBE_SDF: 3, abi.RM_PROBE_CAST_RAY: 6, abi.RM_PROBE_NORMAL: 3, abi.RM_PROBE_MATERIAL: 3, abi.RM_PROBE_CAST_STEPS: 6}[what]
-        out_w = {abi.RM_PROBE_SDF: 1, abi.RM_PROBE_CAST_RAY: 3, abi.RM_PROBE_NORMAL: 3, abi.RM_PROBE_MATERIAL: 12, abi.RM_PROBE_CAST_STEPS: 1}[what]
+        in_w = {abi.RM_PROBE_SDF: 3, abi.RM_PROBE_CAST_RAY: 6, abi.RM_PROBE_NORMAL: 3, abi.RM_PROBE_MATERIAL: 3, abi.RM_PROBE_CAST_STEPS: 6, abi.RM_PROBE_CAST_SHADOW: 9}[what]
+        out_w = {abi.RM_PROBE_SDF: 1, abi.RM_PROBE_CAST_RAY: 3, abi.RM_PROBE_NORMAL: 3, abi.RM_PROBE_MATERIAL: 12, abi.RM_PROBE_CAST_STEPS: 1, abi.RM_PROBE_CAST_SHADOW: 1}[what]
         a = np.ascontiguousarray(inputs, np.float32).reshape(-1, in_w)
         out = np.empty((len(a), out_w), np.float32)
         self._check(self.lib.rm_probe(self.h, scene.h, what, _fp(a), len(a), float(param), flags, _fp(out)))

@@ -1397,24 +1397,31 @@ print("STAGING", int(free0 - free1), same, flush=True)
     assert held[None] < 400 << 20, held
 
 
-def test_far_jump_is_exact_on_the_headline_frame(ctx):
+# The exact far-field exits and the job-shape kernel variants exist in both builds since round 4 (rm_device.hpp ExactExits): each of
+# the tests below runs on the fast AND on the parity arithmetic -- the switch RM_RENDER_NO_FAR_JUMP gives the stepwise march of either.
+BUILDS, BUILD_IDS = [FAST, STRICT], ["fast", "strict"]
+
+
+@pytest.mark.parametrize("build", BUILDS, ids=BUILD_IDS)
+def test_far_jump_is_exact_on_the_headline_frame(ctx, build):
     """The fast Mandelbulb march sets an escaping ray to the end state its remaining steps are known to reach (rm_device.hpp
     far_jump; castRay, raymarcher.frag:163-170, has no distance bound).  Exact: on the benchmarked frame itself -- 3840x2160,
     [256], the light, 2 samples -- all three planes equal the stepwise march (RM_RENDER_NO_FAR_JUMP) bit for bit, and the
     wavefront pipeline gives the same bits with the jump and without it."""
     sc, schema = _c3b()
     noises = GC.halton_pairs(2)
-    jump = render_gpu(ctx, sc, schema, noises, FAST | MK)
-    step = render_gpu(ctx, sc, schema, noises, FAST | MK | abi.RM_RENDER_NO_FAR_JUMP)
-    wf = render_gpu(ctx, sc, schema, noises, FAST | WF)
-    wf_step = render_gpu(ctx, sc, schema, noises, FAST | WF | abi.RM_RENDER_NO_FAR_JUMP)
+    jump = render_gpu(ctx, sc, schema, noises, build | MK)
+    step = render_gpu(ctx, sc, schema, noises, build | MK | abi.RM_RENDER_NO_FAR_JUMP)
+    wf = render_gpu(ctx, sc, schema, noises, build | WF)
+    wf_step = render_gpu(ctx, sc, schema, noises, build | WF | abi.RM_RENDER_NO_FAR_JUMP)
     for k in range(3):
         assert same_bits(jump[k], step[k]).all(), f"plane {k}: {int((~same_bits(jump[k], step[k])).sum())} values differ from the stepwise march"
         assert same_bits(jump[k], wf[k]).all() and same_bits(jump[k], wf_step[k]).all(), f"plane {k}: the wavefront pipeline differs"
     assert (step[2][..., 3] > 1.5e6).mean() > 0.8  # most of the frame is sky: both of a pixel's camera rays escaped
 
 
-def test_far_jump_end_points_equal_the_stepwise_march(ctx):
+@pytest.mark.parametrize("build", BUILDS, ids=BUILD_IDS)
+def test_far_jump_end_points_equal_the_stepwise_march(ctx, build):
     """castRay through the probe, fast build, with and without the jump: random rays from inside, near and far outside the
     bailout sphere (up to 1e6 away), unit directions -- also axis-parallel ones, whose zero components make the end state
     NaN -- and directions that are not unit (no jump), step budgets around the 30 the jump asks for, power 8 with 1..8
@@ -1432,15 +1439,16 @@ def test_far_jump_end_points_equal_the_stepwise_march(ctx):
         d[n // 4: n // 4 + 256] *= 0.5                                                                  # not unit: the jump must not apply
         rays = np.concatenate([o, d], 1).astype(np.float32)
         for steps in (10.0, 15.0, 16.0, 17.0, 21.0, 22.0, 23.0, 29.0, 30.0, 31.0, 64.0, 256.0):  # around the 16 / 22 / 30 the jump asks for by distance
-            a = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST)
-            b = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST | abi.RM_RENDER_NO_FAR_JUMP)
+            a = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, build)
+            b = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, build | abi.RM_RENDER_NO_FAR_JUMP)
             assert same_bits(a, b).all(), f"scene {it}, {steps} steps: {int((~same_bits(a, b)).any(-1).sum())} end points differ"
-        far = ~np.isfinite(ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, 256.0, FAST)).all(-1)
+        far = ~np.isfinite(ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, 256.0, build)).all(-1)
         assert far.mean() > 0.2  # the rays do escape: the jump had something to do
         h.destroy()
 
 
-def test_table_far_jump_is_exact_on_the_csg_frames(ctx):
+@pytest.mark.parametrize("build", BUILDS, ids=BUILD_IDS)
+def test_table_far_jump_is_exact_on_the_csg_frames(ctx, build):
     """The far-field jump of primitive tables (rm_device.hpp Sdf<RM_SCENE_TABLE>::far_jump, rm_api.hip table_far_field): an
     escaping ray of a table without domain rows ends at +-Inf by the signs of its direction, or at NaN when a smooth union
     meets Inf - Inf -- BASELINE's CSG-64.  On C4's own frame (4096 x 4096, [128], the light; 2 samples) and on C5's job
@@ -1451,15 +1459,16 @@ def test_table_far_jump_is_exact_on_the_csg_frames(ctx):
         counts = (128,) if name == "c4" else (128, 64, 64)
         schema = J.make_schema(sc, size, size, counts=counts, render_mode="full", position=(0, 0, -5.0), lights=lights)
         noises = GC.halton_pairs(samples)
-        ref = render_gpu(ctx, sc, schema, noises, FAST | MK | abi.RM_RENDER_NO_FAR_JUMP)
+        ref = render_gpu(ctx, sc, schema, noises, build | MK | abi.RM_RENDER_NO_FAR_JUMP)
         for impl, label in ((MK, "pixel kernel"), (WF, "wavefront pipeline")):
-            got = render_gpu(ctx, sc, schema, noises, FAST | impl)
+            got = render_gpu(ctx, sc, schema, noises, build | impl)
             for k in range(3):
                 assert same_bits(got[k], ref[k]).all(), f"{name}, {label}, plane {k}: {int((~same_bits(got[k], ref[k])).sum())} values differ from the stepwise march"
         assert (ref[2][..., 3] > 1.5e6).mean() > 0.3  # a good part of the frame is sky: rays did escape
 
 
-def test_shadow_rays_with_short_budgets_stop_when_their_test_is_certain(ctx):
+@pytest.mark.parametrize("build", BUILDS, ids=BUILD_IDS)
+def test_shadow_rays_with_short_budgets_stop_when_their_test_is_certain(ctx, build):
     """A table's shadow ray that escapes with too few steps left for the overflow (the 64-step bounces of C5) ends finite and far
     away, and its end point is only compared (raymarcher.frag:362-363): the fast pixel kernel stops such a march once the
     comparison is certain (rm_device.hpp far_shadow_escape); and a ray that passes every shape of a table at a distance is set to
@@ -1486,14 +1495,15 @@ def test_shadow_rays_with_short_budgets_stop_when_their_test_is_certain(ctx):
     jobs.append(("C5 at 1024^2", c5, J.make_schema(c5, 1024, 1024, counts=(128, 64, 64), render_mode="full", position=(0, 0, -5.0), lights=GC.SOFT_LIGHT)))
     for name, sc, schema in jobs:
         noises = GC.halton_pairs(2)
-        ref = render_gpu(ctx, sc, schema, noises, FAST | MK | abi.RM_RENDER_NO_FAR_JUMP)
+        ref = render_gpu(ctx, sc, schema, noises, build | MK | abi.RM_RENDER_NO_FAR_JUMP)
         for impl in (MK, WF):
-            got = render_gpu(ctx, sc, schema, noises, FAST | impl)
+            got = render_gpu(ctx, sc, schema, noises, build | impl)
             for k in range(3):
                 assert same_bits(got[k], ref[k]).all(), f"{name}, plane {k}: {int((~same_bits(got[k], ref[k])).sum())} values differ from the stepwise march"
 
 
-def test_table_far_jump_end_points_equal_the_stepwise_march(ctx):
+@pytest.mark.parametrize("build", BUILDS, ids=BUILD_IDS)
+def test_table_far_jump_end_points_equal_the_stepwise_march(ctx, build):
     """castRay through the probe on 40 random tables without domain rows -- spheres and boxes under every operator, one
     shape to ten -- fast build, with and without the jump: rays from inside the scene, near it and up to 1e6 away, unit
     directions, axis-parallel ones and ones with a single zero component (no jump to the +-Inf pattern for those), directions
@@ -1529,15 +1539,16 @@ def test_table_far_jump_end_points_equal_the_stepwise_march(ctx):
         d[n // 2:] /= np.linalg.norm(d[n // 2:], axis=1, keepdims=True)
         rays = np.concatenate([o, d], 1).astype(np.float32)
         for steps in (24.0, 40.0, 47.0, 48.0, 49.0, 50.0, 51.0, 59.0, 60.0, 61.0, 62.0, 63.0, 64.0, 69.0, 70.0, 71.0, 72.0, 73.0, 89.0, 90.0, 91.0, 99.0, 100.0, 101.0, 128.0, 256.0):  # around the 50 / 63 / 71 the jump asks for by distance, the 90 of a ray that is going to miss the scene's sphere and the 100 from which one that passes every shape at a distance is looked for
-            a = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST)
-            b = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST | abi.RM_RENDER_NO_FAR_JUMP)
+            a = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, build)
+            b = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, build | abi.RM_RENDER_NO_FAR_JUMP)
             assert same_bits(a, b).all(), f"table {it}, {steps} steps: {int((~same_bits(a, b)).any(-1).sum())} end points differ"
-        jumped += int((~np.isfinite(ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, 256.0, FAST)).all(-1)).sum())
+        jumped += int((~np.isfinite(ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, 256.0, build)).all(-1)).sum())
         h.destroy()
     assert jumped > 10000  # the rays do escape: the jump had something to do
 
 
-def test_menger_far_jump_is_exact(ctx):
+@pytest.mark.parametrize("build", BUILDS, ids=BUILD_IDS)
+def test_menger_far_jump_is_exact(ctx, build):
     """The Menger sponge's far field is its unit box's (rm_device.hpp Sdf<RM_SCENE_MENGER>::far_jump): images (both
     implementations) and castRay probes with the jump equal the stepwise march bit for bit, iterations 1..6, budgets around
     the 72 steps the jump asks for, axis-parallel and other directions with zero components included."""
@@ -1546,9 +1557,9 @@ def test_menger_far_jump_is_exact(ctx):
         sc = S.MengerSponge(iterations=iters)
         schema = J.make_schema(sc, 512, 320, counts=(128, 96), render_mode="full", position=(0.5, 0.5, -2.0), lights=GC.LIGHT)
         noises = GC.halton_pairs(2)
-        ref = render_gpu(ctx, sc, schema, noises, FAST | MK | abi.RM_RENDER_NO_FAR_JUMP)
+        ref = render_gpu(ctx, sc, schema, noises, build | MK | abi.RM_RENDER_NO_FAR_JUMP)
         for impl in (MK, WF):
-            got = render_gpu(ctx, sc, schema, noises, FAST | impl)
+            got = render_gpu(ctx, sc, schema, noises, build | impl)
             for k in range(3):
                 assert same_bits(got[k], ref[k]).all(), f"iterations {iters}, plane {k}: {int((~same_bits(got[k], ref[k])).sum())} values differ"
         h = ctx.create_scene(sc)
@@ -1560,14 +1571,15 @@ def test_menger_far_jump_is_exact(ctx):
         d[n // 8: n // 4, int(rng.integers(0, 3))] = 0.0
         rays = np.concatenate([o, d], 1).astype(np.float32)
         for steps in (24.0, 40.0, 47.0, 48.0, 49.0, 50.0, 51.0, 59.0, 60.0, 61.0, 62.0, 63.0, 64.0, 69.0, 70.0, 71.0, 72.0, 73.0, 89.0, 90.0, 91.0, 128.0, 256.0):
-            a = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST)
-            b = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST | abi.RM_RENDER_NO_FAR_JUMP)
+            a = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, build)
+            b = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, build | abi.RM_RENDER_NO_FAR_JUMP)
             assert same_bits(a, b).all(), f"iterations {iters}, {steps} steps: {int((~same_bits(a, b)).any(-1).sum())} end points differ"
-        assert (~np.isfinite(ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, 256.0, FAST)).all(-1)).mean() > 0.3
+        assert (~np.isfinite(ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, 256.0, build)).all(-1)).mean() > 0.3
         h.destroy()
 
 
-def test_sphere_grid_far_jump_is_exact(ctx):
+@pytest.mark.parametrize("build", BUILDS, ids=BUILD_IDS)
+def test_sphere_grid_far_jump_is_exact(ctx, build):
     """The sphere-grid fractal (the reference's fractal1 / guide example, the scene its page starts with) lives inside its big
     sphere; a ray that leaves it escapes (Sdf<RM_SCENE_SPHERE_GRID>::far_jump).  Random parameters; castRay end points at
     budgets around the jump's requirements and the live default job [128, 128, 64, 32, 32] as an image, both
@@ -1585,21 +1597,22 @@ def test_sphere_grid_far_jump_is_exact(ctx):
         d[: n // 8] = np.eye(3)[rng.integers(0, 3, n // 8)] * rng.choice([-1.0, 1.0], size=(n // 8, 1))
         rays = np.concatenate([o, d], 1).astype(np.float32)
         for steps in (24.0, 32.0, 47.0, 48.0, 49.0, 52.0, 55.0, 59.0, 60.0, 61.0, 64.0, 66.0, 69.0, 70.0, 71.0, 72.0, 73.0, 89.0, 90.0, 91.0, 128.0):
-            a = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST)
-            b = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST | abi.RM_RENDER_NO_FAR_JUMP)
+            a = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, build)
+            b = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, build | abi.RM_RENDER_NO_FAR_JUMP)
             assert same_bits(a, b).all(), f"scene {it}, {steps} steps: {int((~same_bits(a, b)).any(-1).sum())} end points differ"
         h.destroy()
         if it < 3:
             schema = J.make_schema(sc, 320, 180, counts=(128, 128, 64, 32, 32), render_mode="full", position=(0.0, 0.0, 0.0))
             noises = GC.halton_pairs(2)
-            ref = render_gpu(ctx, sc, schema, noises, FAST | MK | abi.RM_RENDER_NO_FAR_JUMP)
+            ref = render_gpu(ctx, sc, schema, noises, build | MK | abi.RM_RENDER_NO_FAR_JUMP)
             for impl in (MK, WF):
-                got = render_gpu(ctx, sc, schema, noises, FAST | impl)
+                got = render_gpu(ctx, sc, schema, noises, build | impl)
                 for k in range(3):
                     assert same_bits(got[k], ref[k]).all(), f"scene {it}, plane {k}: {int((~same_bits(got[k], ref[k])).sum())} values differ"
 
 
-def test_kifs_far_field_shortcuts_are_exact(ctx):
+@pytest.mark.parametrize("build", BUILDS, ids=BUILD_IDS)
+def test_kifs_far_field_shortcuts_are_exact(ctx, build):
     """The kaleidoscopic kinds (rm_api.hip kifs_far_field): the rotation fractal's escaping rays are set to their end state
     (Sdf<RM_SCENE_KIFS_BOX>::far_jump), and the tree's evaluation returns its starting value 9999 beyond |p| = 9999 + R'
     without running its levels (plain and smooth).  Random parameters (iterations, scale, angles, offset): the distance at
@@ -1616,8 +1629,8 @@ def test_kifs_far_field_shortcuts_are_exact(ctx):
         h = ctx.create_scene(sc)
         n = 4096
         o = rng.normal(size=(n, 3)) * rng.choice([1.0, 10.0, 5e3, 1e4, 2e4, 1e6, 1e7], size=(n, 1))
-        a = ctx.probe(h, abi.RM_PROBE_SDF, o.astype(np.float32), 0.0, FAST)
-        b = ctx.probe(h, abi.RM_PROBE_SDF, o.astype(np.float32), 0.0, FAST | abi.RM_RENDER_NO_FAR_JUMP)
+        a = ctx.probe(h, abi.RM_PROBE_SDF, o.astype(np.float32), 0.0, build)
+        b = ctx.probe(h, abi.RM_PROBE_SDF, o.astype(np.float32), 0.0, build | abi.RM_RENDER_NO_FAR_JUMP)
         assert same_bits(a, b).all(), f"scene {it}: {int((~same_bits(a, b)).sum())} distances differ"
         if kind != 0:
             assert (a == 9999.0).mean() > 0.3  # the far points do see the starting value
@@ -1626,16 +1639,16 @@ def test_kifs_far_field_shortcuts_are_exact(ctx):
         d[: n // 8] = np.eye(3)[rng.integers(0, 3, n // 8)] * rng.choice([-1.0, 1.0], size=(n // 8, 1))
         rays = np.concatenate([rng.normal(size=(n, 3)) * rng.choice([1.0, 5.0, 1e3, 1e6], size=(n, 1)), d], 1).astype(np.float32)
         for steps in (24.0, 40.0, 48.0, 49.0, 52.0, 55.0, 60.0, 61.0, 66.0, 69.0, 70.0, 72.0, 73.0, 89.0, 90.0, 91.0, 128.0, 256.0):
-            ra = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST)
-            rb = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST | abi.RM_RENDER_NO_FAR_JUMP)
+            ra = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, build)
+            rb = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, build | abi.RM_RENDER_NO_FAR_JUMP)
             assert same_bits(ra, rb).all(), f"scene {it}, {steps} steps: {int((~same_bits(ra, rb)).any(-1).sum())} end points differ"
         h.destroy()
         if it < 6:
             schema = J.make_schema(sc, 320, 192, counts=(128, 80), render_mode="full", position=(0.2, 0.1, -3.5), lights=GC.LIGHT)
             noises = GC.halton_pairs(2)
-            ref = render_gpu(ctx, sc, schema, noises, FAST | MK | abi.RM_RENDER_NO_FAR_JUMP)
+            ref = render_gpu(ctx, sc, schema, noises, build | MK | abi.RM_RENDER_NO_FAR_JUMP)
             for impl in (MK, WF):
-                got = render_gpu(ctx, sc, schema, noises, FAST | impl)
+                got = render_gpu(ctx, sc, schema, noises, build | impl)
                 for k in range(3):
                     assert same_bits(got[k], ref[k]).all(), f"scene {it}, plane {k}: {int((~same_bits(got[k], ref[k])).sum())} values differ"
 
@@ -1651,8 +1664,9 @@ def test_kifs_far_field_shortcuts_are_exact(ctx):
 FAST_TOLERANCE_K = 1.0
 
 
+@pytest.mark.parametrize("build", BUILDS, ids=BUILD_IDS)
 @pytest.mark.parametrize("scene", ["bulb", "csg64", "fractal1", "csg_mixed"])
-def test_kernel_variants_by_job_shape_leave_the_same_bits(ctx, scene):
+def test_kernel_variants_by_job_shape_leave_the_same_bits(ctx, scene, build):
     """The fast pixel kernel has variants for jobs with exactly one light (its term is computed before its shadow march) and for
     one light and one bounce (nothing of the bounce lives across the shadow march: no scratch), rm_kernels.inc ONE_LIGHT.  Every
     job shape -- 0..3 lights (one of them soft), 1..3 bounces -- on the headline kind, CSG-64's kind, a kind without compaction
@@ -1666,15 +1680,15 @@ def test_kernel_variants_by_job_shape_leave_the_same_bits(ctx, scene):
         for counts in ((48,), (48, 24), (40, 24, 16)):
             schema = J.make_schema(sc, 160, 96, counts=counts, render_mode="full", position=pos, lights=lights3[:nl])
             noises = GC.halton_pairs(2)
-            a = render_gpu(ctx, sc, schema, noises, FAST | MK)
-            b = render_gpu(ctx, sc, schema, noises, FAST | WF)
+            a = render_gpu(ctx, sc, schema, noises, build | MK)
+            b = render_gpu(ctx, sc, schema, noises, build | WF)
             for k in range(3):
                 assert same_bits(a[k], b[k]).all(), f"{scene}, {nl} lights, {counts}: plane {k} differs from the pipeline in {int((~same_bits(a[k], b[k])).sum())} values"
     # one light + a second light without colour: the general kernel; the G-buffer planes do not depend on lights at all
     one = J.make_schema(sc, 160, 96, counts=(48,), render_mode="full", position=pos, lights=lights3[:1])
     two = J.make_schema(sc, 160, 96, counts=(48,), render_mode="full", position=pos, lights=[lights3[0], J.point_light((1.0, 1.0, 1.0), color=(0.0, 0.0, 0.0))])
     noises = GC.halton_pairs(1)
-    a, b = render_gpu(ctx, sc, one, noises, FAST | MK), render_gpu(ctx, sc, two, noises, FAST | MK)
+    a, b = render_gpu(ctx, sc, one, noises, build | MK), render_gpu(ctx, sc, two, noises, build | MK)
     assert same_bits(a[1], b[1]).all() and same_bits(a[2], b[2]).all()
 
 

@@ -2,8 +2,8 @@
 sharded job.RenderJobContext -- the classes a GPU node runs -- and rank 0's presented canvases are compared with the
 single-process job's.  There is no GPU here, so the device side is a stand-in built on the oracle (this is a test: the
 oracle is the checker and here also the stand-in renderer): a fake native context that renders this rank's stripes with
-oracle.render, tone-maps / packs them like rm_present_rows / rm_pack_present_rows and runs the present pass of the
-assembled frame with oracle.present.  What is under test is everything above the C ABI: the striped window arithmetic,
+oracle.render, tone-maps / packs them like rm_present_rows / rm_pack_present_rows and runs the present pass of its own
+stripes of the gathered frame with oracle.present (rm_present_striped_rows: with depth of field every rank blurs what it holds).  What is under test is everything above the C ABI: the striped window arithmetic,
 the yield cadence, both gather payloads (depth of field off and on), the assembly, ragged heights."""
 import ctypes
 import os
@@ -60,6 +60,7 @@ class OracleNative:
     def __init__(self, O, shard):
         self.O, self.shard = O, shard
         self.scenes = {}
+        self.calls = {"present_striped_rows": [], "present_device": 0}
 
     def create_scene(self, scene):
         return scene
@@ -91,10 +92,19 @@ class OracleNative:
         out[..., :3] = fb.planes[0][..., :3]
         out[..., 3] = fb.planes[1][..., 3]
 
+    def present_striped_rows(self, color_ptr, normal_dof_ptr, width, height, samples, stripe_rows, parts, part, out_ptr, stream=None):
+        # rm_present_striped_rows: display.frag for the rows this part holds, read from the whole (gathered) frame
+        color = _at(color_ptr, (height, width, 4), np.float32)
+        nd = _at(normal_dof_ptr, (height, width, 4), np.float32)
+        rows = self.shard.owned_rows(height, parts, part, stripe_rows)
+        _at(out_ptr, (len(rows), width, 4), np.uint8)[:] = self.O.present(color, nd, samples)[rows]
+        self.calls["present_striped_rows"].append((parts, part, len(rows)))
+
     def present_device(self, color_ptr, normal_dof_ptr, width, height, samples, out_ptr, stream=None):  # rm_present_device
         color = _at(color_ptr, (height, width, 4), np.float32)
         nd = _at(normal_dof_ptr, (height, width, 4), np.float32)
         _at(out_ptr, (height, width, 4), np.uint8)[:] = self.O.present(color, nd, samples)
+        self.calls["present_device"] += 1
 
 
 def _schema(J, GC, width, height, dof, spp, interval):
@@ -117,7 +127,8 @@ def _worker(rank, world, port, width, height, dof, out_path):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     group = rmdist.ShardGroup(dist, torch.device("cpu"))
     assert group.world == world and group.rank == rank and group.sharded
-    ctx = J.RenderJobContext(group=group, native_context=OracleNative(O, shard))
+    stand_in = OracleNative(O, shard)
+    ctx = J.RenderJobContext(group=group, native_context=stand_in)
     sc, schema = _schema(J, GC, width, height, dof, spp=3, interval=2)
     J.reset_halton()
     frames = []
@@ -133,6 +144,11 @@ def _worker(rank, world, port, width, height, dof, out_path):
     assert res == {"success": True} and frames[-1][0] == 3
     if rank == 0:
         np.save(out_path.replace(".npy", "_again.npy"), frames[-1][1])
+    # with depth of field EVERY rank ran the present pass, for the rows it holds and no others (1 / world of the blur each; round 3 had
+    # rank 0 blur the whole frame); without it nobody blurs
+    mine = len(shard.owned_rows(height, world, rank, group.stripe_rows))
+    assert stand_in.calls["present_device"] == 0
+    assert stand_in.calls["present_striped_rows"] == ([(world, rank, mine)] * 4 if dof else [])
     dist.barrier()
     dist.destroy_process_group()
 

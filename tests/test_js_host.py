@@ -175,6 +175,11 @@ def test_js_sharded_context_presents_the_single_context_bytes(tmp_path):
         assert sorted(res[name]["rows"]) == [16, 16, 20] and sum(res[name]["rows"]) == 52  # 6.5 stripes over 3 contexts
         for (k, a), (_, b) in zip(one["shown"], many["shown"]):
             assert a == b, f"{name}: the canvas after {k} samples differs"
+        # the present in two halves (startPresent / finishPresent: the frame travels while the next samples render): the same canvases
+        lapped = res[name]["lapped"]
+        assert lapped["res"] == {"success": True} and [k for k, _ in lapped["shown"]] == [2, 4, 6, 8, 10, 12]
+        for (k, a), (_, b) in zip(one["shown"], lapped["shown"]):
+            assert a == b, f"{name}: the overlapped canvas after {k} samples differs"
         canv[name] = np.frombuffer(base64.b64decode(one["shown"][-1][1]), np.uint8).reshape(52, 96, 4)
         assert int(canv[name][..., :3].max()) > 100
     assert not np.array_equal(canv["plain"], canv["dof"])

@@ -27,3 +27,20 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(20):
     ctx.present_rows(fb, 1, out.data_ptr())
 torch.cuda.synchronize(); print(f"present_rows 3840x2160: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms")
+# Round 4: one part's share of the pass (rm_present_striped_rows: what every rank of a sharded job with depth of field runs, on the
+# stripes it holds, after the all-gather of the packed rows) by the number of parts, at the blur's 16-pixel cap -- 1 / N of the whole pass
+for WW, HH in ((3840, 2160), (8192, 8192)):
+    color = torch.rand((HH, WW, 4), device="cuda") * 2
+    color[..., 3] = 16.0 / 200.0  # the packed buffer: (colour.rgb, dofRadius) serves as both planes
+    whole = None
+    for parts in (1, 2, 4, 8):
+        rows = (HH // 8 + parts - 1) // parts * 8
+        out = torch.zeros((rows, WW, 4), dtype=torch.uint8, device="cuda")
+        for rep in range(2):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(3):
+                ctx.present_striped_rows(color.data_ptr(), color.data_ptr(), WW, HH, 1, 8, parts, 0, out.data_ptr())
+            torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+        whole = whole or dt
+        print(f"present_striped_rows {WW}x{HH}, radius 16 px (cap), part 0 of {parts}: {dt * 1e3:.3f} ms ({dt / whole:.3f} of the whole pass)")
+    del color
