@@ -58,6 +58,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 128 lanes x 2 flop x 2.4 GHz
 PEAK_HBM_GBS = 8000.0
+VALU_ISSUE_PER_S = 1.0e12  # wave-level VALU instructions/s the chip sustains at the clock it holds under a dense fp32 stream (profiles/r02_valu_issue_rate.txt)
 
 WORKLOADS = {
     # C3b is the headline; the others are selectable for profiling
@@ -158,20 +159,21 @@ def reference_gl(key):
 
 
 def counters_entry(key, strict, pipeline, windowed):
-    """This workload's entry of profiles/r03_counters.json (separate rocprofv3 --pmc passes of this command, tools/profile_gpu.sh
+    """This workload's entry of profiles/<round>_counters.json (separate rocprofv3 --pmc passes of this command, tools/profile_gpu.sh
     + tools/update_counters.py): HBM bytes and executed lane-flops per frame.  The counters belong to the kernel sources they
     were measured on (their hash is recorded): after a source change they are withheld until re-measured."""
     try:
-        cj = json.load(open(os.path.join(ROOT, "profiles", "r03_counters.json")))
         import importlib.util
         spec = importlib.util.spec_from_file_location("update_counters", os.path.join(ROOT, "tools", "update_counters.py"))
         uc = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(uc)
+        name = uc.COUNTERS_ROUND + "_counters.json"
+        cj = json.load(open(os.path.join(ROOT, "profiles", name)))
         base = key + ("_shard" if windowed else "") + ("_strict" if strict else "_fast")
         ent = cj.get(base + "_" + pipeline) or cj.get(base)  # (workloads profiled with both implementations carry the implementation in the key)
         if not ent or ent.get("kernel_source_sha256") != uc.kernel_source_hash() or ent.get("pipeline") != pipeline:
             return None
-        return ent
+        return dict(ent, counters_file="profiles/" + name)
     except Exception:
         return None
 
@@ -464,13 +466,21 @@ def main():
             cpu["reference_gl"] = reference_gl(args.workload)
         nominal_px = NOMINAL_FLOPS_PX[args.workload]
         roof = None
-        # measured in separate rocprofv3 --pmc runs of this command (profiles/r03_counters.json says how and from which file)
-        traffic = executed = counters_file = None
+        # NOT measured in this run: replayed from the builder's separate rocprofv3 --pmc runs of this command, kept in
+        # profiles/<round>_counters.json with the hash of the kernel sources they were measured on (withheld when the sources changed)
+        traffic = executed = counters_file = counters_from = issue_busy = fma_share = None
         ent = counters_entry(args.workload, args.strict, pipeline, rows_window is not None or stripes is not None)
         if ent:
-            traffic = ent["hbm_bytes_per_frame"] * px_launch / ent["pixels_per_frame"]
-            executed = ent["executed_lane_flops_per_frame"] * px_launch / ent["pixels_per_frame"]
+            share = px_launch / ent["pixels_per_frame"]
+            traffic = ent["hbm_bytes_per_frame"] * share
+            executed = ent["executed_lane_flops_per_frame"] * share
             counters_file = ent["profile"]
+            counters_from = f"{ent['counters_file']} (builder-measured with rocprofv3 --pmc, replayed; kernel sources sha256 {ent['kernel_source_sha256'][:16]})"
+            if ent.get("fma_f32_per_frame") is not None and ent["sq_insts_valu_per_frame"]:
+                fma_share = ent["fma_f32_per_frame"] / ent["sq_insts_valu_per_frame"]
+                # issue slots: a transcendental holds the SIMD's issue for 3.2 ordinary slots; a gfx950 sustains ~1.0e12 wave-level
+                # VALU instructions/s at the clock it holds under this load (profiles/r02_valu_issue_rate.txt)
+                issue_busy = (ent["sq_insts_valu_per_frame"] + 2.2 * ent["trans_f32_per_frame"]) * share / (kernel_ms * 1e-3) / VALU_ISSUE_PER_S
         if flops_launch is not None:
             sec = kernel_ms * 1e-3
             achieved = flops_launch / sec / 1e12
@@ -478,6 +488,7 @@ def main():
                     "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,
                     "frac_nominal": nominal_px * px_launch / sec / 1e12 / PEAK_FP32_VALU_TFLOPS,
                     "frac_executed": executed / sec / 1e12 / PEAK_FP32_VALU_TFLOPS if executed else None,
+                    "counters_from": counters_from, "valu_issue_busy": issue_busy, "fma_share": fma_share,
                     "flops_per_pixel_sample_instrumented": flops_px, "flops_per_pixel_sample_nominal": nominal_px,
                     "flops_per_launch_instrumented": flops_launch,
                     "flops_source": f"profiles/flops_per_pixel.json[{args.workload}] (every {fixture['row_stride']} row(s) of the whole frame; tools/count_flops.py)",
@@ -486,7 +497,10 @@ def main():
                     "hbm_algorithmic_GBs": 96.0 * px_launch / sec / 1e9, "hbm_peak_GBs": PEAK_HBM_GBS,
                     "note": "frac prices the REFERENCE algorithm (every step of its fixed-count marches, SURVEY 8(d)) at the kernel's time; the kernel skips, "
                             "exactly, the steps whose outcome is known -- a ray that stopped moving, an escaping ray's way to overflow -- so frac can "
-                            "exceed 1 on frames that are mostly sky; frac_executed is the hardware's own count of the arithmetic done"}
+                            "exceed 1 on frames that are mostly sky; frac_executed is the hardware's own count of the arithmetic done.  traffic, frac_executed, "
+                            "valu_issue_busy and fma_share are REPLAYED from counters_from, not measured in this run: frac_executed = (ADD + MUL + 2 FMA + TRANS) "
+                            "x 64 x lanes active / kernel time / peak; with fma_share of the VALU instructions being FMAs (2 flops) and the rest 1 or 0, and "
+                            "valu_issue_busy of the issue slots taken, that is what bounds it"}
         out = {
             "metric": "Mpixels/sec at 3840x2160 Mandelbulb" if args.workload in ("c3b", "c3a") else "Mpixels/sec",
             "value": value, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -498,8 +512,8 @@ def main():
                        "host": "job.do_render_job on a job.RenderJobContext" + (" (sharded: dist.ShardGroup)" if sharded else ""),
                        "sharding": (f"{shard.STRIPE_ROWS}-row stripes round-robin over ranks; a step = one sample of every pixel, plus -- every {yield_interval} sample(s) "
                                     f"(render.sampleYieldInterval) -- one present: each rank {'packs (colour, DoF radius) of' if payload == 'f32dof' else 'tone-maps'} its rows, the {payload} "
-                                    f"rows are gathered to rank 0 over {'RCCL' if backend == 'nccl' else backend + ' (testing aid: through host memory)'} (overlapped with the next samples' render) and put back in image order"
-                                    + (", and rank 0 runs the present pass with its blur on the assembled frame" if payload == "f32dof" else ""))
+                                    f"rows are {'all-gathered to every rank' if payload == 'f32dof' else 'gathered to rank 0'} over {'RCCL' if backend == 'nccl' else backend + ' (testing aid: through host memory)'} (overlapped with the next samples' render) and put back in image order"
+                                    + (", every rank runs the present pass with its blur for the stripes it holds (1 / N of the pass) and the RGBA8 rows are gathered to rank 0" if payload == "f32dof" else ""))
                        if sharded else "none",
                        "planes": "color+normal_dof+albedo_depth fp32, accumulated in place", "samples_in_flight": in_flight,
                        "sample_yield_interval": yield_interval},

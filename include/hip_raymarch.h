@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RM_ABI_VERSION 6 /* 6: rm_present_striped_rows, rm_present_sharded_start / _finish, RM_PROBE_CAST_SHADOW (additions only); 3: rm_ctx_set_sample_batch, rm_buffer_*; 4: rm_ctx_set_gl_stack; 5: RmSurface / RmSceneDesc.surfaces (the struct grew), rm_pack_present_rows, rm_present_sharded, rm_ctx_last_pipeline, RM_RENDER_NO_FAR_JUMP, RM_RENDER_NO_CULL (additions only) */
+#define RM_ABI_VERSION 6 /* 6: rm_present_striped_rows, rm_present_sharded_start / _finish, rm_ctx_last_warning, RM_PROBE_CAST_SHADOW, RM_PRIM_KIND (additions only); 3: rm_ctx_set_sample_batch, rm_buffer_*; 4: rm_ctx_set_gl_stack; 5: RmSurface / RmSceneDesc.surfaces (the struct grew), rm_pack_present_rows, rm_present_sharded, rm_ctx_last_pipeline, RM_RENDER_NO_FAR_JUMP, RM_RENDER_NO_CULL (additions only) */
 
 #define RM_MAX_BOUNCES 10 /* raymarchingStepCountsArray[10], raymarcher.frag:31 */
 #define RM_MAX_LIGHTS 10  /* lightPositions[10],             raymarcher.frag:37-39 */
@@ -108,8 +108,15 @@ enum {
  *   RM_PRIM_FOLD    q = abs(q / scale) - offset;  q = the three plane rotations by angles;  factor *= scale
  *                   scale = k (> 0), offset = center[0..2], angles = size[0..2] (radians): one level of the
  *                   reference's kaleidoscopic folds (examples/tree.glsl:24-32, rotation-fractal.glsl:21-29)
- * A shape row contributes  shape(q) * factor. */
-enum { RM_PRIM_SPHERE = 0, RM_PRIM_BOX = 1, RM_PRIM_REPEAT = 2, RM_PRIM_FOLD = 3 };
+ * A shape row contributes  shape(q) * factor.
+ *   RM_PRIM_KIND    (ABI 6) a SHAPE row whose distance term is a scene kind's own estimator, so that a composition like "a
+ *                   Mandelbulb cut by a box" or "a lattice of spheres inside a ball" is table data and not a new kind
+ *                   (the reference takes any GLSL sdf(): RenderJobExecutor.tsx:121-127):  kind(q - center)  with
+ *                   kind = (int)size[0] one of RM_SCENE_MANDELBULB, RM_SCENE_SPHERE_LATTICE and the kind's parameters in
+ *                   RmSceneDesc.params (its own slots: one kind per table, any number of rows of it).  Operator, k and
+ *                   surface as for a sphere or a box.  A table with such a row renders with the pixel kernel, without the
+ *                   far-field exits and the row culling (both are arguments about spheres and boxes). */
+enum { RM_PRIM_SPHERE = 0, RM_PRIM_BOX = 1, RM_PRIM_REPEAT = 2, RM_PRIM_FOLD = 3, RM_PRIM_KIND = 4 };
 enum { RM_OP_UNION = 0, RM_OP_SMOOTH_UNION = 1, RM_OP_SUBTRACT = 2, RM_OP_INTERSECT = 3 };
 
 /* One row of the primitive table, 32 bytes.  The scene distance is the left
@@ -119,7 +126,7 @@ typedef struct RmPrim {
   int32_t type; /* RM_PRIM_* in bits 0..7, RM_OP_* in bits 8..15, surface index of a shape row in bits 16..23 (RmSurface) */
   float k;      /* smooth-union radius */
   float center[3];
-  float size[3]; /* sphere: size[0] = radius; box: half extents; repeat: period; fold: angles */
+  float size[3]; /* sphere: size[0] = radius; box: half extents; repeat: period; fold: angles; kind: size[0] = the RM_SCENE_* kind */
 } RmPrim;
 
 /* parameter slots of RmSceneDesc.params per kind */
@@ -204,7 +211,9 @@ enum {
   RM_RENDER_FAST = 1,        /* hardware-rate math in the distance evaluations; same image statistics, not the same bits */
   RM_RENDER_COLOR_ONLY = 2,  /* do not read/write the two G-buffer planes (benchmark "single colour frame" mode) */
   RM_RENDER_MEGAKERNEL = 4,  /* force the one-thread-one-pixel kernel (whole main() per thread) */
-  RM_RENDER_WAVEFRONT = 16,  /* force the wavefront pipeline (ray-compacting persistent march).  With neither flag the
+  RM_RENDER_WAVEFRONT = 16,  /* ask for the wavefront pipeline (ray-compacting persistent march) -- a REQUEST: a table whose shapes
+                                name surfaces (RmSurface) always takes the pixel kernel, the pipeline has no per-shape materials;
+                                rm_ctx_last_pipeline tells which implementation a call ran.  With neither flag the
                                 library picks per job from a measured table: the single kernel -- in the strict
                                 build except for full-mode tiles of >= 16 M pixels over primitive tables of >= 16 rows.  Same
                                 results either way. */
@@ -254,6 +263,10 @@ int rm_ctx_set_stream(rm_ctx* ctx, void* hip_stream);
  * there afterwards sees the sample blended.  The planes receive the same bits as without overlap.  Costs 3 planes
  * of staging per sample in flight. */
 int rm_ctx_set_samples_in_flight(rm_ctx* ctx, int n);
+/* Advice that came with the last rm_ctx_set_samples_in_flight that SUCCEEDED ("" = none): the process environment
+ * (GPU_MAX_HW_QUEUES < 8, read by the HIP runtime when it starts) will keep the samples from overlapping.  Not an
+ * error: rm_last_error is for failures only.  The pointer stays valid until the next such call on the context. */
+const char* rm_ctx_last_warning(const rm_ctx* ctx);
 /* Samples per launch of rm_render_samples (default 0 = automatic, 1 = one launch per sample, 2..8 = fixed).  A small
  * window -- one GPU's rows of a sharded frame -- has too few workgroups to keep the chip busy to the end of a launch
  * (a ray is a serial chain of ~1 ms); rm_render_samples therefore renders up to 8 consecutive samples of the job in

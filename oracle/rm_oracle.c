@@ -298,11 +298,21 @@ static float op_smooth_union(float d1, float d2, float k) {
 /* RM_SCENE_TABLE: the GLSL the composer emits is the same left fold over the shape rows; domain rows
  * (RM_PRIM_REPEAT, RM_PRIM_FOLD: include/hip_raymarch.h) transform the point the following rows see */
 static v3 kifs_rotate(v3 t, const float* ang);
+static float sdf_mandelbulb(const RmSceneDesc* sc, v3 pos);
+static float sdf_sphere_lattice(const RmSceneDesc* sc, v3 p);
+static int is_domain_row(int prim) { return prim == RM_PRIM_REPEAT || prim == RM_PRIM_FOLD; }
+/* RM_PRIM_KIND (include/hip_raymarch.h): a shape row whose distance term is a scene kind's own estimator at q - center, with the
+ * kind's parameters in the scene block -- the composer emits that kind's text as rmKindSdf() and the call (scene.py CsgScene.shape) */
+static float sdf_kind_row(const RmSceneDesc* sc, const RmPrim* pr, v3 q) {
+  FL(3);
+  const v3 at = vsub(q, V(pr->center[0], pr->center[1], pr->center[2]));
+  return (int)pr->size[0] == RM_SCENE_SPHERE_LATTICE ? sdf_sphere_lattice(sc, at) : sdf_mandelbulb(sc, at);
+}
 static float sdf_table(const RmSceneDesc* sc, v3 p) {
   float d = 0.0f, factor = 1.0f;
   int first = 1, domain = 0;
   v3 q = p;
-  for (int i = 0; i < sc->nprims; i++) domain |= (sc->prims[i].type & 0xff) >= RM_PRIM_REPEAT;
+  for (int i = 0; i < sc->nprims; i++) domain |= is_domain_row(sc->prims[i].type & 0xff);
   for (int i = 0; i < sc->nprims; i++) {
     const RmPrim* pr = &sc->prims[i];
     v3 c = V(pr->center[0], pr->center[1], pr->center[2]);
@@ -323,6 +333,7 @@ static float sdf_table(const RmSceneDesc* sc, v3 p) {
     }
     float di;
     if (prim == RM_PRIM_SPHERE) di = sdf_sphere(q, c, pr->size[0]);
+    else if (prim == RM_PRIM_KIND) di = sdf_kind_row(sc, pr, q);
     else di = sd_box(vsub(q, c), V(pr->size[0], pr->size[1], pr->size[2]));
     if (domain) { FL(1); di = di * factor; }
     if (first) { d = di; first = 0; continue; }
@@ -500,7 +511,7 @@ static int surface_index(const RmSceneDesc* sc, v3 p) {
   float best = 0.0f, factor = 1.0f;
   int first = 1, domain = 0, surface = 0;
   v3 q = p;
-  for (int i = 0; i < sc->nprims; i++) domain |= (sc->prims[i].type & 0xff) >= RM_PRIM_REPEAT;
+  for (int i = 0; i < sc->nprims; i++) domain |= is_domain_row(sc->prims[i].type & 0xff);
   for (int i = 0; i < sc->nprims; i++) {
     const RmPrim* pr = &sc->prims[i];
     v3 c = V(pr->center[0], pr->center[1], pr->center[2]);
@@ -519,6 +530,7 @@ static int surface_index(const RmSceneDesc* sc, v3 p) {
     }
     float di;
     if (prim == RM_PRIM_SPHERE) di = sdf_sphere(q, c, pr->size[0]);
+    else if (prim == RM_PRIM_KIND) di = sdf_kind_row(sc, pr, q);
     else di = sd_box(vsub(q, c), V(pr->size[0], pr->size[1], pr->size[2]));
     if (domain) di = di * factor;
     if (first || di < best) { best = di; surface = (pr->type >> 16) & 0xff; }

@@ -12,7 +12,7 @@ RM_OK, RM_ERR_INVALID, RM_ERR_DEVICE, RM_ERR_NO_DEVICE = 0, 1, 2, 3
 
 (RM_SCENE_TABLE, RM_SCENE_MANDELBULB, RM_SCENE_SPHERE_GRID, RM_SCENE_SPHERE_LATTICE,
  RM_SCENE_MENGER, RM_SCENE_KIFS_TREE, RM_SCENE_KIFS_BOX) = range(7)
-RM_PRIM_SPHERE, RM_PRIM_BOX, RM_PRIM_REPEAT, RM_PRIM_FOLD = 0, 1, 2, 3
+RM_PRIM_SPHERE, RM_PRIM_BOX, RM_PRIM_REPEAT, RM_PRIM_FOLD, RM_PRIM_KIND = 0, 1, 2, 3, 4
 RM_OP_UNION, RM_OP_SMOOTH_UNION, RM_OP_SUBTRACT, RM_OP_INTERSECT = 0, 1, 2, 3
 
 RM_RENDER_STRICT, RM_RENDER_FAST, RM_RENDER_COLOR_ONLY, RM_RENDER_MEGAKERNEL, RM_RENDER_NO_COST_CLASSES, RM_RENDER_WAVEFRONT = 0, 1, 2, 4, 8, 16

@@ -115,6 +115,7 @@ struct rm_ctx {
   int shard_w = 0, shard_h = 0;                              // root: the canvas of the pending present
   unsigned long long peer_enabled = 0;  // devices this context's GPU has been given peer access to
   std::string error;
+  std::string warning;  // rm_ctx_last_warning: advice that came with a call that SUCCEEDED (never an error)
 };
 
 struct rm_scene {
@@ -123,6 +124,12 @@ struct rm_scene {
   RmPrim* d_prims = nullptr;
   RmSurface* d_surfaces = nullptr;
   unsigned long long* d_cull = nullptr;
+  // the culling grid of a long CSG table is built by the first fast-build call that can use it (scene_cull_grid): a host that only
+  // ever renders strict, or creates many scenes it renders once, does not pay (32^3 x levels + 1) x words x 8 B -- 4.7 MB at 12
+  // rows, 14 MB at 192 -- and a build kernel per scene
+  bool cull_wanted = false;
+  CullGrid cull_grid{};
+  CullBuild cull_build{};
 };
 
 struct rm_fb {
@@ -276,7 +283,7 @@ int rm_ctx_set_samples_in_flight(rm_ctx* ctx, int n) {
   if (n < 1 || n > RM_SP_MAX) return fail(ctx, RM_ERR_INVALID, "rm_ctx_set_samples_in_flight: n must be in 1..8");
   if (ctx->sp_ready) RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->samples_in_flight = n;
-  ctx->error.clear();
+  ctx->warning.clear();
   if (n > 1) {
     // every sample in flight renders on a side stream; the HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES
     // hardware queues (default 4, read when the runtime starts) and streams that share a queue serialise
@@ -287,11 +294,13 @@ int rm_ctx_set_samples_in_flight(rm_ctx* ctx, int n) {
       std::snprintf(msg, sizeof msg, "warning: %d samples in flight but GPU_MAX_HW_QUEUES is %s%d: the side streams will share hardware queues and "
                     "serialise (measured: 0.59 instead of 0.42 ms per sample on a 1/8 shard); export GPU_MAX_HW_QUEUES=8 before the process "
                     "touches the GPU (raymarching_engine_amd.native and js/index.js do)", n, q ? "" : "unset = ", queues);
-      ctx->error = msg;  // accepted all the same: RM_OK, with the note left for rm_last_error
+      ctx->warning = msg;  // accepted all the same: RM_OK, and rm_last_error stays what it was -- the note goes to rm_ctx_last_warning
     }
   }
   return RM_OK;
 }
+
+const char* rm_ctx_last_warning(const rm_ctx* ctx) { return ctx ? ctx->warning.c_str() : ""; }
 
 int rm_ctx_set_cost_order(rm_ctx* ctx, int on) {
   if (!ctx) return RM_ERR_INVALID;
@@ -386,7 +395,7 @@ static void table_far_field(const RmSceneDesc* desc, DevScene* dev) {
   for (int i = 0; i < desc->nprims; i++) {
     const RmPrim& p = desc->prims[i];
     const int type = p.type & 0xff, op = (p.type >> 8) & 0xff;
-    if (type == RM_PRIM_REPEAT || type == RM_PRIM_FOLD) return;  // a tiled or folded space has no far field
+    if (type == RM_PRIM_REPEAT || type == RM_PRIM_FOLD || type == RM_PRIM_KIND) return;  // a tiled or folded space has no far field; a kind's estimator is not a sphere's or a box's
     const double c = std::sqrt((double)p.center[0] * p.center[0] + (double)p.center[1] * p.center[1] + (double)p.center[2] * p.center[2]);
     const double extent = type == RM_PRIM_SPHERE ? std::fabs((double)p.size[0])
                                                  : std::sqrt((double)p.size[0] * p.size[0] + (double)p.size[1] * p.size[1] + (double)p.size[2] * p.size[2]);
@@ -406,7 +415,7 @@ static void table_far_field(const RmSceneDesc* desc, DevScene* dev) {
   // settles.  How long can it take to leave?  Let rho hold every shape's sphere and K (rho = 1.15 (reach + k_max), b0 <= rho / 8).
   // Inside that sphere a step is >= b0, outside >= |x| - rho + b0; two steps bring a ray from up to 60 Rp away to it, and the worst
   // chord (through the centre) is crossed and the ray out at 2.6 rho -- beyond the jump's 2 Rp, moving outward -- within
-  // 2 rho / (0.99 b0) + 6 steps (tools: the recurrence iterated over every closest approach).  Then the jump's first case: 72 steps.
+  // 2 rho / (0.99 b0) + 6 steps (tools: the recurrence iterated over every closest approach).  Then the jump's first case: far_need's 71 steps.
   // So a march with `left` steps may take b0 = 2.05 rho / (left - 84): 128 steps -> b0 = rho / 21 (C4: 0.16, clearance 0.37).
   if (dev->far_end != 0 && reach + kmax >= 1.05) {
     dev->clear_k = (float)((smooth ? 1.01 * kmax : 0.0) + 1e-3 * (1.0 + reach));
@@ -533,16 +542,28 @@ int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out) {
       std::snprintf(buf, sizeof buf, "scene: primitive table needs 1..%d rows (got %d)", RM_MAX_PRIMS, desc->nprims);
       return fail(ctx, RM_ERR_INVALID, buf);
     }
-    int shapes = 0;
+    int shapes = 0, kind_of_rows = -1;
     for (int i = 0; i < desc->nprims; i++) {
       const RmPrim& p = desc->prims[i];
       const int type = p.type & 0xff, op = (p.type >> 8) & 0xff;
-      if (type > RM_PRIM_FOLD || op > RM_OP_INTERSECT || (p.type >> 24) != 0) {
+      if (type > RM_PRIM_KIND || op > RM_OP_INTERSECT || (p.type >> 24) != 0) {
         std::snprintf(buf, sizeof buf, "scene: row %d: unknown primitive/operator 0x%x", i, p.type);
         return fail(ctx, RM_ERR_INVALID, buf);
       }
       const int surface = (p.type >> 16) & 0xff;
-      if (surface > desc->nsurfaces || (surface != 0 && type != RM_PRIM_SPHERE && type != RM_PRIM_BOX)) {
+      if (type == RM_PRIM_KIND) {
+        const int kind = (int)p.size[0];
+        if ((float)kind != p.size[0] || (kind != RM_SCENE_MANDELBULB && kind != RM_SCENE_SPHERE_LATTICE)) {
+          std::snprintf(buf, sizeof buf, "scene: row %d: a kind row evaluates RM_SCENE_MANDELBULB or RM_SCENE_SPHERE_LATTICE (size[0] = %g)", i, (double)p.size[0]);
+          return fail(ctx, RM_ERR_INVALID, buf);
+        }
+        if (kind_of_rows >= 0 && kind_of_rows != kind) return fail(ctx, RM_ERR_INVALID, "scene: the kind rows of a table evaluate ONE kind (its parameters are the scene's parameter block)");
+        kind_of_rows = kind;
+        if (kind == RM_SCENE_MANDELBULB && !(desc->params[RM_P_BULB_ITERATIONS] >= 0.0f && desc->params[RM_P_BULB_ITERATIONS] <= 64.0f))
+          return fail(ctx, RM_ERR_INVALID, "scene: mandelbulb iterations must be in 0..64");
+        if (kind == RM_SCENE_SPHERE_LATTICE && !(desc->params[RM_P_LATTICE_PERIOD] > 0.0f)) return fail(ctx, RM_ERR_INVALID, "scene: the lattice's period must be > 0");
+      }
+      if (surface > desc->nsurfaces || (surface != 0 && type != RM_PRIM_SPHERE && type != RM_PRIM_BOX && type != RM_PRIM_KIND)) {
         std::snprintf(buf, sizeof buf, "scene: row %d: surface %d of %d (only shape rows name a surface)", i, surface, desc->nsurfaces);
         return fail(ctx, RM_ERR_INVALID, buf);
       }
@@ -558,7 +579,7 @@ int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out) {
         std::snprintf(buf, sizeof buf, "scene: row %d: fold needs scale > 0", i);
         return fail(ctx, RM_ERR_INVALID, buf);
       }
-      const bool shape = type == RM_PRIM_SPHERE || type == RM_PRIM_BOX;
+      const bool shape = type == RM_PRIM_SPHERE || type == RM_PRIM_BOX || type == RM_PRIM_KIND;
       if (shape && op == RM_OP_SMOOTH_UNION && !(p.k > 0.0f) && shapes > 0) {
         std::snprintf(buf, sizeof buf, "scene: row %d: smooth union needs k > 0", i);
         return fail(ctx, RM_ERR_INVALID, buf);
@@ -581,16 +602,18 @@ int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out) {
   s->dev.kind = desc->kind;
   s->dev.nprims = desc->kind == RM_SCENE_TABLE ? desc->nprims : 0;
   if (desc->kind == RM_SCENE_TABLE) {
-    bool spheres_smooth = true, domain = false, boxes = false, surfaces = false;
+    bool spheres_smooth = true, domain = false, boxes = false, surfaces = false, kinds = false;
     for (int i = 0; i < desc->nprims; i++) {
       const int type = desc->prims[i].type & 0xff, op = (desc->prims[i].type >> 8) & 0xff;
       if (((desc->prims[i].type >> 16) & 0xff) != 0) surfaces = true;
       if (type != RM_PRIM_SPHERE || (i > 0 && op != RM_OP_SMOOTH_UNION)) spheres_smooth = false;
       if (type == RM_PRIM_REPEAT || type == RM_PRIM_FOLD) domain = true;
       if (type == RM_PRIM_BOX) boxes = true;
+      if (type == RM_PRIM_KIND) kinds = true;
     }
-    s->dev.table_flags = (spheres_smooth ? RM_TABLE_SPHERES_SMOOTH : 0) | (domain ? RM_TABLE_HAS_DOMAIN : 0) | (boxes ? 0 : RM_TABLE_NO_BOXES) |
-                         (surfaces ? RM_TABLE_HAS_SURFACES : 0);
+    // (RM_TABLE_NO_BOXES promises a non-finite distance at a non-finite point: not said of a kind's estimator, so a kind row withdraws it)
+    s->dev.table_flags = (spheres_smooth ? RM_TABLE_SPHERES_SMOOTH : 0) | (domain ? RM_TABLE_HAS_DOMAIN : 0) | (boxes || kinds ? 0 : RM_TABLE_NO_BOXES) |
+                         (surfaces ? RM_TABLE_HAS_SURFACES : 0) | (kinds ? RM_TABLE_HAS_KIND : 0);
     if (spheres_smooth && desc->nprims >= 2 && desc->nprims * 3 <= RM_MAX_PRIMS * 2) {  // one smooth-union radius for the whole table (the usual case): it travels as a kernel argument, and a compact image of the rows fits behind them in LDS
       bool one_k = true;
       for (int i = 2; i < desc->nprims; i++) one_k = one_k && desc->prims[i].k == desc->prims[1].k;
@@ -625,21 +648,10 @@ int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out) {
   if (desc->kind == RM_SCENE_TABLE) {
     CullGrid g;
     CullBuild build;
-    if (table_cull_params(desc, &g, &build)) {
-      const size_t bytes = ((size_t)g.n * g.n * g.n * (size_t)g.levels + 1) * (size_t)g.words * sizeof(unsigned long long);
-      hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_cull), bytes);
-      build.prims = s->d_prims;
-      build.cells = s->d_cull;
-      if (e == hipSuccess) e = rm::launch_cull_build(build, ctx->stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-      if (e != hipSuccess) {
-        if (s->d_cull) (void)hipFree(s->d_cull);
-        if (s->d_prims) (void)hipFree(s->d_prims);
-        delete s;
-        return fail(ctx, RM_ERR_DEVICE, std::string("rm_scene_create: ") + hipGetErrorString(e));
-      }
-      g.cells = s->d_cull;
-      s->dev.cull = g;
+    if (table_cull_params(desc, &g, &build)) {  // built on first use: scene_cull_grid
+      s->cull_wanted = true;
+      s->cull_grid = g;
+      s->cull_build = build;
     }
   }
   if (s->dev.table_flags & RM_TABLE_HAS_SURFACES) {  // entry 0 = the scene's own material block, then the surfaces as given
@@ -872,6 +884,25 @@ int rm_buffer_upload(rm_ctx* ctx, void* device_ptr, const void* host, size_t byt
   return RM_OK;
 }
 
+// The culling grid of a scene that has one coming (rm_scene_create), before the first fast-build call that reads it: one allocation,
+// one build kernel and one wait on the context's stream, once per scene.  A failure to allocate is not an error: the fold of every
+// row gives the same bits.
+static void scene_cull_grid(rm_ctx* ctx, rm_scene* s, int flags) {
+  if (!s->cull_wanted || !(flags & RM_RENDER_FAST) || (flags & RM_RENDER_NO_CULL)) return;
+  s->cull_wanted = false;
+  CullGrid g = s->cull_grid;
+  CullBuild build = s->cull_build;
+  const size_t bytes = ((size_t)g.n * g.n * g.n * (size_t)g.levels + 1) * (size_t)g.words * sizeof(unsigned long long);
+  if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&s->d_cull), bytes) != hipSuccess) { (void)hipGetLastError(); s->d_cull = nullptr; return; }
+  build.prims = s->d_prims;
+  build.cells = s->d_cull;
+  hipError_t e = rm::launch_cull_build(build, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) { (void)hipGetLastError(); (void)hipFree(s->d_cull); s->d_cull = nullptr; return; }
+  g.cells = s->d_cull;
+  s->dev.cull = g;
+}
+
 // ---- the hot path ---------------------------------------------------------------
 
 static int build_params(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* u, const RmRect* tile, int flags,
@@ -901,6 +932,7 @@ static int build_params(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniform
     l1 = (y1 > fb->row_begin + fb->row_count ? fb->row_begin + fb->row_count : y1) - fb->row_begin;
   }
   *empty = x1 <= x0 || l1 <= l0;
+  scene_cull_grid(ctx, scene, flags);
   P->u = *u;
   P->scene = scene->dev;
   P->color = fb->plane[0];
@@ -1106,7 +1138,7 @@ static hipError_t launch_wavefront(rm_ctx* ctx, const KParams& P, int flags) {
 static bool prefer_wavefront(const KParams& P, int flags) {
   if (flags & RM_RENDER_FAST) return false;
   if (P.u.renderMode == 1) return false;
-  if (P.scene.table_flags & RM_TABLE_HAS_SURFACES) return false;  // (see uses_wavefront)
+  if (P.scene.table_flags & (RM_TABLE_HAS_SURFACES | RM_TABLE_HAS_KIND)) return false;  // (see uses_wavefront)
   if ((long long)P.tw * (long long)P.th < (1ll << 24)) return false;
   return P.scene.kind == RM_SCENE_TABLE && P.scene.nprims >= 16;
 }
@@ -1116,7 +1148,7 @@ static bool prefer_wavefront(const KParams& P, int flags) {
 // stage has no scene table staged -- so such scenes render with the pixel kernel whatever the flags ask for (same results).
 static bool uses_wavefront(const rm_ctx* ctx, const KParams& P, int flags) {
   if (ctx->gl_stack && !(flags & RM_RENDER_FAST)) return false;
-  if (P.scene.table_flags & RM_TABLE_HAS_SURFACES) return false;
+  if (P.scene.table_flags & (RM_TABLE_HAS_SURFACES | RM_TABLE_HAS_KIND)) return false;
   return (flags & RM_RENDER_WAVEFRONT) ? true : (flags & RM_RENDER_MEGAKERNEL) ? false : prefer_wavefront(P, flags);
 }
 
@@ -1628,6 +1660,7 @@ int rm_probe(rm_ctx* ctx, rm_scene* scene, int what, const float* in, int n, flo
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_out), out_bytes);
   if (e == hipSuccess) e = hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
+    scene_cull_grid(ctx, scene, flags);
     ProbeParams P{scene->dev, d_in, d_out, n, what, param, (flags & RM_RENDER_FAST) ? ctx->retire_eps : 0.0f, (flags & RM_RENDER_NO_FAR_JUMP) ? 1 : 0};
     if (P.no_far_jump) P.scene.far_end = 0, P.scene.clear_rho = 0.0f;
     if (flags & RM_RENDER_NO_CULL) P.scene.cull.cells = nullptr;

@@ -339,7 +339,6 @@ template <class M> RM_DEV float op_smooth_union(float d1, float d2, float k) {
 
 template <int KIND>
 struct Sdf;
-
 // The exact far-field exits of the march -- the jump, the miss, the clear miss, the shadow ray's certain comparison -- are arguments
 // about the scene's distance bound with a 1e-3 rounding allowance per product: they do not depend on the arithmetic policy, and
 // since round 4 the parity build takes them too (round 3 compiled them into the fast build only).  Not the GL stack's arithmetic:
@@ -357,13 +356,15 @@ template <class M> struct ExactExits { static constexpr bool value = !RM_GL_STAC
 // real directions are unit and rarely tangential -- but the jump is only exact if the bound is.  The count taken exactly per step,
 // 71 - floor(log2 r), would let a few more budgets jump and costs the sphere-grid kernel, whose march is short, 12 %.)
 RM_DEV int far_need(float r2, float far_r2) { return r2 >= far_r2 * 2.5e11f ? 50 : (r2 >= far_r2 * 2500.0f ? 63 : 71); }
+// (tests/test_far_bounds_cpu.py iterates this recurrence in double precision for R' = 1e-6 .. 5e8 and asserts the three tiers, the
+// miss's 90 and the shadow exit's growth bound; tests/test_gpu_far_field.py constructs these worst cases on the GPU.)
 // The conditions all those jumps share: a unit direction without a zero component (0 x Inf = NaN), and a ray that is certain to
 // escape with steps to spare --
 //  * outside (r^2 > far_r2 = (2 Rp)^2, Rp = R' + 1/2) and not moving inward, far_need() steps left (at most 71); or
 //  * about to MISS the scene: the ray's line ahead stays m >= 1.25 Rp from the origin.  All along it d >= |x| - Rp >= Rp / 4, so
 //    the march never settles: one step brings a ray from far inside to within Rp of its closest point (d >= the distance still to
 //    go, minus Rp), 12 steps of >= Rp / 4 (13 with |dir|^2 = 0.98 and the rounding) take it from there to 2 Rp beyond, where
-//    |x| >= sqrt(1.25^2 + 4) Rp > 2 Rp and it moves outward: the first case, from r ~ 2 Rp -- 72 steps.  Asked for: 72 + 18 left.
+//    |x| >= sqrt(1.25^2 + 4) Rp > 2 Rp and it moves outward: the first case, from r ~ 2 Rp -- far_need's 71 steps.  Asked for: 90 left (tests/test_far_bounds_cpu.py test_miss_budget iterates it).
 //    (m^2 = r^2 - (p.dir)^2 / |dir|^2 cancels: only taken where r^2 < 1000 far_r2, against the 2.4 % between 0.4 and 1.25^2 / 4; a ray
 //    cast from 10^6 away -- the shadow ray of a sky pixel, raymarcher.frag:279,354-362 -- is looked at again after its first step.)
 //    Three quarters of the sky pixels' shadow rays of BASELINE's C4 end here after one evaluation instead of ten.
@@ -478,20 +479,28 @@ struct Sdf<RM_SCENE_TABLE> {
     const v3 q = p - V(r.x, r.y, r.z);
     return FM::sqrt(FM::fma(q.z, q.z, FM::fma(q.y, q.y, q.x * q.x))) - r.w;
   }
-  // one smooth-union radius for the whole table (RM_TABLE_UNIFORM_K): the fold is as much LDS-bound as VALU-bound -- half the LDS traffic
+  // one smooth-union radius for the whole table (RM_TABLE_UNIFORM_K): the compact image, one ds_read_b128 per row instead of two
   static RM_DEV float eval_spheres_one_k(const DevScene& sc, const SceneLds& lds, v3 p) {
     const int n = sc.nprims;
     const float k = sc.p[0], half_inv_k = sc.p[1];
     const float4* rows = &lds.rows[2 * n];  // the compact image (stage)
     float d = sphere_row1(rows[0], p);
     int i = 1;
-    for (; i + 1 < n; i += 2) {
-      const float4 r0 = rows[i], r1 = rows[i + 1];
+    // four rows per trip (round 4): one address register with immediate offsets and four reads in flight; C4 12.19 -> 11.99 ms, C5 154.8 ->
+    // 148.7, their 1/8 stripes -5 %.  (Two rows per trip with the next two read ahead: C4 11.79, C5 152.1; four with a rotating read-ahead
+    // of two: no gain over two, 24 registers of rows.  With HALF the LDS reads and the same arithmetic -- a diagnostic build -- the fold
+    // is not faster at all, 12.9 against 12.1 ms: it is not LDS-bound; and at 6 / 5 waves per SIMD, where nothing spills, C5 takes
+    // 177 / 235 ms: it lives on occupancy.)
+    for (; i + 3 < n; i += 4) {
+      const float4 r0 = rows[i], r1 = rows[i + 1], r2 = rows[i + 2], r3 = rows[i + 3];
       const float d0 = sphere_row1(r0, p), d1 = sphere_row1(r1, p);
       d = smooth_row(d, d0, k, half_inv_k);
       d = smooth_row(d, d1, k, half_inv_k);
+      const float d2 = sphere_row1(r2, p), d3 = sphere_row1(r3, p);
+      d = smooth_row(d, d2, k, half_inv_k);
+      d = smooth_row(d, d3, k, half_inv_k);
     }
-    if (i < n) d = smooth_row(d, sphere_row1(rows[i], p), k, half_inv_k);
+    for (; i < n; i++) d = smooth_row(d, sphere_row1(rows[i], p), k, half_inv_k);
     return d;
   }
   static RM_DEV float eval_spheres_smooth(const DevScene& sc, const SceneLds& lds, v3 p) {
@@ -658,7 +667,7 @@ struct Sdf<RM_SCENE_TABLE> {
   // A ray that passes every shape of the table at a distance (round 3; fast policy; rm_api.hip table_far_field has the argument): the
   // scene's bounding sphere is a poor judge of that -- a camera looking AT the scene sends every ray through it -- but the shapes'
   // own bounding spheres are not.  If the half-line p + t dir, t >= 0, stays k_max + b0 clear of every one of them, the march never
-  // settles, leaves the scene within left - 72 steps (b0 is chosen for the steps there are) and ends where the jump ends: most of
+  // settles, leaves the scene within left - 71 steps (b0 is chosen for the steps there are; 84 are set aside) and ends where the jump ends: most of
   // C4's sky takes this exit at the first step of its camera ray instead of marching past the cluster for seven.  One pass over
   // the rows, ~15 instructions each (about one evaluation); asked of a ray once, at the start of its march, and only from outside
   // the scene's own sphere (a shadow ray leaving a surface has no clearance to show).  dist^2 = |v|^2 - (v.dir)^2 / |dir|^2 from
@@ -707,7 +716,10 @@ struct Sdf<RM_SCENE_TABLE> {
   // shape row with the smallest distance term names -- the terms of eval()'s fold, row by row, before their operators --
   // the earliest row on a tie; a NaN term never wins (`<` is false), so a point whose terms are all NaN has the first
   // shape row's surface.  The composer emits the same loop as GLSL (scene.py rmSurfaceIndex).
+  // a RM_PRIM_KIND row's term: the scene kind's own estimator at q - centre, its parameters in the scene block (include/hip_raymarch.h)
   template <class M>
+  static RM_DEV float kind_row(const DevScene& sc, const SceneLds& lds, int kind, v3 at);
+  template <class M, bool KINDS = false>
   static RM_DEV int surface_index(const DevScene& sc, const SceneLds& lds, v3 p) {
     const bool domain = (sc.table_flags & RM_TABLE_HAS_DOMAIN) != 0;  // kernel-uniform
     float best = 0.0f, factor = 1.0f;
@@ -732,6 +744,7 @@ struct Sdf<RM_SCENE_TABLE> {
       }
       float di;
       if (prim == RM_PRIM_SPHERE) di = sdf_sphere<M>(q, c, b.y);
+      else if (KINDS && prim == RM_PRIM_KIND) di = kind_row<M>(sc, lds, __builtin_amdgcn_readfirstlane((int)b.y), q - c);
       else di = sd_box<M>(q - c, V(b.y, b.z, b.w));
       if (domain) di = di * factor;
       if (first || di < best) { best = di; surface = (type >> 16) & 0xff; }
@@ -745,7 +758,7 @@ struct Sdf<RM_SCENE_TABLE> {
     if (M::fast && sc.cull.cells != nullptr) return eval_general_culled<M>(sc, lds, p);  // kernel-uniform
     return eval_general<M>(sc, lds, p);
   }
-  template <class M>
+  template <class M, bool KINDS = false>
   static RM_DEV float eval_general(const DevScene& sc, const SceneLds& lds, v3 p) {
     const bool domain = (sc.table_flags & RM_TABLE_HAS_DOMAIN) != 0;  // kernel-uniform
     float d = 0.0f, factor = 1.0f;
@@ -769,6 +782,7 @@ struct Sdf<RM_SCENE_TABLE> {
       }
       float di;
       if (prim == RM_PRIM_SPHERE) di = sdf_sphere<M>(q, c, b.y);
+      else if (KINDS && prim == RM_PRIM_KIND) di = kind_row<M>(sc, lds, __builtin_amdgcn_readfirstlane((int)b.y), q - c);
       else di = sd_box<M>(q - c, V(b.y, b.z, b.w));
       if (domain) di = di * factor;
       if (first) { d = di; first = false; continue; }
@@ -1090,7 +1104,19 @@ struct Sdf<RM_KIND_TABLE_SMOOTH> : Sdf<RM_SCENE_TABLE> {
     else return Sdf<RM_SCENE_TABLE>::template eval<M>(sc, lds, p);
   }
 };
-template <int KIND> struct IsTable { static constexpr bool value = KIND == RM_SCENE_TABLE || KIND == RM_KIND_TABLE_BIG || KIND == RM_KIND_TABLE_SMOOTH; };
+// ... and a table with RM_PRIM_KIND rows (round 4): the general fold with the kind rows' branch compiled in -- a Mandelbulb's or a
+// lattice's evaluator inlined into the row loop -- so that the other tables' kernels do not carry it.  No far-field exits (their
+// arguments are about spheres and boxes), no row culling, no ray compaction; the pixel kernel only (rm_api.hip uses_wavefront).
+#define RM_KIND_TABLE_KINDS (RM_SCENE_KIND_COUNT + 3)
+template <>
+struct Sdf<RM_KIND_TABLE_KINDS> : Sdf<RM_SCENE_TABLE> {
+  template <class M>
+  static RM_DEV float eval(const DevScene& sc, const SceneLds& lds, v3 p) { return Sdf<RM_SCENE_TABLE>::template eval_general<M, true>(sc, lds, p); }
+  template <class M>
+  static RM_DEV int surface_index(const DevScene& sc, const SceneLds& lds, v3 p) { return Sdf<RM_SCENE_TABLE>::template surface_index<M, true>(sc, lds, p); }
+  static RM_DEV bool far_jump_applies(const DevScene&) { return false; }
+};
+template <int KIND> struct IsTable { static constexpr bool value = KIND == RM_SCENE_TABLE || KIND == RM_KIND_TABLE_BIG || KIND == RM_KIND_TABLE_SMOOTH || KIND == RM_KIND_TABLE_KINDS; };
 // the long tables' kernels: where an evaluation is dear enough for the per-march and per-step tests of the far field's finer exits
 // (clear_miss, far_shadow_escape) -- on a 5-row table they cost 8 % and save nothing
 template <int KIND> struct IsBigTable { static constexpr bool value = KIND == RM_KIND_TABLE_BIG || KIND == RM_KIND_TABLE_SMOOTH; };
@@ -1113,7 +1139,7 @@ template <> struct FusedJump<RM_KIND_BULB8> { static constexpr bool value = true
 
 // kernels that may evaluate the power-8 Mandelbulb on the fast policy start with this (FM::omod_mode)
 template <int KIND, bool FAST> RM_DEV void enter_math_mode() {
-  if (FAST && (KIND == RM_SCENE_MANDELBULB || KIND == RM_KIND_BULB8)) FM::omod_mode();
+  if (FAST && (KIND == RM_SCENE_MANDELBULB || KIND == RM_KIND_BULB8 || KIND == RM_KIND_TABLE_KINDS)) FM::omod_mode();
 }
 
 // per-level scale factors pow(base, i), i = first .. first + RM_TAB_POW - 1,
@@ -1273,6 +1299,13 @@ struct Sdf<RM_SCENE_KIFS_BOX> {
     return sd_box<M>(t * csf, V(csf, csf, csf));
   }
 };
+
+// the kinds a table row can evaluate (RM_PRIM_KIND), now that they are defined
+template <class M>
+RM_DEV float Sdf<RM_SCENE_TABLE>::kind_row(const DevScene& sc, const SceneLds& lds, int kind, v3 at) {
+  if (kind == RM_SCENE_SPHERE_LATTICE) return Sdf<RM_SCENE_SPHERE_LATTICE>::template eval<M>(sc, lds, at);
+  return Sdf<RM_SCENE_MANDELBULB>::template eval<M>(sc, lds, at);
+}
 
 // ---- material functions (Validate.tsx:18-51 with the constants of RmMaterial)
 

@@ -10,6 +10,7 @@
 #define RM_TABLE_HAS_DOMAIN 2      /* the table has domain rows (RM_PRIM_REPEAT / RM_PRIM_FOLD) */
 #define RM_TABLE_NO_BOXES 8         /* no RM_PRIM_BOX row: the sdf of a point with a non-finite coordinate is itself non-finite */
 #define RM_TABLE_UNIFORM_K 4       /* RM_TABLE_SPHERES_SMOOTH with one k for every fold: k in p[0], 0.5 / k in p[1] */
+#define RM_TABLE_HAS_KIND 32      /* some shape row evaluates a scene kind's estimator (RM_PRIM_KIND): its own pixel kernel, no far-field exits, no row culling */
 #define RM_TABLE_HAS_SURFACES 16   /* some shape row names a surface (RmPrim.type bits 16..23): the material functions depend on the position */
 
 #define RM_BATCH_MAX 8  /* samples one pixel-kernel launch can render (KParams::batch) */
@@ -108,7 +109,8 @@ struct DevScene {
   int nsurfaces;
   // The far field of a primitive table without domain rows (rm_device.hpp Sdf<RM_SCENE_TABLE>::far_jump; set by rm_scene_create):
   // far_end = 0: no jump; 1: an escaping ray ends at +-Inf by the sign of its direction components; 2: at (NaN, NaN, NaN).
-  // far_r2 = (2 R')^2 with R' = the radius of a sphere about the origin that holds every shape, plus the largest smooth-union radius k (a chain of smooth unions stays within k of the minimum).
+  // far_r2 = (2 R' + 1)^2 with R' = the radius of a sphere about the origin that holds every shape, plus 1.01 x the largest smooth-union radius k (a chain of
+  // smooth unions stays within k of the minimum): rm_api.hip table_far_field; far_escape's Rp is R' + 1/2.
   int far_end;
   float far_r2;
   // a ray that passes every shape of a table at a distance (rm_device.hpp Sdf<RM_SCENE_TABLE>::clear_miss): the clearance beyond a
@@ -153,7 +155,7 @@ struct KParams {
 // a table long enough for the compacting pixel kernel (rm_device.hpp RM_KIND_TABLE_BIG); launcher and grid computation agree through this
 #define RM_TABLE_BIG_ROWS 16
 __host__ __device__ inline bool rm_table_big(const KParams& P) {
-  return P.scene.kind == RM_SCENE_TABLE && P.scene.nprims >= RM_TABLE_BIG_ROWS && P.u.renderMode == 0;
+  return P.scene.kind == RM_SCENE_TABLE && P.scene.nprims >= RM_TABLE_BIG_ROWS && P.u.renderMode == 0 && !(P.scene.table_flags & RM_TABLE_HAS_KIND);
 }
 
 // image row of a local (plane) row

@@ -12,6 +12,7 @@ GLSL text.
 from __future__ import annotations
 
 import math
+from collections import OrderedDict
 from typing import Callable, Dict, Generator, Iterable, Optional, Tuple
 
 from . import abi
@@ -192,6 +193,9 @@ def tile_rect(schema: dict, x_part: int, y_part: int, reference_scissor: bool = 
     return abi.RmRect(x1, y1, x2 - x1, y2 - y1)
 
 
+SCENE_CACHE_ENTRIES = 64  # scenes a RenderJobContext keeps (least recently used out first)
+
+
 class RenderJobContext:
     """Counterpart of RenderJobContext (RenderJobExecutor.tsx:32-54) +
     loadRenderJobContext (LoadRenderJobContext.tsx:162-287): the native
@@ -230,11 +234,17 @@ class RenderJobContext:
 
             dev = torch.device(self.group.device)
             if dev.type == "cuda":
-                # not torch's default stream: its handle is NULL, which the context's own non-blocking stream is not ordered with
+                # not torch's default stream: its handle is NULL, which the context's own non-blocking stream is not ordered with.
+                # The stream is made torch's CURRENT stream of this thread -- the collective of a present is enqueued from it -- and
+                # close() puts the previous one back: a host with torch work of its own scopes the context (`with ctx:` / close()).
+                self._prev_stream = torch.cuda.current_stream(dev)
                 self.stream = torch.cuda.Stream(device=dev)
                 torch.cuda.set_stream(self.stream)
                 self.native.set_stream(self.stream.cuda_stream)
-        self._scenes: Dict[bytes, object] = {}
+        # programCache: by description; bounded (the reference's cache grows with every edit of the shader text -- a page's lifetime; a
+        # long-running host that animates scene parameters would otherwise keep a device table, and for long CSG tables a culling
+        # grid of 5-14 MB, per distinct scene).  Least recently used out first, its handle destroyed.
+        self._scenes: "OrderedDict[bytes, object]" = OrderedDict()
         self._live: Dict[Tuple[int, int, int], object] = {}
         self._purgatory: list = []
 
@@ -250,7 +260,38 @@ class RenderJobContext:
             except native.RmError as e:  # cached like a failed compile
                 hit = {"type": "fragment", "infoLog": str(e)}
             self._scenes[key] = hit
+            while len(self._scenes) > SCENE_CACHE_ENTRIES:
+                _, old = self._scenes.popitem(last=False)
+                if not isinstance(old, dict) and hasattr(old, "destroy"):
+                    old.destroy()  # (rm_scene_destroy waits for the renders that use it)
+        else:
+            self._scenes.move_to_end(key)
         return hit
+
+    def close(self):
+        """Destroys the cached scenes and framebuffers and, for a sharded context on a GPU, makes the stream that was torch's
+        current one before the context was made current again.  (The native context is the caller's to close when it was passed in.)"""
+        for h in self._scenes.values():
+            if not isinstance(h, dict) and hasattr(h, "destroy"):
+                h.destroy()
+        self._scenes.clear()
+        for fb in list(self._live.values()) + [fb for _, fb in self._purgatory]:
+            fb.destroy()
+        self._live.clear()
+        self._purgatory.clear()
+        if self.stream is not None:
+            import torch
+
+            self.native.sync()
+            torch.cuda.set_stream(self._prev_stream)
+            self.stream = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     # fbo.create: LoadRenderJobContext.tsx:186-223
     def fbo_create(self, width: int, height: int, frameid: int):
@@ -349,8 +390,12 @@ def do_render_job(schema: dict, context: RenderJobContext):
                     samples += k
                     left -= k
         context.fbo_delete(r["width"], r["height"], r["frameid"])  # :333-337
-        if not sharded:
+        # The job's last word, sharded or not: wait for the device once, so that a failure of an asynchronous launch becomes THIS
+        # job's {success: False} and not an exception out of some later call (errors are values: RenderJobExecutor.tsx:56-68).
+        try:
             context.native.sync()
+        except Exception as e:
+            return {"success": False, "why": {"type": "general", "infoLog": "render failed: " + str(e)}}
         present(schema, context, fb, samples)
         return {"success": True}
 

@@ -19,6 +19,8 @@ export class CsgScene extends Scene {
   sphere(center: Vec3, radius: number, surface?: Surface): this; box(center: Vec3, halfExtents: Vec3, surface?: Surface): this;
   /** domain operators: transform the point the FOLLOWING primitives are evaluated at (sphere-grid.glsl's repeat; one level of tree.glsl's fold) */
   repeat(period: Vec3): this; fold(scale: number, offset: Vec3, angles?: Vec3): this;
+  /** a shape whose distance term is another scene kind's estimator at p - center (RM_PRIM_KIND): a Mandelbulb cut by a box is table data */
+  shape(scene: Scene, center?: Vec3, surface?: Surface): this;
   glsl(): string;
 }
 export class Mandelbulb extends Scene { constructor(power?: number, iterations?: number, bailout?: number, material?: Partial<Material>); }

@@ -21,7 +21,7 @@ const addon = require("./rm_napi.node");
 const RM = {
   MAX_BOUNCES: 10, MAX_LIGHTS: 10,
   SCENE_TABLE: 0, SCENE_MANDELBULB: 1, SCENE_SPHERE_GRID: 2, SCENE_SPHERE_LATTICE: 3, SCENE_MENGER: 4, SCENE_KIFS_TREE: 5, SCENE_KIFS_BOX: 6,
-  PRIM_SPHERE: 0, PRIM_BOX: 1, PRIM_REPEAT: 2, PRIM_FOLD: 3, OP_UNION: 0, OP_SMOOTH_UNION: 1, OP_SUBTRACT: 2, OP_INTERSECT: 3,
+  PRIM_SPHERE: 0, PRIM_BOX: 1, PRIM_REPEAT: 2, PRIM_FOLD: 3, PRIM_KIND: 4, OP_UNION: 0, OP_SMOOTH_UNION: 1, OP_SUBTRACT: 2, OP_INTERSECT: 3,
   RENDER_STRICT: 0, RENDER_FAST: 1, RENDER_COLOR_ONLY: 2, RENDER_MEGAKERNEL: 4, RENDER_WAVEFRONT: 16, RENDER_NO_OVERLAP: 32, RENDER_NO_FAR_JUMP: 64, RENDER_NO_CULL: 128,
 };
 
@@ -106,11 +106,23 @@ class CsgScene extends Scene {
   }
   sphere(center, radius, surface) { this.prims.push({ prim: RM.PRIM_SPHERE, op: this._op, k: this._k, center, size: [radius, 0, 0], surface: this._surface(surface) }); return this; }
   box(center, half, surface) { this.prims.push({ prim: RM.PRIM_BOX, op: this._op, k: this._k, center, size: half, surface: this._surface(surface) }); return this; }
+  // a shape whose distance term is another scene kind's own estimator at p - center (RM_PRIM_KIND, include/hip_raymarch.h): a Mandelbulb
+  // (or a kind 3 lattice), folded like a sphere or a box -- new CsgScene().shape(new Mandelbulb()).intersect().box(...) is a Mandelbulb cut
+  // by a box.  One kind with one parameter set per table (they travel in the scene's parameter block).  The GLSL text of such a table
+  // is the Python composer's (scene.py CsgScene.shape); glsl() here throws.
+  shape(scene, center = [0, 0, 0], surface) {
+    if (scene.kind !== RM.SCENE_MANDELBULB && scene.kind !== 3) throw new TypeError("shape(): the kinds a table row can evaluate are the Mandelbulb and the sphere lattice");
+    if (this._kind !== undefined && (this._kind !== scene.kind || JSON.stringify(this.params) !== JSON.stringify(scene.params))) throw new TypeError("shape(): a table evaluates ONE kind with one set of parameters");
+    this._kind = scene.kind; this.params = scene.params.slice();
+    this.prims.push({ prim: RM.PRIM_KIND, op: this._op, k: this._k, center, size: [scene.kind, 0, 0], surface: this._surface(surface) });
+    return this;
+  }
   // domain operators (include/hip_raymarch.h): they transform the point the FOLLOWING primitives are evaluated at
   repeat(period) { this.prims.push({ prim: RM.PRIM_REPEAT, op: 0, k: 0, center: [0, 0, 0], size: period }); return this; }
   fold(scale, offset, angles = [0, 0, 0]) { this.prims.push({ prim: RM.PRIM_FOLD, op: 0, k: scale, center: offset, size: angles }); return this; }
   glsl() {  // the reference's scene contract: float sdf(vec3); helpers sdfSphere/sdBox come from raymarcher.frag:74,108
     const lines = [];
+    if (this.prims.some((n) => n.prim === RM.PRIM_KIND)) throw new Error("glsl(): a table with kind rows gets its text from the Python composer (scene.py CsgScene.shape)");
     const isShape = (n) => n.prim === RM.PRIM_SPHERE || n.prim === RM.PRIM_BOX;
     const shapes = this.prims.filter(isShape), domain = shapes.length !== this.prims.length;
     if (shapes.slice(1).some((p) => p.op === RM.OP_SMOOTH_UNION))
@@ -213,16 +225,23 @@ function tileRect(schema, xp, yp) {
   return new Int32Array([x1, y1, x2 - x1, y2 - y1]);
 }
 
+// A scene cache keeps this many entries (a Map iterates in insertion order: the first key is the least recently used).  The
+// reference's programCache grows with every edit of the shader text, for a page's lifetime; a long-running host that animates scene
+// parameters would otherwise keep a device table -- and for a long CSG table a culling grid of 5-14 MB -- per distinct scene.
+const SCENE_CACHE_ENTRIES = 64;
+function evictScenes(map, destroy) { while (map.size > SCENE_CACHE_ENTRIES) { const k = map.keys().next().value; const v = map.get(k); map.delete(k); destroy(v); } }
+
 class RenderJobContext {  // RenderJobContext + loadRenderJobContext (LoadRenderJobContext.tsx:162-287)
   constructor(device = 0, flags = RM.RENDER_STRICT) {
     this.ctx = addon.ctxCreate(device); this.flags = flags; this.scenes = new Map(); this.live = new Map(); this.purgatory = [];
   }
-  getScene(scene) {  // programCache.getProgram: results AND errors are cached (ShaderCache.tsx:91-119)
+  getScene(scene) {  // programCache.getProgram: results AND errors are cached (ShaderCache.tsx:91-119); bounded, least recently used out first
     const key = scene.key();
     if (!this.scenes.has(key)) {
       try { const d = scene.desc(); this.scenes.set(key, addon.sceneCreate(this.ctx, d.desc, d.prims, d.surfaces)); }
       catch (e) { this.scenes.set(key, { type: "fragment", infoLog: String(e.message) }); }
-    }
+      evictScenes(this.scenes, (s) => { if (!(s && s.infoLog)) addon.sceneDestroy(s); });
+    } else { const hit = this.scenes.get(key); this.scenes.delete(key); this.scenes.set(key, hit); }
     return this.scenes.get(key);
   }
   fboCreate(w, h, frameid) {  // :186-223
@@ -275,7 +294,8 @@ class ShardedRenderJobContext {
       const made = [];
       try { const d = scene.desc(); for (const c of this.ctxs) made.push(addon.sceneCreate(c, d.desc, d.prims, d.surfaces)); this.scenes.set(key, { handles: made }); }
       catch (e) { for (const h of made) addon.sceneDestroy(h); this.scenes.set(key, { type: "fragment", infoLog: String(e.message) }); }
-    }
+      evictScenes(this.scenes, (s) => { if (s.handles) for (const h of s.handles) addon.sceneDestroy(h); });
+    } else { const hit = this.scenes.get(key); this.scenes.delete(key); this.scenes.set(key, hit); }
     return this.scenes.get(key);
   }
   fboCreate(w, h, frameid) {

@@ -32,7 +32,7 @@ LIB_PATH = Path(os.environ.get("RM_LIB") or Path(__file__).resolve().parent / "l
 # every symbol include/hip_raymarch.h declares
 EXPORTS = [
     "rm_abi_version", "rm_material_default", "rm_ctx_create", "rm_ctx_destroy", "rm_last_error", "rm_ctx_set_stream",
-    "rm_ctx_set_retire_eps", "rm_ctx_set_samples_in_flight", "rm_ctx_set_cost_order", "rm_debug_counters", "rm_device_memory", "rm_sync", "rm_scene_create", "rm_scene_destroy", "rm_fb_create", "rm_fb_create_striped", "rm_fb_rows", "rm_fb_width", "rm_fb_height", "rm_fb_wrap", "rm_fb_clear", "rm_fb_destroy",
+    "rm_ctx_set_retire_eps", "rm_ctx_set_samples_in_flight", "rm_ctx_last_warning", "rm_ctx_set_cost_order", "rm_debug_counters", "rm_device_memory", "rm_sync", "rm_scene_create", "rm_scene_destroy", "rm_fb_create", "rm_fb_create_striped", "rm_fb_rows", "rm_fb_width", "rm_fb_height", "rm_fb_wrap", "rm_fb_clear", "rm_fb_destroy",
     "rm_fb_download", "rm_fb_upload", "rm_fb_device_ptr", "rm_buffer_create", "rm_buffer_destroy", "rm_buffer_download", "rm_buffer_upload", "rm_render_sample", "rm_render_samples", "rm_ctx_set_sample_batch", "rm_ctx_set_gl_stack", "rm_render_timed",
     "rm_probe", "rm_probe_camera", "rm_probe_rng", "rm_assemble_striped", "rm_assemble_striped_bytes", "rm_present", "rm_present_planes", "rm_present_device", "rm_present_rows", "rm_pack_present_rows", "rm_ctx_last_pipeline", "rm_present_sharded", "rm_present_sharded_start", "rm_present_sharded_finish", "rm_present_striped_rows", "rm_debug_cull_cell",
 ]
@@ -108,6 +108,7 @@ def load_library():
         "rm_ctx_set_stream": (ip, [vp, vp]),
         "rm_ctx_set_retire_eps": (ip, [vp, C.c_float]),
         "rm_ctx_set_samples_in_flight": (ip, [vp, C.c_int]),
+        "rm_ctx_last_warning": (C.c_char_p, [vp]),
         "rm_ctx_set_sample_batch": (ip, [vp, C.c_int]),
         "rm_ctx_set_gl_stack": (ip, [vp, C.c_int]),
         "rm_device_memory": (ip, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
@@ -230,6 +231,8 @@ class DeviceBuffer:
 
 
 class Context:
+    gl_stack_on = False
+
     def __init__(self, device: int = 0):
         self.lib = load_library()
         h = C.c_void_p()
@@ -261,7 +264,7 @@ class Context:
     def set_samples_in_flight(self, n: int):
         """Consecutive full-mode samples that may overlap on the GPU (1 = none); the planes get the same bits."""
         self._check(self.lib.rm_ctx_set_samples_in_flight(self.h, int(n)))
-        note = self.lib.rm_last_error(self.h).decode()
+        note = self.lib.rm_ctx_last_warning(self.h).decode()
         if note.startswith("warning:"):  # accepted, but the process environment will keep the samples from overlapping
             import warnings
 
@@ -281,6 +284,7 @@ class Context:
         """Parity mode: strict-flag renders, probes and presents in the arithmetic of the GL stack the goldens were
         rendered under (include/hip_raymarch.h rm_ctx_set_gl_stack)."""
         self._check(self.lib.rm_ctx_set_gl_stack(self.h, int(on)))  # True / 1: on; 2: on, with the stack's own tan
+        self.gl_stack_on = bool(on)
 
     def set_sample_batch(self, n: int):
         """Samples per launch of render_samples (0 = automatic, 1 = one launch per sample, up to 8); same bits."""

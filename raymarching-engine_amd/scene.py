@@ -193,6 +193,10 @@ class _Node:
     surface: int = 0  # 0 = the scene's material; k = the k-th Surface given to the scene's shapes
 
 
+SHAPE_PRIMS = (abi.RM_PRIM_SPHERE, abi.RM_PRIM_BOX, abi.RM_PRIM_KIND)  # rows that contribute a distance term
+KIND_SHAPES = (abi.RM_SCENE_MANDELBULB, abi.RM_SCENE_SPHERE_LATTICE)      # kinds a RM_PRIM_KIND row can evaluate
+
+
 class CsgScene(Scene):
     """Left fold of primitives: ``d = prim0; d = op_i(d, prim_i)``.
 
@@ -220,6 +224,7 @@ class CsgScene(Scene):
         self._op = abi.RM_OP_UNION
         self._k = 0.0
         self._surfaces: List[Surface] = []
+        self._kind_scene: Optional[Scene] = None  # the scene kind whose estimator the table's RM_PRIM_KIND rows evaluate
 
     def _surface(self, surface: Optional[Surface]) -> int:
         """The index a shape row carries for `surface` (0 = none: the scene's material block)."""
@@ -261,6 +266,21 @@ class CsgScene(Scene):
         self._nodes.append(_Node(abi.RM_PRIM_BOX, self._op, self._k, tuple(center), tuple(half_extents), self._surface(surface)))
         return self
 
+    def shape(self, scene: "Scene", center: Sequence[float] = (0.0, 0.0, 0.0), surface: Optional[Surface] = None):
+        """A shape whose distance term is another scene kind's own estimator at `p - center` (RM_PRIM_KIND): a Mandelbulb
+        or a SphereLattice, folded with the current operator like a sphere or a box -- ``CsgScene().shape(Mandelbulb())
+        .intersect().box(...)`` is a Mandelbulb cut by a box.  One kind (one parameter set) per table, any number of rows."""
+        if scene.kind not in KIND_SHAPES:
+            raise ValueError("shape(): the kinds a table row can evaluate are Mandelbulb and SphereLattice")
+        if self._kind_scene is not None and (self._kind_scene.kind != scene.kind or list(self._kind_scene.params()) != list(scene.params())):
+            raise ValueError("shape(): a table evaluates ONE kind with one set of parameters (they travel in the scene's parameter block)")
+        self._kind_scene = scene
+        self._nodes.append(_Node(abi.RM_PRIM_KIND, self._op, self._k, tuple(float(v) for v in center), (float(scene.kind), 0.0, 0.0), self._surface(surface)))
+        return self
+
+    def params(self):
+        return list(self._kind_scene.params()) if self._kind_scene is not None else []
+
     def repeat(self, period: Sequence[float]):
         """q = mod(q + period / 2, period) - period / 2 for the primitives that follow; every period > 0."""
         self._nodes.append(_Node(abi.RM_PRIM_REPEAT, 0, 0.0, (0.0, 0.0, 0.0), tuple(float(v) for v in period)))
@@ -283,11 +303,15 @@ class CsgScene(Scene):
         return out
 
     def sdf_glsl(self) -> str:
-        shapes = [n for n in self._nodes if n.prim in (abi.RM_PRIM_SPHERE, abi.RM_PRIM_BOX)]
+        shapes = [n for n in self._nodes if n.prim in SHAPE_PRIMS]
         if not shapes:
-            raise ValueError("a CSG scene needs at least one sphere or box")
+            raise ValueError("a CSG scene needs at least one sphere, box or kind shape")
         domain = len(shapes) != len(self._nodes)
         lines = []
+        if self._kind_scene is not None:  # the kind's own text, as a function of its own name
+            text = self._kind_scene.sdf_glsl()
+            assert text.count("float sdf(") == 1
+            lines.append(text.replace("float sdf(", "float rmKindSdf("))
         if any(n.op == abi.RM_OP_SMOOTH_UNION for n in shapes[1:]):
             lines.append(
                 "float rmSmoothUnion(float d1, float d2, float k) {"
@@ -336,6 +360,8 @@ class CsgScene(Scene):
                 continue
             if n.prim == abi.RM_PRIM_SPHERE:
                 e = f"sdfSphere({q}, {_v3(n.center)}, {_f(n.size[0])})"
+            elif n.prim == abi.RM_PRIM_KIND:
+                e = f"rmKindSdf({q} - {_v3(n.center)})"
             else:
                 e = f"sdBox({q} - {_v3(n.center)}, {_v3(n.size)})"
             if domain:
@@ -348,7 +374,7 @@ class CsgScene(Scene):
         earliest row on a tie, a NaN never wins) -- the rule the kernel and the oracle implement (rm_device.hpp
         surface_index).  Cut-offs and the sky are the scene's."""
         m = self.material
-        shapes = [n for n in self._nodes if n.prim in (abi.RM_PRIM_SPHERE, abi.RM_PRIM_BOX)]
+        shapes = [n for n in self._nodes if n.prim in SHAPE_PRIMS]
         domain = len(shapes) != len(self._nodes)
         all_surfaces = [Surface(m.diffuse, m.specular, m.roughness, m.subsurface, m.subsurface_color, m.ior)] + self._surfaces
         n = len(all_surfaces)

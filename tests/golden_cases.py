@@ -65,6 +65,19 @@ SCENES = {
         .subtract().box((0.0, 1.0, -0.5), (0.25, 0.25, 0.25), surface=S.Surface(diffuse=(0.75, 0.75, 0.125), specular=(0.125, 0.125, 0.125), roughness=0.75)),
         None,
     ),
+    # round 4: a kind as a SHAPE of a table (RM_PRIM_KIND; the composer emits the kind's own text as rmKindSdf and the fold around it):
+    # a five-round Mandelbulb cut by a box, with a sphere that names a surface carved out of it; and a lattice of small spheres kept
+    # inside a ball, standing on a slab
+    "csg_bulb_cut": (
+        lambda: S.CsgScene().shape(S.Mandelbulb(power=8.0, iterations=5, bailout=2.0)).intersect().box((0.0, 0.0, 0.25), (1.25, 1.25, 0.75))
+        .subtract().sphere((0.5, 0.375, -0.5), 0.375, surface=S.Surface(diffuse=(0.875, 0.25, 0.125), specular=(0.5, 0.5, 0.5), roughness=0.25)),
+        None,
+    ),
+    "csg_lattice_ball": (
+        lambda: S.CsgScene().sphere((0.0, 0.0, 0.0), 1.5).intersect().shape(S.SphereLattice(0.75, 0.25), center=(0.125, 0.0, 0.0))
+        .union().box((0.0, -1.75, 0.0), (2.0, 0.125, 2.0)),
+        None,
+    ),
     "mandelbulb": (lambda: S.Mandelbulb(), None),
     "lattice": (lambda: S.sphere_lattice_example(), None),
     "fractal1": (lambda: S.SphereGridFractal(), "fractal1.glsl"),
@@ -77,9 +90,9 @@ SCENES = {
 # scenes whose SDF the oracle reproduces bit for bit (only + - * / sqrt floor
 # abs min max); the others go through sin/cos/acos/atan/pow/log where
 # SwiftShader and the oracle (either of its math modes) differ in the last bits (or much more: see test tolerances)
-SDF_BIT_EXACT = ("sphere", "sphere_sss", "csg64", "csg_mixed", "csg_repeat_fold", "csg_surfaces", "lattice", "fractal1")
+SDF_BIT_EXACT = ("sphere", "sphere_sss", "csg64", "csg_mixed", "csg_repeat_fold", "csg_surfaces", "csg_lattice_ball", "lattice", "fractal1")
 # scenes with a material-function golden (tests/golden/misc_material_<name>.npz)
-MATERIAL_SCENES = ("sphere", "lattice", "csg_surfaces")
+MATERIAL_SCENES = ("sphere", "lattice", "csg_surfaces", "csg_bulb_cut")
 
 IMG_W, IMG_H = 64, 32
 
@@ -119,6 +132,10 @@ IMAGES = {
     # roughness at the moved point (:366), the subsurface branch of one shape only; and the preview's diffuse + specular (:218-219)
     "csg_surfaces_full_2b": ("csg_surfaces", 2, dict(render_mode="full", position=(0.25, 0.5, -3.5), counts=(64, 32), lights=THREE_LIGHTS)),
     "csg_surfaces_preview": ("csg_surfaces", 1, dict(render_mode="preview", position=(0.25, 0.5, -3.5), counts=(64,))),
+    # round 4: kind rows through the whole main()
+    "csg_bulb_cut_full_2b": ("csg_bulb_cut", 2, dict(render_mode="full", position=(0.25, 0.125, -1.625), counts=(48, 24), lights=LIGHT)),
+    "csg_lattice_ball_full_2b": ("csg_lattice_ball", 1, dict(render_mode="full", position=(0.25, 0.5, -3.5), counts=(48, 24), lights=LIGHT)),
+    "csg_lattice_ball_preview": ("csg_lattice_ball", 1, dict(render_mode="preview", position=(0.25, 0.5, -3.5), counts=(64,))),
 }
 
 # cast-ray goldens: scene -> (camera position, steps)
@@ -130,6 +147,7 @@ CAST = {
     "mandelbulb": ((0, 0, -2.5), 64.0),
     "menger": ((0.5, 0.5, -2.0), 48.0),
     "csg_repeat_fold": ((0.2, 0.1, -1.4), 48.0),
+    "csg_lattice_ball": ((0.25, 0.5, -3.5), 64.0),
 }
 
 

@@ -78,6 +78,12 @@ def render_gpu(ctx, sc, schema, noises, flags=STRICT, rows=None, tile=None):
     fb = ctx.create_framebuffer(r["width"], r["height"], rb, rc)
     for n in noises:
         ctx.render_sample(h, fb, J.uniforms_from_schema(schema, tuple(n)), tile, flags)
+    # the implementation that ran is the one the flags asked for -- RM_RENDER_WAVEFRONT is a request: a table whose shapes name
+    # surfaces always takes the pixel kernel (rm_api.hip uses_wavefront), and a test that renders "both implementations" of such a
+    # scene compares the pixel kernel with itself; its second check is the oracle
+    if flags & (MK | WF) and not ctx.gl_stack_on:
+        surfaces = bool(getattr(sc, "surfaces", lambda: [])()) or getattr(sc, "_kind_scene", None) is not None  # (and tables with kind rows, RM_PRIM_KIND)
+        assert ctx.last_pipeline() == ("wavefront" if flags & WF and not surfaces else "megakernel"), (ctx.last_pipeline(), flags, surfaces)
     out = [fb.download(p) for p in (0, 1, 2)]
     fb.destroy()
     h.destroy()
@@ -930,6 +936,11 @@ def _random_scene(rng):
         surfaces = [S.Surface(diffuse=tuple(rng.uniform(0.05, 0.95, 3)), specular=tuple(rng.uniform(0.05, 0.95, 3)), roughness=float(rng.uniform(0.05, 0.8)),
                               subsurface=float(rng.choice([11111115.0, 11111115.0, 4.0, 0.7])), subsurface_color=tuple(rng.uniform(0.3, 1.0, 3)),
                               ior=float(rng.choice([1.3, 1.5, 100.0]))) for _ in range(int(rng.integers(1, 5)))]
+    # round 4: two tables in ten have rows that evaluate a scene kind's own estimator (RM_PRIM_KIND): a Mandelbulb or a lattice of spheres
+    kind_shape = None
+    if rng.random() < 0.2:
+        kind_shape = S.Mandelbulb(power=float(rng.choice([8.0, 8.0, 3.0])), iterations=int(rng.integers(1, 5)), bailout=2.0) if rng.random() < 0.5 else \
+            S.SphereLattice(period=float(rng.uniform(0.6, 1.5)), radius=float(rng.uniform(0.1, 0.3)))
     for i in range(int(rng.integers(1, 11))):
         if i:
             op = rng.integers(0, 4)
@@ -939,7 +950,8 @@ def _random_scene(rng):
             else: sc.intersect() if rng.random() < 0.3 else sc.smooth_union(0.2)
         c = tuple(rng.uniform(-1.2, 1.2, 3))
         surface = surfaces[int(rng.integers(0, len(surfaces)))] if surfaces and rng.random() < 0.6 else None
-        if rng.random() < 0.6: sc.sphere(c, float(rng.uniform(0.2, 0.9)), surface=surface)
+        if kind_shape is not None and rng.random() < 0.4: sc.shape(kind_shape, tuple(rng.uniform(-0.5, 0.5, 3)), surface=surface)
+        elif rng.random() < 0.6: sc.sphere(c, float(rng.uniform(0.2, 0.9)), surface=surface)
         else: sc.box(c, tuple(rng.uniform(0.15, 0.8, 3)), surface=surface)
     return sc, (0.2, 0.1, -4.0)
 

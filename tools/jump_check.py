@@ -2,7 +2,7 @@
 """Round 3: the far-field jump of the fast Mandelbulb march (rm_device.hpp far_jump).
 (1) the planes with the jump against RM_RENDER_NO_FAR_JUMP on the headline frame, 2 samples, both implementations: bit for bit;
 (2) kernel time of both, headline (C3b) and preview (C3a), and of the other scene kinds (regressions).
-    python tools/r03_jump.py [lib.so ...]   ("default" = the product library)"""
+    python tools/jump_check.py [lib.so ...]   ("default" = the product library)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) >= 2 and sys.argv[1] != "--child":

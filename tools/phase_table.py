@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Round 3: cumulative cost of the pixel kernel's phases on a table job, with and without row culling (the smooth-union experiment ran on C4 / C5; csg_blocks is a table the culling applies to).
-python tools/phase_cost.py && python tools/r03_phase.py [c4|c5s]   (the RM_DIAG_STOP builds of tools/phase_cost.py)"""
+python tools/phase_cost.py && python tools/phase_table.py [c4|c5s]   (the RM_DIAG_STOP builds of tools/phase_cost.py)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if "--child" not in sys.argv:

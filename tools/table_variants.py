@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Round 3: table scenes (CSG-64) by library variant: python tools/r03_table.py default tools/_exp_x.so ...
+"""Round 3: table scenes (CSG-64) by library variant: python tools/table_variants.py default tools/_exp_x.so ...
 ms per sample of C4 (4096^2 full frame, both implementations), one 8-way shard of it, one 8-way shard of C5, and C2."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
