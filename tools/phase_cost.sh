@@ -4,6 +4,8 @@ OUT=$PWD/gpurun_out/${1:-phase}; mkdir -p $OUT; export TMPDIR=/tmp
 for n in 1 2 3 4 5 0; do
   if [ $n = 0 ]; then unset RM_LIB; else export RM_LIB=$PWD/tools/_exp_stop$n.so; fi
   rocprofv3 --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $OUT/stop$n -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline > $OUT/stop$n.log 2>&1
+  # the instruction mix of the same build, a pass of its own
+  rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 --kernel-trace --output-format csv -d $OUT/stop$n/mix -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline > $OUT/stop${n}_mix.log 2>&1
   python3 - $OUT/stop$n $n <<'PY'
 import csv, glob, sys
 from collections import defaultdict

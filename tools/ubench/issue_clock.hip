@@ -47,6 +47,18 @@ __global__ __launch_bounds__(256) void k(Stamp* out, int iters, float seed) {
       REP8(asm volatile("v_rcp_f32 %0, %0\n v_rsq_f32 %1, %1\n v_sqrt_f32 %2, %2\n v_log_f32 %3, %3\n"
                         "v_rcp_f32 %4, %4\n v_rsq_f32 %5, %5\n v_sqrt_f32 %6, %6\n v_log_f32 %7, %7"
                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+    } else if (MODE == 8 || MODE == 9) {  // round 4: fp64 v_fma_f64 (8) / v_mul_f64 + v_add_f64 (9), 4 chains on register pairs
+      double d0 = a0, d1 = a1, d2 = a2, d3 = a3, dm = m, dc = c;
+      if (MODE == 8) {
+        REP8(asm volatile("v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %1, %1, %4, %5\n v_fma_f64 %2, %2, %4, %5\n v_fma_f64 %3, %3, %4, %5\n"
+                          "v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %1, %1, %4, %5\n v_fma_f64 %2, %2, %4, %5\n v_fma_f64 %3, %3, %4, %5"
+                          : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(dm), "v"(dc));)
+      } else {
+        REP8(asm volatile("v_mul_f64 %0, %0, %4\n v_add_f64 %1, %1, %5\n v_mul_f64 %2, %2, %4\n v_add_f64 %3, %3, %5\n"
+                          "v_mul_f64 %0, %0, %4\n v_add_f64 %1, %1, %5\n v_mul_f64 %2, %2, %4\n v_add_f64 %3, %3, %5"
+                          : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(dm), "v"(dc));)
+      }
+      a0 = (float)d0; a1 = (float)d1; a2 = (float)d2; a3 = (float)d3;
     } else if (MODE == 7) {  // v_pk_fma_f32 on register pairs, SGPR-free
       typedef float float2v __attribute__((ext_vector_type(2)));
       float2v p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, mm = {m, m}, cc = {c, c};
@@ -100,6 +112,8 @@ int main() {
     run<5>("v_fma_f32 1 dependent chain", d, w);
     run<6>("v_rcp/rsq/sqrt/log_f32  8 chains", d, w);
     run<7>("v_pk_fma_f32  4 pair chains", d, w);
+    run<8>("v_fma_f64  4 chains", d, w);
+    run<9>("v_mul_f64 / v_add_f64  4 chains", d, w);
   }
   return 0;
 }
