@@ -26,6 +26,17 @@ const rm = require("./index.js");
     process.stdout.write(JSON.stringify({ prims: Buffer.from(d.prims).toString("hex"), glsl: sc.glsl() }));
     return;
   }
+  if (mode === "kinds") {  // no GPU needed: a table whose rows evaluate a scene kind (RM_PRIM_KIND), as the description and the table
+    const sc = new rm.CsgScene().shape(new rm.Mandelbulb(8, 5, 2)).intersect().box([0.0, 0.0, 0.25], [1.25, 1.25, 0.75])
+      .subtract().sphere([0.5, 0.375, -0.5], 0.375, { diffuse: [0.875, 0.25, 0.125], specular: [0.5, 0.5, 0.5], roughness: 0.25 });
+    const d = sc.desc();
+    let refused = "";
+    try { sc.glsl(); } catch (e) { refused = e.message; }
+    let mixed = "";
+    try { new rm.CsgScene().shape(new rm.Mandelbulb(8, 5, 2)).shape(new rm.Mandelbulb(8, 6, 2)); } catch (e) { mixed = e.name; }
+    process.stdout.write(JSON.stringify({ desc: Buffer.from(d.desc).toString("hex"), prims: Buffer.from(d.prims).toString("hex"), surfaces: Buffer.from(d.surfaces).toString("hex"), refused, mixed }));
+    return;
+  }
   if (mode === "surfaces") {  // no GPU needed: a scene whose shapes name surfaces, as the table, the surface rows and GLSL
     const sc = new rm.CsgScene().box([0, 0, 0], [1.0, 0.5, 0.75]).smoothUnion(0.25)
       .sphere([-1.25, 0.25, 0.0], 0.5, { diffuse: [0.875, 0.125, 0.125], specular: [0.25, 0.25, 0.25], roughness: 0.5 })

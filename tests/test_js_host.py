@@ -46,6 +46,22 @@ def test_js_layouts_match_the_c_abi():
     assert out["halton3"] == [next(g), next(g), next(g)]
 
 
+def test_js_kind_rows_match_the_python_composer():
+    """RM_PRIM_KIND in the JS composer: the description (the kind's parameters in the scene block), the table rows and the surface
+    rows of `csg_bulb_cut` are byte for byte the Python composer's; its GLSL text is the Python composer's to emit."""
+    import ctypes as C
+
+    out = json.loads(subprocess.run(["node", str(JS / "render_cli.js"), "-", "kinds"], capture_output=True, text=True, check=True).stdout)
+    sc = GC.build_scene("csg_bulb_cut")
+    d = sc.desc()
+    raw = bytearray(bytes(d))
+    raw[8:16] = b"\0" * 8  # the prims pointer is filled natively ...
+    assert out["desc"][: 2 * 120] == bytes(raw).hex()[: 2 * 120]  # ... and so is the surfaces pointer at the end: kind, nprims, params, material, nsurfaces
+    assert out["prims"] == bytes(C.string_at(d.prims, 32 * d.nprims)).hex()
+    assert out["surfaces"] == bytes(C.string_at(d.surfaces, 48 * d.nsurfaces)).hex()
+    assert "Python composer" in out["refused"] and out["mixed"] == "TypeError"
+
+
 def test_js_domain_operators_match_the_python_composer():
     """repeat / fold (the composition API's domain operators): the JS composer lays out the same table rows and the
     same GLSL statements as the Python one."""
