@@ -54,6 +54,24 @@ def _worker(rank, world, port, width, height, out_path):
     frame2 = g.finish(handle)
     if rank == 0:
         assert torch.equal(frame2, first)
+    # the all-gather form (to_all: what a job with depth of field uses for its packed rows, round 4): EVERY rank ends up with the
+    # assembled frame, bit for bit the one rank 0 gathered
+    ga = rmdist.FrameGatherer(height, width, world, rank, torch.device("cpu"), to_all=True)
+    plane2 = torch.zeros((ga.max_rows, width, 4), dtype=torch.float32)
+    for k in range(0, len(rows), shard.STRIPE_ROWS):
+        r0 = int(rows[k])
+        n = min(shard.STRIPE_ROWS, height - r0)
+        fr = O.Frame(width, height, r0, n)
+        for nz in noises:
+            O.render(sc, J.uniforms_from_schema(schema, nz), fr)
+        plane2[k : k + n] = torch.from_numpy(fr.color)
+    everyone = ga.finish(ga.start(plane2, dist))
+    assert everyone is not None and everyone.shape == (height, width, 4)
+    check = [torch.zeros_like(everyone) for _ in range(world)]
+    dist.all_gather(check, everyone.contiguous())
+    assert all(torch.equal(torch.nan_to_num(c), torch.nan_to_num(check[0])) for c in check)
+    if rank == 0:
+        assert torch.equal(torch.nan_to_num(everyone), torch.nan_to_num(first))
     if rank == 0:
         np.save(out_path, frame.numpy())
     else:
