@@ -126,7 +126,7 @@ struct rm_scene {
   unsigned long long* d_cull = nullptr;
   // the culling grid of a long CSG table is built by the first fast-build call that can use it (scene_cull_grid): a host that only
   // ever renders strict, or creates many scenes it renders once, does not pay (32^3 x levels + 1) x words x 8 B -- 4.7 MB at 12
-  // rows, 14 MB at 192 -- and a build kernel per scene
+  // rows, 14 MB at 192; 134 MB for a table of spheres under one smooth-union radius, whose rule wants 128^3 cells -- and a build kernel per scene
   bool cull_wanted = false;
   CullGrid cull_grid{};
   CullBuild cull_build{};
@@ -433,6 +433,12 @@ static void table_far_field(const RmSceneDesc* desc, DevScene* dev) {
 #ifndef RM_CULL_N
 #define RM_CULL_N 32
 #endif
+#ifndef RM_CULL_N_SMOOTH
+#define RM_CULL_N_SMOOTH 128  // C4 12.4 ms without the grid, 9.8 with 64^3 cells, 9.1 with 128^3 (profiles/r04_smooth_union_culling.txt)
+#endif
+#ifndef RM_CULL_SMOOTH_LEVELS
+#define RM_CULL_SMOOTH_LEVELS 8  // out to 128 scene widths (a camera further away folds every row until its rays get there): 134 MB of cells
+#endif
 #ifndef RM_CULL_MAX_LEVELS
 #define RM_CULL_MAX_LEVELS 18
 #endif
@@ -457,7 +463,10 @@ static bool table_cull_params(const RmSceneDesc* desc, CullGrid* g, CullBuild* b
     }
     if (((p.type >> 8) & 0xff) == RM_OP_SMOOTH_UNION) kmax = std::fmax(kmax, (double)p.k);
   }
-  if (cullable * 2 < n) return false;  // mostly smooth unions: the grid would cost more than it saves
+  // spheres under one smooth-union radius (CSG-64's shape; round 4): their far rows can be dropped where the rounding they perform is
+  // provably the identity (rm_params.hpp rm_cull_cell_smooth_spheres) -- on a finer grid, the binade tests want small cells
+  const bool smooth_spheres = n >= RM_TABLE_BIG_ROWS && rm_cull_uniform_smooth_spheres(desc->prims, n);
+  if (cullable * 2 < n && !smooth_spheres) return false;  // mostly smooth unions of other kinds: the grid would cost more than it saves
   double half = 0.0, reach = 0.0;
   for (int a = 0; a < 3; a++) {
     half = std::fmax(half, 0.5 * (hi[a] - lo[a]));
@@ -469,16 +478,18 @@ static bool table_cull_params(const RmSceneDesc* desc, CullGrid* g, CullBuild* b
   // levels: out to where the fp32 allowance of the build kernel (1.2e-7 (n + 8) |coordinates|) exceeds the scene's own width
   int levels = 1;
   while (levels < RM_CULL_MAX_LEVELS && 1.2e-7 * (n + 8) * 1.74 * std::ldexp(half, levels) < 2.0 * half) levels++;
+  if (smooth_spheres && levels > RM_CULL_SMOOTH_LEVELS) levels = RM_CULL_SMOOTH_LEVELS;
   build->half0 = half;
   build->reach = reach;
   build->nprims = n;
-  build->n = RM_CULL_N;
+  const int cells = smooth_spheres ? RM_CULL_N_SMOOTH : RM_CULL_N;
+  build->n = cells;
   build->levels = levels;
   build->words = (n + 63) / 64;
   for (int a = 0; a < 3; a++) g->centre[a] = (float)build->centre[a];
   g->inv_half0 = (float)(1.0 / half);
-  g->scale0 = (float)(RM_CULL_N / (2.0 * half));
-  g->n = RM_CULL_N;
+  g->scale0 = (float)(cells / (2.0 * half));
+  g->n = cells;
   g->levels = levels;
   g->words = build->words;
   return true;

@@ -320,6 +320,7 @@ RM_DEV bool is_neg_zero(float x) { return __float_as_uint(x) == 0x80000000u; }
 struct SceneLds {
   float4 rows[RM_MAX_PRIMS * 2];
   float4 surf[(RM_MAX_SURFACES + 1) * 3];  // RM_TABLE_HAS_SURFACES: the surfaces' values, 3 x float4 each ([0] = the scene's material block)
+  unsigned int cull_here;  // smooth sphere tables: 0 while the workgroup's rays are too far apart to share a cell (eval_spheres_one_k)
 };
 
 // :74-76
@@ -433,6 +434,7 @@ struct Sdf<RM_SCENE_TABLE> {
   static RM_DEV bool nonfinite_normal_is_nan(const DevScene& sc) { return (sc.table_flags & RM_TABLE_NO_BOXES) != 0; }
   static RM_DEV void stage(const DevScene& sc, SceneLds& lds) {
     const float4* src = reinterpret_cast<const float4*>(sc.prims);
+    if (threadIdx.x == 0) lds.cull_here = 1u;
     if (sc.table_flags & RM_TABLE_UNIFORM_K) {  // spheres, one k: also a compact image, (centre, radius) per row, behind the rows:
       for (int i = threadIdx.x; i < sc.nprims; i += blockDim.x) {  // ONE ds_read_b128 per row in the fast fold
         const float4 a = src[2 * i], b = src[2 * i + 1];
@@ -466,7 +468,8 @@ struct Sdf<RM_SCENE_TABLE> {
   // d itself once a shape is further than k away and so lets an evaluation skip such rows exactly: C4 14.2 -> 7.0 ms -- and 14 %
   // fewer lit pixels, because the rounding of d to the grid of (di - d) that THIS form, like the reference's mix(d2, d1, 1), performs
   // for every far row is the noise the creeping shadow rays of a smooth-union scene live on.  Not kept:
-  // profiles/r03_row_culling_smooth_union_experiment.txt.  Smooth-union rows are never culled.)
+  // profiles/r03_row_culling_smooth_union_experiment.txt.  Round 4 drops the rows for which that rounding is provably the identity:
+  // rm_params.hpp rm_cull_cell_smooth_spheres.)
   static RM_DEV float smooth_row(float d, float di, float k, float half_inv_k) {
     const float t = di - d;  // d - di is -t exactly (up to the sign of a zero): one subtraction instead of two
     const float h = gclamp(FM::fma(half_inv_k, t, 0.5f), 0.0f, 1.0f);
@@ -480,27 +483,67 @@ struct Sdf<RM_SCENE_TABLE> {
     return FM::sqrt(FM::fma(q.z, q.z, FM::fma(q.y, q.y, q.x * q.x))) - r.w;
   }
   // one smooth-union radius for the whole table (RM_TABLE_UNIFORM_K): the compact image, one ds_read_b128 per row instead of two
+#ifndef RM_CULL_SMOOTH_MAX
+#define RM_CULL_SMOOTH_MAX 52  // of 64 rows: above this the unrolled fold of the whole word is the cheaper one
+#endif
   static RM_DEV float eval_spheres_one_k(const DevScene& sc, const SceneLds& lds, v3 p) {
     const int n = sc.nprims;
     const float k = sc.p[0], half_inv_k = sc.p[1];
     const float4* rows = &lds.rows[2 * n];  // the compact image (stage)
     float d = sphere_row1(rows[0], p);
-    int i = 1;
     // four rows per trip (round 4): one address register with immediate offsets and four reads in flight; C4 12.19 -> 11.99 ms, C5 154.8 ->
     // 148.7, their 1/8 stripes -5 %.  (Two rows per trip with the next two read ahead: C4 11.79, C5 152.1; four with a rotating read-ahead
     // of two: no gain over two, 24 registers of rows.  With HALF the LDS reads and the same arithmetic -- a diagnostic build -- the fold
     // is not faster at all, 12.9 against 12.1 ms: it is not LDS-bound; and at 6 / 5 waves per SIMD, where nothing spills, C5 takes
     // 177 / 235 ms: it lives on occupancy.)
-    for (; i + 3 < n; i += 4) {
-      const float4 r0 = rows[i], r1 = rows[i + 1], r2 = rows[i + 2], r3 = rows[i + 3];
-      const float d0 = sphere_row1(r0, p), d1 = sphere_row1(r1, p);
-      d = smooth_row(d, d0, k, half_inv_k);
-      d = smooth_row(d, d1, k, half_inv_k);
-      const float d2 = sphere_row1(r2, p), d3 = sphere_row1(r3, p);
-      d = smooth_row(d, d2, k, half_inv_k);
-      d = smooth_row(d, d3, k, half_inv_k);
+    auto fold_range = [&](int i, int end) {
+      for (; i + 3 < end; i += 4) {
+        const float4 r0 = rows[i], r1 = rows[i + 1], r2 = rows[i + 2], r3 = rows[i + 3];
+        const float d0 = sphere_row1(r0, p), d1 = sphere_row1(r1, p);
+        d = smooth_row(d, d0, k, half_inv_k);
+        d = smooth_row(d, d1, k, half_inv_k);
+        const float d2 = sphere_row1(r2, p), d3 = sphere_row1(r3, p);
+        d = smooth_row(d, d2, k, half_inv_k);
+        d = smooth_row(d, d3, k, half_inv_k);
+      }
+      for (; i < end; i++) d = smooth_row(d, sphere_row1(rows[i], p), k, half_inv_k);
+    };
+    if (sc.cull.cells == nullptr || lds.cull_here == 0u) {  // uniform over the kernel / the workgroup
+      fold_range(1, n);
+      return d;
     }
-    for (; i < n; i++) d = smooth_row(d, sphere_row1(rows[i], p), k, half_inv_k);
+    // Round 4: the rows of this point's cell that are not exact no-ops (rm_params.hpp rm_cull_cell_smooth_spheres: a far row of a smooth
+    // union ROUNDS the running value, and where that rounding is provably the identity the row is skipped) -- about half of CSG-64's.
+    // Folded: the union of the wave's cells (any superset of a lane's list gives the same bits: the extra rows are identities for it),
+    // and the whole word where the wave is spread over too many cells for a common list (the rays of a diffuse bounce) or the list is
+    // not much shorter than the word (RM_CULL_SMOOTH_MAX: the scalar row loop costs more per row than the unrolled one).  The
+    // pixel kernel switches the lookup off for the bounces after the first (lds.cull_here): their waves seldom share a list, and the
+    // cell's read and the union would be paid for nothing (C5: 156 ms with it on throughout, 151 without any culling).  Whatever is
+    // folded, the bits are those of the fold of every row (RM_RENDER_NO_CULL).
+    const unsigned long long* cell = cull_cell(sc.cull, p);
+    for (int w = 0; w < sc.cull.words; w++) {
+      unsigned long long u = wave_union(cell[w]);
+      const int first = w == 0 ? 1 : 64 * w, end = min(n, 64 * w + 64);
+      if (u == 0ull || __builtin_popcountll(u) > RM_CULL_SMOOTH_MAX * (end - 64 * w) / 64) {
+        fold_range(first, end);
+        continue;
+      }
+      if (w == 0) u &= ~1ull;
+      while (u != 0ull) {
+        const int j0 = 64 * w + __builtin_ctzll(u);
+        u &= u - 1ull;
+        if (u != 0ull) {
+          const int j1 = 64 * w + __builtin_ctzll(u);
+          u &= u - 1ull;
+          const float4 r0 = rows[j0], r1 = rows[j1];
+          const float d0 = sphere_row1(r0, p), d1 = sphere_row1(r1, p);
+          d = smooth_row(d, d0, k, half_inv_k);
+          d = smooth_row(d, d1, k, half_inv_k);
+        } else {
+          d = smooth_row(d, sphere_row1(rows[j0], p), k, half_inv_k);
+        }
+      }
+    }
     return d;
   }
   static RM_DEV float eval_spheres_smooth(const DevScene& sc, const SceneLds& lds, v3 p) {

@@ -85,3 +85,71 @@ def test_rejects_domain_rows():
         sc.sphere((0, 0, 0), 0.3)
     with pytest.raises(native.RmError):
         native.cull_cell(sc, (0, 0, 0), 0.1)
+
+
+# ---- spheres under ONE smooth-union radius (round 4: rm_params.hpp rm_cull_cell_smooth_spheres) -----------------------------------
+# A far row of a smooth union is not a no-op -- the fast fold's d' = di - fl(di - d) rounds d to the grid of (di - d) -- unless d
+# already lies on a grid at least as coarse; the rule tracks that per cell and drops the rows whose rounding is provably the identity.
+# Here: the rule against an fp32 restatement of the FAST fold (rm_device.hpp sphere_row1 / smooth_row: v_fma_f32, v_sqrt_f32 taken as
+# correctly rounded -- any rounding of the square root leaves the argument intact: it only needs di to be a float), bit for bit.
+
+def _fma32(a, b, c):
+    return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)  # (a 2^-29 chance of a double rounding: both folds share it)
+
+
+def fast_fold_fp32(C, R, k, pts, keep):
+    f32 = np.float32
+    hik = f32(0.5) * (f32(1.0) / f32(k))
+
+    def row(i):
+        q = pts - C[i][None]
+        s = _fma32(q[:, 2], q[:, 2], _fma32(q[:, 1], q[:, 1], q[:, 0] * q[:, 0]))
+        return (np.sqrt(s.astype(np.float64)).astype(f32) - R[i]).astype(f32)
+
+    d = row(0)
+    for i in range(1, len(R)):
+        if not keep[i]:
+            continue
+        di = row(i)
+        t = (di - d).astype(f32)
+        h = np.minimum(np.maximum(_fma32(np.full_like(t, hik), t, np.full_like(t, 0.5)), f32(0)), f32(1))
+        d = _fma32(-h, _fma32(np.full_like(t, f32(k)), (f32(1) - h).astype(f32), t), di)
+    return d
+
+
+def test_far_rows_of_a_smooth_union_are_dropped_only_where_their_rounding_is_the_identity():
+    rng = np.random.default_rng(404)
+    dropped = total = 0
+    for trial in range(14):
+        sc = S.csg64() if trial == 0 else S.CsgScene()
+        if trial:
+            n, k = int(rng.integers(16, 90)), float(np.float32(rng.uniform(0.05, 0.4)))
+            spacing = float(rng.uniform(0.6, 1.2))
+            sc.smooth_union(k)
+            for _ in range(n):
+                sc.sphere(tuple(rng.uniform(-2, 2, 3) * spacing), float(rng.uniform(0.15, 0.5)))
+        C = np.array([nd.center for nd in sc._nodes], np.float32)
+        R = np.array([nd.size[0] for nd in sc._nodes], np.float32)
+        k = np.float32(sc._nodes[1].k)
+        for nd, c in zip(sc._nodes, C):
+            nd.center = tuple(float(v) for v in c)
+        n = len(R)
+        for _ in range(40):
+            # cells the size the grid has (64^3 over the scene, and the coarser outer levels), near surfaces, inside shapes, far outside
+            rad = float(rng.choice([0.02, 0.05, 0.07, 0.15, 0.4]))
+            i = int(rng.integers(0, n))
+            u = rng.normal(size=3)
+            u /= np.linalg.norm(u)
+            c = C[i].astype(np.float64) + u * (float(R[i]) + float(rng.choice([-0.1, -1e-3, 0.0, 1e-4, 0.01, 0.05, 0.3, 1.0, 4.0, 30.0])))
+            margin = 1e-4 + 1.2e-7 * (n + 8) * (float(np.abs(c).max()) + rad + 3.0)  # rm_cull_margin at this cell's magnitude
+            keep = native.cull_cell(sc, c, rad, margin)
+            assert keep[0]
+            v = rng.normal(0, 1, (300, 3))
+            v /= np.linalg.norm(v, axis=1, keepdims=True)
+            pts = (c[None] + v * (rad * rng.uniform(0, 1, (300, 1)) ** (1 / 3))).astype(np.float32)
+            full, part = fast_fold_fp32(C, R, k, pts, [True] * n), fast_fold_fp32(C, R, k, pts, keep)
+            same = full.view(np.uint32) == part.view(np.uint32)
+            assert same.all(), (trial, int((~same).sum()), rad, [j for j in range(n) if not keep[j]][:8])
+            dropped += n - sum(keep)
+            total += n
+    assert dropped > 0.25 * total, (dropped, total)  # the rule does drop rows: about half of them in cells of the grid's size

@@ -1707,7 +1707,7 @@ def test_kernel_variants_by_job_shape_leave_the_same_bits(ctx, scene, build):
 
 def _cull_table(rng, kind, rows=None):
     """a random table without domain rows, long enough for the culling grid: spheres and boxes under 0 = unions, 1 = unions,
-    subtractions and intersections, 2 = those and smooth unions (which the grid never drops)"""
+    subtractions and intersections, 2 = those and smooth unions (which this rule never drops; tables of spheres under ONE smooth-union radius have their own: the next test)"""
     sc = S.CsgScene()
     p = [[1.0, 0, 0, 0], [0.6, 0, 0.25, 0.15], [0.5, 0.25, 0.15, 0.1]][kind]
     for _ in range(rows or int(rng.integers(12, 100))):
@@ -1757,17 +1757,49 @@ def test_row_culling_is_exact_on_random_tables(ctx, kind):
                     assert same_bits(got[k], ref[k]).all(), f"table {it}, plane {k}"
 
 
-def test_row_culling_leaves_smooth_union_tables_alone(ctx):
-    """BASELINE's CSG-64 is all smooth unions: its rows are never dropped (profiles/r03_row_culling_smooth_union_experiment.txt has
-    the measurement that decided it), so the switch changes nothing -- and the job keeps the bits it had before the grid existed
-    (the fast-against-strict statistics and the far-jump tests of this file run on it)."""
-    sc = S.csg64()
-    schema = J.make_schema(sc, 512, 512, counts=(128,), render_mode="full", position=(0, 0, -5.0), lights=GC.LIGHT)
-    noises = GC.halton_pairs(1)
-    a = render_gpu(ctx, sc, schema, noises, FAST | MK)
-    b = render_gpu(ctx, sc, schema, noises, FAST | MK | abi.RM_RENDER_NO_CULL)
-    for k in range(3):
-        assert same_bits(a[k], b[k]).all()
+def _smooth_sphere_table(rng, rows):
+    sc = S.CsgScene()
+    sc.smooth_union(float(np.float32(rng.uniform(0.05, 0.4))))
+    spread = float(rng.uniform(0.8, 2.5))
+    for _ in range(rows):
+        sc.sphere(rng.uniform(-spread, spread, 3), float(rng.uniform(0.15, 0.5)))
+    return sc
+
+
+def test_row_culling_of_smooth_sphere_tables_is_exact(ctx):
+    """Round 4.  A far row of a smooth union is not a no-op -- the fast fold rounds the running value to the row's grid -- except
+    where the value already lies on a grid at least as coarse; the grid of a table of spheres under ONE smooth-union radius (CSG-64's
+    shape) drops exactly those rows (rm_params.hpp rm_cull_cell_smooth_spheres; the rule against an fp32 fold:
+    tests/test_cull_rule_cpu.py).  CSG-64 and random tables of 16 .. 200 such rows: the distance at points in, around and far from the
+    scene and at points with NaN / infinite coordinates, castRay end points, and whole frames of both implementations (two bounces, a
+    light: the creeping shadow rays round 3's inexact version changed) have the bits of the fold of every row (RM_RENDER_NO_CULL)."""
+    NC = abi.RM_RENDER_NO_CULL
+    rng = np.random.default_rng(977 + SEED_OFFSET)
+    special = np.array([[np.nan, 0, 0], [0.5, np.nan, 1], [np.inf, 1, 1], [1, 1, -np.inf], [np.nan, np.nan, np.nan], [1e30, 0, 0], [3e38, 3e38, 3e38], [0, 0, 0]])
+    for it, rows in enumerate([0, 16, 17, 64, 65, 130, 200, 33]):
+        sc = S.csg64() if rows == 0 else _smooth_sphere_table(rng, rows)
+        h = ctx.create_scene(sc)
+        pts = np.concatenate([rng.uniform(-3, 3, (30000, 3)), rng.uniform(-12, 12, (6000, 3)), rng.normal(0, 1, (6000, 3)) * 10.0 ** rng.uniform(1, 7, (6000, 1)), special]).astype(np.float32)
+        a = ctx.probe(h, abi.RM_PROBE_SDF, pts, 0.0, FAST)
+        b = ctx.probe(h, abi.RM_PROBE_SDF, pts, 0.0, FAST | NC)
+        assert same_bits(a, b).all(), f"table {it} ({len(sc._nodes)} rows): the distance differs at {int((~same_bits(a, b)).sum())} points, first {pts[np.argmax(~same_bits(a, b))]}"
+        o = rng.uniform(-5, 5, (16384, 3))
+        d = rng.normal(0, 1, (16384, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        rays = np.concatenate([o, d], 1).astype(np.float32)
+        for steps in (24.0, 128.0):
+            ra = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST)
+            rb = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST | NC)
+            assert same_bits(ra, rb).all(), f"table {it}: {int((~same_bits(ra, rb)).any(-1).sum())} end points differ"
+        h.destroy()
+        if it < 4:
+            schema = J.make_schema(sc, 320, 256, counts=(128, 64), render_mode="full", position=(0.0, 0.0, -5.0) if rows == 0 else (0.3, 0.2, -6.0), lights=GC.LIGHT)
+            noises = GC.halton_pairs(2)
+            ref = render_gpu(ctx, sc, schema, noises, FAST | MK | NC)
+            for impl in (MK, WF):
+                got = render_gpu(ctx, sc, schema, noises, FAST | impl)
+                for k in range(3):
+                    assert same_bits(got[k], ref[k]).all(), f"table {it}, plane {k}: {int((~same_bits(got[k], ref[k])).sum())} values differ"
 
 
 def test_fast_build_tolerance_is_anchored_to_the_spread_between_glsl_legal_arithmetics(ctx):
