@@ -229,11 +229,14 @@ enum {
                                 that escapes with too few steps left for the overflow is marched to the end instead of being
                                 stopped once its comparison (raymarcher.frag:362-363) is certain.  A measurement and test
                                 switch: the same bits in every plane either way. */
-  RM_RENDER_NO_CULL = 128     /* RM_RENDER_FAST, long primitive tables built with union / subtract / intersect: evaluate every row
-                                of the table at every point instead of the rows the point's grid cell lists (a row whose operator
-                                is an exact no-op everywhere in the cell is skipped: min(d, di) with the shape further away than
-                                the running value, max(d, +-di) with the term below it; smooth unions are never skipped).  A
-                                measurement and test switch: the same bits either way. */
+  RM_RENDER_NO_CULL = 128     /* long primitive tables (no domain rows): evaluate every row of the table at every point instead of
+                                the rows the point's grid cell lists.  A row that is an exact no-op everywhere in the cell is
+                                skipped: min(d, di) with the shape further away than the running value, max(d, +-di) with the term
+                                below it; and, in a table of spheres under ONE smooth-union radius, a far row whose rounding of
+                                the running value -- d' = fl(di - fl(di - d)), what mix(di, d, 1) does -- is provably the identity
+                                because d already lies on a grid at least as coarse.  Other smooth-union rows are never skipped.
+                                Both builds since round 4 (the parity build's GL-stack arithmetic folds every row).  A measurement
+                                and test switch: the same bits either way. */
 };
 
 enum { RM_PLANE_COLOR = 0, RM_PLANE_NORMAL_DOF = 1, RM_PLANE_ALBEDO_DEPTH = 2 };
@@ -309,8 +312,8 @@ int rm_ctx_set_gl_stack(rm_ctx* ctx, int on);
 int rm_debug_counters(rm_ctx* ctx, unsigned long long* out16, int reset);
 
 /* Debug (tests): the rows of a primitive table (no domain rows) that an evaluation anywhere in the ball (centre, radius) has
- * to fold -- what the culling grid of RM_RENDER_FAST stores per cell (RM_RENDER_NO_CULL) -- as (nprims + 63) / 64 64-bit words,
- * bit i = row i stays (row 0 and smooth-union rows always do); `margin` = the allowance for fp32 rounding (0 tests the rule in
+ * to fold -- what the culling grid stores per cell (RM_RENDER_NO_CULL) -- as (nprims + 63) / 64 64-bit words,
+ * bit i = row i stays (row 0 always does; smooth-union rows do except in a table of spheres under one smooth-union radius); `margin` = the allowance for fp32 rounding (0 tests the rule in
  * exact arithmetic).  Host arithmetic:
  * needs no GPU and no context.  Returns RM_ERR_INVALID for a table with domain rows. */
 int rm_debug_cull_cell(const RmSceneDesc* desc, const double* centre, double radius, double margin, unsigned long long* out_words);

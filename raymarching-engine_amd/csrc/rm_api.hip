@@ -124,8 +124,8 @@ struct rm_scene {
   RmPrim* d_prims = nullptr;
   RmSurface* d_surfaces = nullptr;
   unsigned long long* d_cull = nullptr;
-  // the culling grid of a long CSG table is built by the first fast-build call that can use it (scene_cull_grid): a host that only
-  // ever renders strict, or creates many scenes it renders once, does not pay (32^3 x levels + 1) x words x 8 B -- 4.7 MB at 12
+  // the culling grid of a long CSG table is built by the first call that can use it (scene_cull_grid): a host that
+  // creates many scenes it never renders does not pay (32^3 x levels + 1) x words x 8 B -- 4.7 MB at 12
   // rows, 14 MB at 192; 134 MB for a table of spheres under one smooth-union radius, whose rule wants 128^3 cells -- and a build kernel per scene
   bool cull_wanted = false;
   CullGrid cull_grid{};
@@ -895,11 +895,11 @@ int rm_buffer_upload(rm_ctx* ctx, void* device_ptr, const void* host, size_t byt
   return RM_OK;
 }
 
-// The culling grid of a scene that has one coming (rm_scene_create), before the first fast-build call that reads it: one allocation,
+// The culling grid of a scene that has one coming (rm_scene_create), before the first call that reads it (either build; not the GL stack's arithmetic): one allocation,
 // one build kernel and one wait on the context's stream, once per scene.  A failure to allocate is not an error: the fold of every
 // row gives the same bits.
 static void scene_cull_grid(rm_ctx* ctx, rm_scene* s, int flags) {
-  if (!s->cull_wanted || !(flags & RM_RENDER_FAST) || (flags & RM_RENDER_NO_CULL)) return;
+  if (!s->cull_wanted || (flags & RM_RENDER_NO_CULL) || (ctx->gl_stack && !(flags & RM_RENDER_FAST))) return;
   s->cull_wanted = false;
   CullGrid g = s->cull_grid;
   CullBuild build = s->cull_build;

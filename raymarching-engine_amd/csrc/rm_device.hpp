@@ -563,7 +563,7 @@ struct Sdf<RM_SCENE_TABLE> {
     }
     return d;
   }
-  // ---- row culling (round 3; fast policy; tables without domain rows; rm_params.hpp rm_cull_cell has the rule) ------------------
+  // ---- row culling (round 3; tables without domain rows; rm_params.hpp rm_cull_cell has the rule; the parity build too since round 4) --
   // A row whose operator cannot change the running value of the fold is an exact no-op: min(d, di) with di >= d, max(d, -di) and
   // max(d, di) with the term below d.  (Not the smooth union: see smooth_row.)  The scene's grid lists, per cell, the rows for which
   // that cannot be said of every point of the cell; an evaluation folds the rows listed for ITS WAVE's points -- the union of the
@@ -798,7 +798,10 @@ struct Sdf<RM_SCENE_TABLE> {
   template <class M>
   static RM_DEV float eval(const DevScene& sc, const SceneLds& lds, v3 p) {
     if (M::fast && (sc.table_flags & RM_TABLE_SPHERES_SMOOTH)) return eval_spheres_smooth(sc, lds, p);
-    if (M::fast && sc.cull.cells != nullptr) return eval_general_culled<M>(sc, lds, p);  // kernel-uniform
+    // kernel-uniform.  Both builds (round 4; round 3: the fast one only): which rows are identities at a point is an argument about the
+    // shapes' distances with an fp32 allowance and, for a far smooth-union row, about  d' = fl(di - fl(di - d))  -- which mix(di, d, 1)
+    // is in either arithmetic.  Not the GL stack's (ExactExits).
+    if (ExactExits<M>::value && sc.cull.cells != nullptr) return eval_general_culled<M>(sc, lds, p);
     return eval_general<M>(sc, lds, p);
   }
   template <class M, bool KINDS = false>

@@ -91,13 +91,15 @@ __host__ __device__ inline void rm_cull_cell_smooth_spheres(const RmPrim* prims,
     } else {
       const double emin = lo - U, emax = hi - L;  // t = di - d over the cell, both > 0
       const int bmin = (int)floor(log2(emin * (1.0 - 1e-5))), bmax = (int)floor(log2(emax * (1.0 + 1e-5)));
-      const int bdi = (int)floor(log2(lo * (1.0 - 1e-5)));  // lo > U + k > ... : positive here
+      // the lowest binade of |di| over the cell; a far row's distance may be negative (the running value is then further inside
+      // still) or change sign in the cell: then |di| has no lowest binade and nothing is claimed
+      const int bdi = lo > 0.0 ? (int)floor(log2(lo * (1.0 - 1e-5))) : (hi < 0.0 ? (int)floor(log2(-hi * (1.0 - 1e-5))) : NONE);
       if (B != NONE && B >= bmax && bmax <= bdi) {
         keep = false;  // an exact no-op everywhere in the cell
       } else {
         const int g = bmin < bdi ? bmin : bdi;
         const double big = fabs(L) > fabs(U) ? fabs(L) : fabs(U);
-        B = big * (1.0 + 1e-5) < ldexp(1.0, g + 1) ? g : NONE;  // the grid this row leaves d on, when d' = dm - t is exact
+        B = g != NONE && big * (1.0 + 1e-5) < ldexp(1.0, g + 1) ? g : NONE;  // the grid this row leaves d on, when d' = dm - t is exact
       }
     }
     L = rm_smooth_min(L, lo, k) - margin;

@@ -117,7 +117,29 @@ def fast_fold_fp32(C, R, k, pts, keep):
     return d
 
 
-def test_far_rows_of_a_smooth_union_are_dropped_only_where_their_rounding_is_the_identity():
+def parity_fold_fp32(C, R, k, pts, keep):
+    """the parity build's fold (rm_device.hpp op_smooth_union<PM>: h = clamp(0.5 + 0.5 (di - d) / k), mix(di, d, h) - k h (1 - h) with mix
+    = x + a (y - x), every operation rounded once; the distance correctly rounded): a far row is d' = fl(di + fl(d - di)) here too"""
+    f32 = np.float32
+    P64, C64 = pts.astype(np.float64), C.astype(np.float64)
+
+    def row(i):
+        return (np.sqrt(((P64 - C64[i][None]) ** 2).sum(1)) - float(R[i])).astype(f32)
+
+    d = row(0)
+    for i in range(1, len(R)):
+        if not keep[i]:
+            continue
+        di = row(i)
+        h = np.minimum(np.maximum(f32(0.5) + ((f32(0.5) * (di - d)).astype(f32) / f32(k)).astype(f32), f32(0)), f32(1)).astype(f32)
+        mix = (di + (h * (d - di).astype(f32)).astype(f32)).astype(f32)
+        d = (mix - ((f32(k) * h).astype(f32) * (f32(1) - h).astype(f32)).astype(f32)).astype(f32)
+    return d
+
+
+@pytest.mark.parametrize("fold", ["fast", "parity"])
+def test_far_rows_of_a_smooth_union_are_dropped_only_where_their_rounding_is_the_identity(fold):
+    fold_fp32 = fast_fold_fp32 if fold == "fast" else parity_fold_fp32
     rng = np.random.default_rng(404)
     dropped = total = 0
     for trial in range(14):
@@ -140,14 +162,14 @@ def test_far_rows_of_a_smooth_union_are_dropped_only_where_their_rounding_is_the
             i = int(rng.integers(0, n))
             u = rng.normal(size=3)
             u /= np.linalg.norm(u)
-            c = C[i].astype(np.float64) + u * (float(R[i]) + float(rng.choice([-0.1, -1e-3, 0.0, 1e-4, 0.01, 0.05, 0.3, 1.0, 4.0, 30.0])))
+            c = C[i].astype(np.float64) + u * (float(R[i]) + float(rng.choice([-0.3, -0.1, -1e-3, 0.0, 1e-4, 0.01, 0.05, 0.3, 1.0, 4.0, 30.0])))
             margin = 1e-4 + 1.2e-7 * (n + 8) * (float(np.abs(c).max()) + rad + 3.0)  # rm_cull_margin at this cell's magnitude
             keep = native.cull_cell(sc, c, rad, margin)
             assert keep[0]
             v = rng.normal(0, 1, (300, 3))
             v /= np.linalg.norm(v, axis=1, keepdims=True)
             pts = (c[None] + v * (rad * rng.uniform(0, 1, (300, 1)) ** (1 / 3))).astype(np.float32)
-            full, part = fast_fold_fp32(C, R, k, pts, [True] * n), fast_fold_fp32(C, R, k, pts, keep)
+            full, part = fold_fp32(C, R, k, pts, [True] * n), fold_fp32(C, R, k, pts, keep)
             same = full.view(np.uint32) == part.view(np.uint32)
             assert same.all(), (trial, int((~same).sum()), rad, [j for j in range(n) if not keep[j]][:8])
             dropped += n - sum(keep)

@@ -1720,14 +1720,15 @@ def _cull_table(rng, kind, rows=None):
     return sc
 
 
+@pytest.mark.parametrize("build", BUILDS, ids=BUILD_IDS)
 @pytest.mark.parametrize("kind", [0, 1, 2])
-def test_row_culling_is_exact_on_random_tables(ctx, kind):
-    """The fast build folds, at a point of a long table built with union / subtract / intersect, the rows its grid cell lists
+def test_row_culling_is_exact_on_random_tables(ctx, kind, build):
+    """Either build folds, at a point of a long table built with union / subtract / intersect, the rows its grid cell lists
     (rm_device.hpp culled_rows; the rule: rm_params.hpp rm_cull_cell, tests/test_cull_rule_cpu.py): the others are exact no-ops
     there.  Random tables of 12 .. 200 rows (up to four 64-row words of the grid's cells): the distance at points inside the
     scene, around it, up to 1e7 away, at points with a NaN or an infinite coordinate, and castRay from random origins have the
     bits of the fold of every row (RM_RENDER_NO_CULL).  So do whole frames of three of the tables (full mode, two bounces, a
-    light; both implementations)."""
+    light; both implementations).  The parity build since round 4: the rule is about the shapes' distances, not the arithmetic."""
     NC = abi.RM_RENDER_NO_CULL
     rng = np.random.default_rng(2024 + 31 * kind + SEED_OFFSET)
     special = np.array([[np.nan, 0, 0], [0.5, np.nan, 1], [np.inf, 1, 1], [1, 1, -np.inf], [np.nan, np.nan, np.nan], [1e30, 0, 0], [3e38, 3e38, 3e38], [0, 0, 0]])
@@ -1735,24 +1736,24 @@ def test_row_culling_is_exact_on_random_tables(ctx, kind):
         sc = _cull_table(rng, kind, rows=[None, None, 64, 65, 130, 200, None, None, 12, 13][it])
         h = ctx.create_scene(sc)
         pts = np.concatenate([rng.uniform(-3, 3, (20000, 3)), rng.uniform(-12, 12, (6000, 3)), rng.normal(0, 1, (6000, 3)) * 10.0 ** rng.uniform(1, 7, (6000, 1)), special]).astype(np.float32)
-        a = ctx.probe(h, abi.RM_PROBE_SDF, pts, 0.0, FAST)
-        b = ctx.probe(h, abi.RM_PROBE_SDF, pts, 0.0, FAST | NC)
+        a = ctx.probe(h, abi.RM_PROBE_SDF, pts, 0.0, build)
+        b = ctx.probe(h, abi.RM_PROBE_SDF, pts, 0.0, build | NC)
         assert same_bits(a, b).all(), f"table {it} ({len(sc._nodes)} rows): the distance differs at {int((~same_bits(a, b)).sum())} points, first {pts[np.argmax(~same_bits(a, b))]}"
         o = rng.uniform(-5, 5, (16384, 3))
         d = rng.normal(0, 1, (16384, 3))
         d /= np.linalg.norm(d, axis=1, keepdims=True)
         rays = np.concatenate([o, d], 1).astype(np.float32)
         for steps in (24.0, 96.0):
-            ra = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST)
-            rb = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST | NC)
+            ra = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, build)
+            rb = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, build | NC)
             assert same_bits(ra, rb).all(), f"table {it}: {int((~same_bits(ra, rb)).any(-1).sum())} end points differ"
         h.destroy()
         if it < 3:
             schema = J.make_schema(sc, 256, 192, counts=(64, 32), render_mode="full", position=(0.3, 0.2, -6.0), lights=GC.LIGHT)
             noises = GC.halton_pairs(2)
-            ref = render_gpu(ctx, sc, schema, noises, FAST | MK | NC)
+            ref = render_gpu(ctx, sc, schema, noises, build | MK | NC)
             for impl in (MK, WF):
-                got = render_gpu(ctx, sc, schema, noises, FAST | impl)
+                got = render_gpu(ctx, sc, schema, noises, build | impl)
                 for k in range(3):
                     assert same_bits(got[k], ref[k]).all(), f"table {it}, plane {k}"
 
@@ -1766,7 +1767,8 @@ def _smooth_sphere_table(rng, rows):
     return sc
 
 
-def test_row_culling_of_smooth_sphere_tables_is_exact(ctx):
+@pytest.mark.parametrize("build", BUILDS, ids=BUILD_IDS)
+def test_row_culling_of_smooth_sphere_tables_is_exact(ctx, build):
     """Round 4.  A far row of a smooth union is not a no-op -- the fast fold rounds the running value to the row's grid -- except
     where the value already lies on a grid at least as coarse; the grid of a table of spheres under ONE smooth-union radius (CSG-64's
     shape) drops exactly those rows (rm_params.hpp rm_cull_cell_smooth_spheres; the rule against an fp32 fold:
@@ -1780,24 +1782,24 @@ def test_row_culling_of_smooth_sphere_tables_is_exact(ctx):
         sc = S.csg64() if rows == 0 else _smooth_sphere_table(rng, rows)
         h = ctx.create_scene(sc)
         pts = np.concatenate([rng.uniform(-3, 3, (30000, 3)), rng.uniform(-12, 12, (6000, 3)), rng.normal(0, 1, (6000, 3)) * 10.0 ** rng.uniform(1, 7, (6000, 1)), special]).astype(np.float32)
-        a = ctx.probe(h, abi.RM_PROBE_SDF, pts, 0.0, FAST)
-        b = ctx.probe(h, abi.RM_PROBE_SDF, pts, 0.0, FAST | NC)
+        a = ctx.probe(h, abi.RM_PROBE_SDF, pts, 0.0, build)
+        b = ctx.probe(h, abi.RM_PROBE_SDF, pts, 0.0, build | NC)
         assert same_bits(a, b).all(), f"table {it} ({len(sc._nodes)} rows): the distance differs at {int((~same_bits(a, b)).sum())} points, first {pts[np.argmax(~same_bits(a, b))]}"
         o = rng.uniform(-5, 5, (16384, 3))
         d = rng.normal(0, 1, (16384, 3))
         d /= np.linalg.norm(d, axis=1, keepdims=True)
         rays = np.concatenate([o, d], 1).astype(np.float32)
         for steps in (24.0, 128.0):
-            ra = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST)
-            rb = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, FAST | NC)
+            ra = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, build)
+            rb = ctx.probe(h, abi.RM_PROBE_CAST_RAY, rays, steps, build | NC)
             assert same_bits(ra, rb).all(), f"table {it}: {int((~same_bits(ra, rb)).any(-1).sum())} end points differ"
         h.destroy()
         if it < 4:
             schema = J.make_schema(sc, 320, 256, counts=(128, 64), render_mode="full", position=(0.0, 0.0, -5.0) if rows == 0 else (0.3, 0.2, -6.0), lights=GC.LIGHT)
             noises = GC.halton_pairs(2)
-            ref = render_gpu(ctx, sc, schema, noises, FAST | MK | NC)
+            ref = render_gpu(ctx, sc, schema, noises, build | MK | NC)
             for impl in (MK, WF):
-                got = render_gpu(ctx, sc, schema, noises, FAST | impl)
+                got = render_gpu(ctx, sc, schema, noises, build | impl)
                 for k in range(3):
                     assert same_bits(got[k], ref[k]).all(), f"table {it}, plane {k}: {int((~same_bits(got[k], ref[k])).sum())} values differ"
 
