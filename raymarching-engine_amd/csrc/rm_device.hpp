@@ -508,7 +508,7 @@ struct Sdf<RM_SCENE_TABLE> {
       }
       for (; i < end; i++) d = smooth_row(d, sphere_row1(rows[i], p), k, half_inv_k);
     };
-    if (sc.cull.cells == nullptr || lds.cull_here == 0u) {  // uniform over the kernel / the workgroup
+    if (sc.cull.cells == nullptr) {  // kernel-uniform
       fold_range(1, n);
       return d;
     }
@@ -518,8 +518,14 @@ struct Sdf<RM_SCENE_TABLE> {
     // and the whole word where the wave is spread over too many cells for a common list (the rays of a diffuse bounce) or the list is
     // not much shorter than the word (RM_CULL_SMOOTH_MAX: the scalar row loop costs more per row than the unrolled one).  The
     // pixel kernel switches the lookup off for the bounces after the first (lds.cull_here): their waves seldom share a list, and the
-    // cell's read and the union would be paid for nothing (C5: 156 ms with it on throughout, 151 without any culling).  Whatever is
+    // cell's read and the union would be paid for nothing (C5: 156 ms with it on throughout, 151 without any culling; asking there
+    // only whether the whole wave sits in ONE cell, and reading its list by a scalar address if so: 153 against 144 -- the cell index
+    // alone costs more than the few coherent steps at the start of a bounce return).  Whatever is
     // folded, the bits are those of the fold of every row (RM_RENDER_NO_CULL).
+    if (lds.cull_here == 0u) {  // workgroup-uniform
+      fold_range(1, n);
+      return d;
+    }
     const unsigned long long* cell = cull_cell(sc.cull, p);
     for (int w = 0; w < sc.cull.words; w++) {
       unsigned long long u = wave_union(cell[w]);

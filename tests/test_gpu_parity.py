@@ -1778,7 +1778,8 @@ def test_row_culling_of_smooth_sphere_tables_is_exact(ctx, build):
     NC = abi.RM_RENDER_NO_CULL
     rng = np.random.default_rng(977 + SEED_OFFSET)
     special = np.array([[np.nan, 0, 0], [0.5, np.nan, 1], [np.inf, 1, 1], [1, 1, -np.inf], [np.nan, np.nan, np.nan], [1e30, 0, 0], [3e38, 3e38, 3e38], [0, 0, 0]])
-    for it, rows in enumerate([0, 16, 17, 64, 65, 130, 200, 33]):
+    extra = int(os.environ.get("RM_CULL_TABLES", "0"))  # tools/fuzz.sh: hundreds more tables (profiles/r04_fuzz_log.txt)
+    for it, rows in enumerate([0, 16, 17, 64, 65, 130, 200, 33] + [int(r) for r in rng.integers(16, 257, extra)]):
         sc = S.csg64() if rows == 0 else _smooth_sphere_table(rng, rows)
         h = ctx.create_scene(sc)
         pts = np.concatenate([rng.uniform(-3, 3, (30000, 3)), rng.uniform(-12, 12, (6000, 3)), rng.normal(0, 1, (6000, 3)) * 10.0 ** rng.uniform(1, 7, (6000, 1)), special]).astype(np.float32)
