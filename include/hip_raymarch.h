@@ -214,9 +214,8 @@ enum {
   RM_RENDER_WAVEFRONT = 16,  /* ask for the wavefront pipeline (ray-compacting persistent march) -- a REQUEST: a table whose shapes
                                 name surfaces (RmSurface) always takes the pixel kernel, the pipeline has no per-shape materials;
                                 rm_ctx_last_pipeline tells which implementation a call ran.  With neither flag the
-                                library picks per job from a measured table: the single kernel -- in the strict
-                                build except for full-mode tiles of >= 16 M pixels over primitive tables of >= 16 rows.  Same
-                                results either way. */
+                                library takes the single kernel: since round 4 it is the faster one for every measured job
+                                in both builds (rm_api.hip prefer_wavefront has the table).  Same results either way. */
   RM_RENDER_NO_COST_CLASSES = 8, /* wavefront march in one pass even for scene kinds whose sdf cost depends on the
                                    point (Mandelbulb); a measurement switch, same results */
   RM_RENDER_NO_OVERLAP = 32, /* this sample runs alone on the context's stream and blends in its own kernel (see

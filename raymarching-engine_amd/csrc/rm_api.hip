@@ -1145,14 +1145,11 @@ static hipError_t launch_wavefront(rm_ctx* ctx, const KParams& P, int flags) {
 // The fast build's one-kernel form now wins or ties everywhere -- the pipeline's global ray compaction bought 10-16 % on the two
 // full CSG frames in round 2, 6 % after the pixel kernel compacted its table rays, nothing now -- and it needs no 240 bytes of
 // workspace per pixel: the fast build never picks the pipeline by itself any more (RM_RENDER_WAVEFRONT still forces it; it remains
-// the second implementation the tests hold the pixel kernel to).  The strict build keeps round 3's rule (165 against 170 ms on C4).
-static bool prefer_wavefront(const KParams& P, int flags) {
-  if (flags & RM_RENDER_FAST) return false;
-  if (P.u.renderMode == 1) return false;
-  if (P.scene.table_flags & (RM_TABLE_HAS_SURFACES | RM_TABLE_HAS_KIND)) return false;  // (see uses_wavefront)
-  if ((long long)P.tw * (long long)P.th < (1ll << 24)) return false;
-  return P.scene.kind == RM_SCENE_TABLE && P.scene.nprims >= 16;
-}
+// the second implementation the tests hold the pixel kernel to).  Round 4, with the exits, the job-shape variants and the row culling
+// in the parity build too, the same holds there (strict, pixel kernel / pipeline):
+//   CSG-64 4096x4096               26.5 / 29.8        CSG-64 8192^2, rank 0's 1/8    45.2 / 85.7
+// so the library never picks the pipeline by itself.
+static bool prefer_wavefront(const KParams&, int) { return false; }
 
 // The implementation a render call uses.  The GL-stack arithmetic exists as the pixel kernel only, and so do
 // position-dependent materials (RM_TABLE_HAS_SURFACES): the pipeline's stages carry one material block per scene -- its light
