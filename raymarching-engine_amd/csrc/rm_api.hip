@@ -426,7 +426,7 @@ static void table_far_field(const RmSceneDesc* desc, DevScene* dev) {
 // The culling grid of a primitive table without domain rows (rm_params.hpp CullGrid; rm_kernels.inc rm_cull_build_kernel has the
 // argument and fills it on the device; fast policy only): nested cubes of RM_CULL_N^3 cells about the shapes' bounding box, each
 // twice as wide as the one before, out to where fp32 no longer tells the rows apart.
-// For tables of at least RM_CULL_MIN_ROWS rows of which at least half stand under union / subtract / intersect.
+// For tables of at least RM_CULL_MIN_ROWS rows (round 3: those of mostly hard operators; round 4: every one, rm_params.hpp rm_cull_cell).
 #ifndef RM_CULL_MIN_ROWS
 #define RM_CULL_MIN_ROWS 12
 #endif
@@ -450,12 +450,10 @@ static bool table_cull_params(const RmSceneDesc* desc, CullGrid* g, CullBuild* b
   if (const char* v = std::getenv("RM_NO_CULL"))
     if (v[0] == '1') return false;
   double lo[3] = {1e30, 1e30, 1e30}, hi[3] = {-1e30, -1e30, -1e30}, kmax = 0.0;
-  int cullable = 0;  // rows under union / subtract / intersect: a smooth union is never dropped (rm_device.hpp smooth_row)
   for (int i = 0; i < n; i++) {
     const RmPrim& p = desc->prims[i];
     const int type = p.type & 0xff;
     if (type != RM_PRIM_SPHERE && type != RM_PRIM_BOX) return false;  // domain rows: no grid in the table's own space
-    if (i > 0 && ((p.type >> 8) & 0xff) != RM_OP_SMOOTH_UNION) cullable++;
     for (int a = 0; a < 3; a++) {
       const double e = std::fabs((double)(type == RM_PRIM_SPHERE ? p.size[0] : p.size[a]));
       lo[a] = std::fmin(lo[a], p.center[a] - e);
@@ -463,10 +461,10 @@ static bool table_cull_params(const RmSceneDesc* desc, CullGrid* g, CullBuild* b
     }
     if (((p.type >> 8) & 0xff) == RM_OP_SMOOTH_UNION) kmax = std::fmax(kmax, (double)p.k);
   }
-  // spheres under one smooth-union radius (CSG-64's shape; round 4): their far rows can be dropped where the rounding they perform is
-  // provably the identity (rm_params.hpp rm_cull_cell_smooth_spheres) -- on a finer grid, the binade tests want small cells
-  const bool smooth_spheres = n >= RM_TABLE_BIG_ROWS && rm_cull_uniform_smooth_spheres(desc->prims, n);
-  if (cullable * 2 < n && !smooth_spheres) return false;  // mostly smooth unions of other kinds: the grid would cost more than it saves
+  // a table of mostly smooth unions (CSG-64; round 4): their far rows are dropped where the rounding they perform is provably the
+  // identity (rm_params.hpp rm_cull_cell) -- on a finer grid, the binade tests want small cells
+  const bool smooth_spheres = rm_cull_mostly_smooth(desc->prims, n);
+  if (smooth_spheres && n < RM_TABLE_BIG_ROWS) return false;  // about half of such a table's rows stay: too few to pay for the lookup
   double half = 0.0, reach = 0.0;
   for (int a = 0; a < 3; a++) {
     half = std::fmax(half, 0.5 * (hi[a] - lo[a]));
@@ -482,7 +480,7 @@ static bool table_cull_params(const RmSceneDesc* desc, CullGrid* g, CullBuild* b
   build->half0 = half;
   build->reach = reach;
   build->nprims = n;
-  const int cells = smooth_spheres ? RM_CULL_N_SMOOTH : RM_CULL_N;
+  const int cells = smooth_spheres ? (n >= 32 ? RM_CULL_N_SMOOTH : RM_CULL_N_SMOOTH / 2) : RM_CULL_N;  // (17 MB instead of 134 for the shorter tables)
   build->n = cells;
   build->levels = levels;
   build->words = (n + 63) / 64;

@@ -469,7 +469,7 @@ struct Sdf<RM_SCENE_TABLE> {
   // fewer lit pixels, because the rounding of d to the grid of (di - d) that THIS form, like the reference's mix(d2, d1, 1), performs
   // for every far row is the noise the creeping shadow rays of a smooth-union scene live on.  Not kept:
   // profiles/r03_row_culling_smooth_union_experiment.txt.  Round 4 drops the rows for which that rounding is provably the identity:
-  // rm_params.hpp rm_cull_cell_smooth_spheres.)
+  // rm_params.hpp rm_cull_cell.)
   static RM_DEV float smooth_row(float d, float di, float k, float half_inv_k) {
     const float t = di - d;  // d - di is -t exactly (up to the sign of a zero): one subtraction instead of two
     const float h = gclamp(FM::fma(half_inv_k, t, 0.5f), 0.0f, 1.0f);
@@ -512,7 +512,7 @@ struct Sdf<RM_SCENE_TABLE> {
       fold_range(1, n);
       return d;
     }
-    // Round 4: the rows of this point's cell that are not exact no-ops (rm_params.hpp rm_cull_cell_smooth_spheres: a far row of a smooth
+    // Round 4: the rows of this point's cell that are not exact no-ops (rm_params.hpp rm_cull_cell: a far row of a smooth
     // union ROUNDS the running value, and where that rounding is provably the identity the row is skipped) -- about half of CSG-64's.
     // Folded: the union of the wave's cells (any superset of a lane's list gives the same bits: the extra rows are identities for it),
     // and the whole word where the wave is spread over too many cells for a common list (the rays of a diffuse bounce) or the list is
@@ -556,6 +556,20 @@ struct Sdf<RM_SCENE_TABLE> {
     const int n = sc.nprims;
     if (sc.table_flags & RM_TABLE_UNIFORM_K) return eval_spheres_one_k(sc, lds, p);  // kernel-uniform
     float d = sphere_row(lds.rows[0], lds.rows[1], p);
+    if (sc.cull.cells != nullptr) {  // kernel-uniform: the rows of the wave's cells, in this fold's own arithmetic (culled_rows)
+      culled_rows(sc, p,
+                  [&](int j, bool) {
+                    const float4 a0 = lds.rows[2 * j], b0 = lds.rows[2 * j + 1];
+                    d = smooth_row(d, sphere_row(a0, b0, p), a0.y, b0.z);
+                  },
+                  [&](int j0, int j1) {
+                    const float4 a0 = lds.rows[2 * j0], b0 = lds.rows[2 * j0 + 1], a1 = lds.rows[2 * j1], b1 = lds.rows[2 * j1 + 1];
+                    const float d0 = sphere_row(a0, b0, p), d1 = sphere_row(a1, b1, p);
+                    d = smooth_row(d, d0, a0.y, b0.z);
+                    d = smooth_row(d, d1, a1.y, b1.z);
+                  });
+      return d;
+    }
     int i = 1;
     for (; i + 1 < n; i += 2) {
       const float4 a0 = lds.rows[2 * i], b0 = lds.rows[2 * i + 1], a1 = lds.rows[2 * i + 2], b1 = lds.rows[2 * i + 3];

@@ -48,87 +48,83 @@ __host__ __device__ inline double rm_cull_shape_distance(const RmPrim& p, const 
 // The rows of a table (no domain rows) that an evaluation anywhere in the ball (c, rad) has to fold: bit i of out[] set = row i
 // stays.  The argument is with rm_cull_build_kernel (rm_kernels.inc), which calls this once per cell; host-callable so that the
 // CPU tests can check it against the fold itself (rm_debug_cull_cell).
-// ---- spheres under ONE smooth-union radius (RM_TABLE_UNIFORM_K: BASELINE's CSG-64), round 4 ---------------------------------------
-// Round 3 built row culling for smooth unions, measured it (C4 14.2 -> 7.0 ms) and took it out: a row further than k from the running
-// value does not leave it alone -- the fast fold's  d' = di - fl(di - d)  (h clamps to exactly 1) ROUNDS d to the grid of (di - d), and
-// that noise is what the creeping shadow rays of a smooth-union scene live on (14 % fewer lit pixels without it).  The rounding itself
-// can be reasoned about exactly.  Write e(x) = floor(log2 |x|); a float x is a multiple of 2^(e(x) - 23).
+//
+// Hard operators: min(d, di) with the shape further away than the running value can be anywhere in the cell, max(d, +-di) with
+// the term below it -- exact no-ops whatever the arithmetic.
+//
+// Smooth unions (round 4).  Round 3 built row culling for them, measured it (C4 14.2 -> 7.0 ms) and took it out: a row further than k
+// from the running value does not leave it alone -- mix(di, d, 1), in both builds' arithmetic, is  d' = fl(di - fl(di - d)): it ROUNDS
+// d to the grid of (di - d), and that noise is what the creeping shadow rays of a smooth-union scene live on (14 % fewer lit pixels
+// without it).  The rounding itself can be reasoned about exactly.  Write e(x) = floor(log2 |x|); a float x is a multiple of
+// 2^(e(x) - 23) (the argument is the same in any binary precision).
 //  * EXECUTING a far row m (t = fl(dm - d), d' = fl(dm - t)): dm and t are multiples of 2^(g - 23), g = min(e(dm), e(t)), so is their
 //    difference, and it is representable when |d'| < 2^(g + 1): then d' = dm - t exactly and d' lies ON THE GRID 2^(g - 23).
 //  * a later far row i finds d on a grid 2^(B - 23) with B >= e(di - d) and e(di - d) <= e(di): then di and d are both multiples of
 //    the unit of t = di - d, t is exact, and d'' = di - t = d: the row is an EXACT NO-OP and may be skipped.
-//  * any row that is not certainly far (its h may be below 1) moves d off every grid: the chain starts again after it; and a far row
-//    that is executed without meeting the no-op conditions leaves d on ITS grid, which may be finer than the one before.
-// Per cell (ball c, rad) the rule runs this bookkeeping on INTERVALS: the running value in [L, U] (the smooth minimum is monotone in both
+//  * any row that is executed and is not certainly far -- a near smooth union, a hard operator that may take the other value --
+//    moves d off every grid: the chain starts again after it; a far row that is executed without meeting the no-op conditions
+//    leaves d on ITS grid, which may be finer than the one before; a row that is skipped leaves d, and the grid it is on, alone.
+// Per cell the rule runs this bookkeeping on INTERVALS: the running value in [L, U] (the smooth minimum is monotone in both
 // arguments, so its interval is the smooth minimum of the ends), row i's distance in [lo_i, hi_i], binades taken where the whole
-// interval lies in one.  What it cannot decide it keeps: a kept row is the reference's own arithmetic.  tests/test_cull_rule_cpu.py
-// checks the rule against an fp32 restatement of the fast fold; the GPU suite holds the culled fold to RM_RENDER_NO_CULL bit for bit.
+// interval lies in one; a distance that is negative or changes sign in the cell claims nothing.  What the rule cannot decide it
+// keeps: a kept row is the reference's own arithmetic, and any superset of a point's list gives the same bits (the extra rows are
+// identities there) -- which is what lets a wave fold the union of its lanes' lists.  About half of CSG-64's 64 rows stay per cell.
+// tests/test_cull_rule_cpu.py checks the rule against fp32 restatements of both builds' folds; the GPU suite holds the culled fold
+// to RM_RENDER_NO_CULL bit for bit.
 __host__ __device__ inline double rm_smooth_min(double a, double b, double k) {  // examples/smooth-tree.glsl:20-22, in double
   double h = 0.5 + 0.5 * (b - a) / k;
   h = h < 0.0 ? 0.0 : (h > 1.0 ? 1.0 : h);
   return b + h * (a - b) - k * h * (1.0 - h);
 }
-__host__ __device__ inline bool rm_cull_uniform_smooth_spheres(const RmPrim* prims, int nprims) {
-  if (nprims < 2) return false;
-  for (int i = 0; i < nprims; i++) {
-    if ((prims[i].type & 0xff) != RM_PRIM_SPHERE) return false;
-    if (i > 0 && (((prims[i].type >> 8) & 0xff) != RM_OP_SMOOTH_UNION || prims[i].k != prims[1].k)) return false;
-  }
-  return prims[1].k > 0.0f;
-}
-__host__ __device__ inline void rm_cull_cell_smooth_spheres(const RmPrim* prims, int nprims, int words, const double* c, double rad, double margin, unsigned long long* out) {
-  const int NONE = -100000;
-  const double k = (double)prims[1].k;
-  const double d0 = rm_cull_shape_distance(prims[0], c);
-  double L = d0 - rad - margin, U = d0 + rad + margin;
-  int B = NONE;  // d is certainly a multiple of 2^(B - 23)
-  out[0] |= 1ull;
-  for (int i = 1; i < nprims; i++) {
-    const double di = rm_cull_shape_distance(prims[i], c), lo = di - rad - margin, hi = di + rad + margin;
-    bool keep = true;
-    if (!(lo - U >= 1.002 * k + margin)) {
-      B = NONE;  // possibly near: whatever grid d was on, it leaves it
-    } else {
-      const double emin = lo - U, emax = hi - L;  // t = di - d over the cell, both > 0
-      const int bmin = (int)floor(log2(emin * (1.0 - 1e-5))), bmax = (int)floor(log2(emax * (1.0 + 1e-5)));
-      // the lowest binade of |di| over the cell; a far row's distance may be negative (the running value is then further inside
-      // still) or change sign in the cell: then |di| has no lowest binade and nothing is claimed
-      const int bdi = lo > 0.0 ? (int)floor(log2(lo * (1.0 - 1e-5))) : (hi < 0.0 ? (int)floor(log2(-hi * (1.0 - 1e-5))) : NONE);
-      if (B != NONE && B >= bmax && bmax <= bdi) {
-        keep = false;  // an exact no-op everywhere in the cell
-      } else {
-        const int g = bmin < bdi ? bmin : bdi;
-        const double big = fabs(L) > fabs(U) ? fabs(L) : fabs(U);
-        B = g != NONE && big * (1.0 + 1e-5) < ldexp(1.0, g + 1) ? g : NONE;  // the grid this row leaves d on, when d' = dm - t is exact
-      }
-    }
-    L = rm_smooth_min(L, lo, k) - margin;
-    U = rm_smooth_min(U, hi, k) + margin;
-    if (keep) out[i >> 6] |= 1ull << (i & 63);
-  }
+// tables whose rows are mostly smooth unions get the finer grid: the binade tests want small cells (rm_api.hip table_cull_params)
+__host__ __device__ inline bool rm_cull_mostly_smooth(const RmPrim* prims, int nprims) {
+  int smooth = 0;
+  for (int i = 1; i < nprims; i++) smooth += ((prims[i].type >> 8) & 0xff) == RM_OP_SMOOTH_UNION;
+  return 2 * smooth > nprims;
 }
 
 __host__ __device__ inline void rm_cull_cell(const RmPrim* prims, int nprims, int words, const double* c, double rad, double margin, unsigned long long* out) {
+  const int NONE = -100000;
   for (int w = 0; w < words; w++) out[w] = 0ull;
-  if (rm_cull_uniform_smooth_spheres(prims, nprims)) {
-    rm_cull_cell_smooth_spheres(prims, nprims, words, c, rad, margin, out);
-    return;
-  }
   const double d0 = rm_cull_shape_distance(prims[0], c);
   double L = d0 - rad, U = d0 + rad;
   int best = 0;  // the nearest earlier row at c that bounds the running value from above (-1: none)
   double best_d = d0;
+  int B = NONE;  // the running value is certainly a multiple of 2^(B - 23)
   out[0] |= 1ull;
   for (int i = 1; i < nprims; i++) {
     const RmPrim p = prims[i];
     const int op = (p.type >> 8) & 0xff;
     const double di = rm_cull_shape_distance(p, c), lo_i = di - rad, hi_i = di + rad;
     bool keep;
-    if (op == RM_OP_UNION || op == RM_OP_SMOOTH_UNION) {
-      // (a smooth union always stays: even where h clamps, the kernels' form of it rounds the running value -- rm_device.hpp smooth_row)
+    if (op == RM_OP_SMOOTH_UNION) {
+      const double k = (double)p.k;  // > 0 (rm_scene_create)
+      keep = true;
+      if (!(lo_i - U >= 1.002 * k + 2.0 * margin)) {
+        B = NONE;  // possibly near: whatever grid d was on, it leaves it
+      } else {
+        const double emin = lo_i - U - 2.0 * margin, emax = hi_i - L + 2.0 * margin;  // t = di - d over the cell, both > 0
+        const int bmin = (int)floor(log2(emin * (1.0 - 1e-5))), bmax = (int)floor(log2(emax * (1.0 + 1e-5)));
+        // the lowest binade of |di| over the cell; a far row's distance may be negative (the running value is then further inside
+        // still) or change sign in the cell: then |di| has no lowest binade and nothing is claimed
+        const double lo_m = lo_i - margin, hi_m = hi_i + margin;
+        const int bdi = lo_m > 0.0 ? (int)floor(log2(lo_m * (1.0 - 1e-5))) : (hi_m < 0.0 ? (int)floor(log2(-hi_m * (1.0 - 1e-5))) : NONE);
+        if (B != NONE && B >= bmax && bmax <= bdi) {
+          keep = false;  // an exact no-op everywhere in the cell
+        } else {
+          const int g = bmin < bdi ? bmin : bdi;
+          const double big = (fabs(L) > fabs(U) ? fabs(L) : fabs(U)) + margin;
+          B = g != NONE && big * (1.0 + 1e-5) < ldexp(1.0, g + 1) ? g : NONE;  // the grid this row leaves d on, when d' = dm - t is exact
+        }
+      }
+      const double u_smooth = rm_smooth_min(U, hi_i, k) + margin;
+      U = fmin(fmin(U, hi_i), u_smooth);
+      L = rm_smooth_min(L, lo_i, k) - margin;  // (at most k / 4 below the minimum)
+      if (best < 0 || di < best_d) { best = i; best_d = di; }
+    } else if (op == RM_OP_UNION) {
       const double k = 0.0;
-      keep = op == RM_OP_SMOOTH_UNION || !(lo_i >= U + margin);
-      if (keep && op == RM_OP_UNION && best >= 0) {
+      keep = !(lo_i >= U + margin);
+      if (keep && best >= 0) {
         const RmPrim q = prims[best];
         const double sx = (double)p.center[0] - q.center[0], sy = (double)p.center[1] - q.center[1], sz = (double)p.center[2] - q.center[2];
         // the point the gradient of a shape's distance points away from: a sphere's centre; the nearest point of a box (within its
@@ -144,18 +140,19 @@ __host__ __device__ inline void rm_cull_cell(const RmPrim* prims, int nprims, in
         }
       }
       U = fmin(U, hi_i);
-      L = fmin(L, lo_i) - (op == RM_OP_SMOOTH_UNION ? 0.25 * fabs((double)p.k) + margin : 0.0);  // the smooth minimum is at most k / 4 below the minimum
+      L = fmin(L, lo_i);
       if (best < 0 || di < best_d) { best = i; best_d = di; }
+      if (keep) B = NONE;  // min(d, di) may hand on di
     } else if (op == RM_OP_SUBTRACT) {
       keep = !(-lo_i <= L - margin);
       U = fmax(U, -lo_i);
       L = fmax(L, -hi_i);
-      if (keep) best = -1;  // the value may now exceed every earlier term
+      if (keep) best = -1, B = NONE;  // the value may now exceed every earlier term
     } else {
       keep = !(hi_i <= L - margin);
       U = fmax(U, hi_i);
       L = fmax(L, lo_i);
-      if (keep) best = -1;  // max(d, di) where di may win: no earlier term bounds the value from above any more
+      if (keep) best = -1, B = NONE;  // max(d, di) where di may win: no earlier term bounds the value from above any more
     }
     if (keep) out[i >> 6] |= 1ull << (i & 63);
   }

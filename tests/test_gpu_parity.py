@@ -1707,9 +1707,9 @@ def test_kernel_variants_by_job_shape_leave_the_same_bits(ctx, scene, build):
 
 def _cull_table(rng, kind, rows=None):
     """a random table without domain rows, long enough for the culling grid: spheres and boxes under 0 = unions, 1 = unions,
-    subtractions and intersections, 2 = those and smooth unions (which this rule never drops; tables of spheres under ONE smooth-union radius have their own: the next test)"""
+    subtractions and intersections, 2 = those and smooth unions, 3 = mostly smooth unions of several radii (the finer grid)"""
     sc = S.CsgScene()
-    p = [[1.0, 0, 0, 0], [0.6, 0, 0.25, 0.15], [0.5, 0.25, 0.15, 0.1]][kind]
+    p = [[1.0, 0, 0, 0], [0.6, 0, 0.25, 0.15], [0.5, 0.25, 0.15, 0.1], [0.1, 0.8, 0.05, 0.05]][kind]
     for _ in range(rows or int(rng.integers(12, 100))):
         [sc.union, lambda: sc.smooth_union(float(rng.uniform(0.05, 0.5))), sc.subtract, sc.intersect][int(rng.choice(4, p=p))]()
         c = rng.uniform(-2, 2, 3)
@@ -1721,11 +1721,11 @@ def _cull_table(rng, kind, rows=None):
 
 
 @pytest.mark.parametrize("build", BUILDS, ids=BUILD_IDS)
-@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
 def test_row_culling_is_exact_on_random_tables(ctx, kind, build):
-    """Either build folds, at a point of a long table built with union / subtract / intersect, the rows its grid cell lists
-    (rm_device.hpp culled_rows; the rule: rm_params.hpp rm_cull_cell, tests/test_cull_rule_cpu.py): the others are exact no-ops
-    there.  Random tables of 12 .. 200 rows (up to four 64-row words of the grid's cells): the distance at points inside the
+    """Either build folds, at a point of a long table without domain rows, the rows its grid cell lists (rm_device.hpp culled_rows;
+    the rule: rm_params.hpp rm_cull_cell, tests/test_cull_rule_cpu.py): the others are exact no-ops there -- a hard operator that
+    cannot change the running value, a far smooth union whose rounding of it is the identity (round 4).  Random tables of 12 .. 200 rows (up to four 64-row words of the grid's cells): the distance at points inside the
     scene, around it, up to 1e7 away, at points with a NaN or an infinite coordinate, and castRay from random origins have the
     bits of the fold of every row (RM_RENDER_NO_CULL).  So do whole frames of three of the tables (full mode, two bounces, a
     light; both implementations).  The parity build since round 4: the rule is about the shapes' distances, not the arithmetic."""
@@ -1758,11 +1758,13 @@ def test_row_culling_is_exact_on_random_tables(ctx, kind, build):
                     assert same_bits(got[k], ref[k]).all(), f"table {it}, plane {k}"
 
 
-def _smooth_sphere_table(rng, rows):
+def _smooth_sphere_table(rng, rows, one_k=True):
     sc = S.CsgScene()
     sc.smooth_union(float(np.float32(rng.uniform(0.05, 0.4))))
     spread = float(rng.uniform(0.8, 2.5))
     for _ in range(rows):
+        if not one_k:  # several radii: the general fold (the fast build's own loop is for one)
+            sc.smooth_union(float(np.float32(rng.uniform(0.05, 0.4))))
         sc.sphere(rng.uniform(-spread, spread, 3), float(rng.uniform(0.15, 0.5)))
     return sc
 
@@ -1771,7 +1773,7 @@ def _smooth_sphere_table(rng, rows):
 def test_row_culling_of_smooth_sphere_tables_is_exact(ctx, build):
     """Round 4.  A far row of a smooth union is not a no-op -- the fast fold rounds the running value to the row's grid -- except
     where the value already lies on a grid at least as coarse; the grid of a table of spheres under ONE smooth-union radius (CSG-64's
-    shape) drops exactly those rows (rm_params.hpp rm_cull_cell_smooth_spheres; the rule against an fp32 fold:
+    shape; every fourth table here has several radii) drops exactly those rows (rm_params.hpp rm_cull_cell; the rule against an fp32 fold:
     tests/test_cull_rule_cpu.py).  CSG-64 and random tables of 16 .. 200 such rows: the distance at points in, around and far from the
     scene and at points with NaN / infinite coordinates, castRay end points, and whole frames of both implementations (two bounces, a
     light: the creeping shadow rays round 3's inexact version changed) have the bits of the fold of every row (RM_RENDER_NO_CULL)."""
@@ -1780,7 +1782,7 @@ def test_row_culling_of_smooth_sphere_tables_is_exact(ctx, build):
     special = np.array([[np.nan, 0, 0], [0.5, np.nan, 1], [np.inf, 1, 1], [1, 1, -np.inf], [np.nan, np.nan, np.nan], [1e30, 0, 0], [3e38, 3e38, 3e38], [0, 0, 0]])
     extra = int(os.environ.get("RM_CULL_TABLES", "0"))  # tools/fuzz.sh: hundreds more tables (profiles/r04_fuzz_log.txt)
     for it, rows in enumerate([0, 16, 17, 64, 65, 130, 200, 33] + [int(r) for r in rng.integers(16, 257, extra)]):
-        sc = S.csg64() if rows == 0 else _smooth_sphere_table(rng, rows)
+        sc = S.csg64() if rows == 0 else _smooth_sphere_table(rng, rows, one_k=it % 4 != 3)
         h = ctx.create_scene(sc)
         pts = np.concatenate([rng.uniform(-3, 3, (30000, 3)), rng.uniform(-12, 12, (6000, 3)), rng.normal(0, 1, (6000, 3)) * 10.0 ** rng.uniform(1, 7, (6000, 1)), special]).astype(np.float32)
         a = ctx.probe(h, abi.RM_PROBE_SDF, pts, 0.0, build)

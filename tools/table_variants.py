@@ -23,6 +23,16 @@ cases = [("c4 full", S.csg64(), dict(width=4096, height=4096, counts=(128,), ren
          ("csg_blocks (192 rows, hard operators) 1080p", S.csg_blocks(), dict(width=1920, height=1080, counts=(128, 64), render_mode="full", position=(0.3, 0.2, -6.0), lights=GC.LIGHT), None, (MK, WF)),
          ("csg_blocks preview 1080p", S.csg_blocks(), dict(width=1920, height=1080, counts=(128,), render_mode="preview", position=(0.3, 0.2, -6.0)), None, (MK,)),
          ("csg_mixed 1080p", GC.build_scene("csg_mixed"), dict(width=1920, height=1080, counts=(128, 64), render_mode="full", position=(0.3, 0.2, -4.0), lights=GC.LIGHT), None, (MK,))]
+def smooth_table(rows, boxes, seed=11):  # mostly smooth unions of several radii (round 4: the general fold culls their far rows too)
+    import numpy as np
+    rng = np.random.default_rng(seed); t = S.CsgScene()
+    for i in range(rows):
+        t.smooth_union(float(np.float32(rng.uniform(0.05, 0.4)))) if rng.uniform() < 0.9 or i == 0 else t.union()
+        c = rng.uniform(-2, 2, 3)
+        t.box(c, rng.uniform(0.1, 0.5, 3)) if boxes and rng.uniform() < 0.4 else t.sphere(c, float(rng.uniform(0.2, 0.6)))
+    return t
+cases += [("smooth spheres, 64 rows of several radii, 1080p", smooth_table(64, False), dict(width=1920, height=1080, counts=(128, 64), render_mode="full", position=(0.3, 0.2, -6.0), lights=GC.LIGHT), None, (MK,)),
+          ("smooth spheres and boxes, 96 rows, 1080p", smooth_table(96, True), dict(width=1920, height=1080, counts=(128, 64), render_mode="full", position=(0.3, 0.2, -6.0), lights=GC.LIGHT), None, (MK,))]
 for name, sc, kw, parts, impls in cases:
     schema = J.make_schema(sc, **kw); h = ctx.create_scene(sc)
     fb = ctx.create_framebuffer(kw["width"], kw["height"]) if parts is None else ctx.create_striped_framebuffer(kw["width"], kw["height"], shard.STRIPE_ROWS, parts, 0)
