@@ -231,9 +231,9 @@ enum {
   RM_RENDER_NO_CULL = 128     /* long primitive tables (no domain rows): evaluate every row of the table at every point instead of
                                 the rows the point's grid cell lists.  A row that is an exact no-op everywhere in the cell is
                                 skipped: min(d, di) with the shape further away than the running value, max(d, +-di) with the term
-                                below it; and, in a table of spheres under ONE smooth-union radius, a far row whose rounding of
-                                the running value -- d' = fl(di - fl(di - d)), what mix(di, d, 1) does -- is provably the identity
-                                because d already lies on a grid at least as coarse.  Other smooth-union rows are never skipped.
+                                below it; and a far smooth-union row whose rounding of the running value -- d' = fl(di -
+                                fl(di - d)), what mix(di, d, 1) does -- is provably the identity because d already lies on a
+                                grid at least as coarse.  Other smooth-union rows are never skipped.
                                 Both builds since round 4 (the parity build's GL-stack arithmetic folds every row).  A measurement
                                 and test switch: the same bits either way. */
 };
@@ -312,7 +312,7 @@ int rm_debug_counters(rm_ctx* ctx, unsigned long long* out16, int reset);
 
 /* Debug (tests): the rows of a primitive table (no domain rows) that an evaluation anywhere in the ball (centre, radius) has
  * to fold -- what the culling grid stores per cell (RM_RENDER_NO_CULL) -- as (nprims + 63) / 64 64-bit words,
- * bit i = row i stays (row 0 always does; smooth-union rows do except in a table of spheres under one smooth-union radius); `margin` = the allowance for fp32 rounding (0 tests the rule in
+ * bit i = row i stays (row 0 always does); `margin` = the allowance for fp32 rounding (0 tests the rule in
  * exact arithmetic).  Host arithmetic:
  * needs no GPU and no context.  Returns RM_ERR_INVALID for a table with domain rows. */
 int rm_debug_cull_cell(const RmSceneDesc* desc, const double* centre, double radius, double margin, unsigned long long* out_words);
