@@ -1732,8 +1732,8 @@ def test_row_culling_is_exact_on_random_tables(ctx, kind, build):
     NC = abi.RM_RENDER_NO_CULL
     rng = np.random.default_rng(2024 + 31 * kind + SEED_OFFSET)
     special = np.array([[np.nan, 0, 0], [0.5, np.nan, 1], [np.inf, 1, 1], [1, 1, -np.inf], [np.nan, np.nan, np.nan], [1e30, 0, 0], [3e38, 3e38, 3e38], [0, 0, 0]])
-    for it in range(10):
-        sc = _cull_table(rng, kind, rows=[None, None, 64, 65, 130, 200, None, None, 12, 13][it])
+    for it in range(10 + int(os.environ.get("RM_CULL_TABLES", "0"))):  # tools/fuzz.sh: hundreds more tables
+        sc = _cull_table(rng, kind, rows=[None, None, 64, 65, 130, 200, None, None, 12, 13][it] if it < 10 else None)
         h = ctx.create_scene(sc)
         pts = np.concatenate([rng.uniform(-3, 3, (20000, 3)), rng.uniform(-12, 12, (6000, 3)), rng.normal(0, 1, (6000, 3)) * 10.0 ** rng.uniform(1, 7, (6000, 1)), special]).astype(np.float32)
         a = ctx.probe(h, abi.RM_PROBE_SDF, pts, 0.0, build)

@@ -13,6 +13,7 @@ RM_RANDOM_SCENES=12000 timeout 1500 python -m pytest tests/test_gpu_parity.py -m
 RM_RANDOM_JOBS2=6000 timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "random_jobs_partitions" 2>&1 | tail -1
 for seed in 1 2 3; do echo "far field x30, seed $seed"; RM_RANDOM_SEED=$seed RM_FAR_RAYS=30 timeout 1500 python -m pytest tests/test_gpu_far_field.py -m gpu -q -x 2>&1 | tail -1; done
 for seed in 1 2 3 4 5 6; do RM_RANDOM_SEED=$seed timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "far_jump or far_field or row_culling or shadow_rays" 2>&1 | tail -1; done
+for b in fast strict; do echo "row culling of random tables of every kind (hard operators, mixed, mostly smooth), 200 more tables each, seed 9, $b"; RM_RANDOM_SEED=9 RM_CULL_TABLES=200 timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "row_culling_is_exact and $b" 2>&1 | tail -1; done
 for seed in 7 8; do for b in fast strict; do echo "row culling of smooth sphere tables, 300 more tables of 16..256 rows, seed $seed, $b"; RM_RANDOM_SEED=$seed RM_CULL_TABLES=300 timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "row_culling_of_smooth and $b" 2>&1 | tail -1; done; done
 date
 } 2>&1 | tee $O/log.txt
