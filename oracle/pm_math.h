@@ -1,5 +1,5 @@
 /* Portable transcendentals of the PARITY arithmetic ("PM"): sin, cos, log, exp, pow, acos, atan2 of a float, computed
- * in double precision from +, -, *, /, sqrt, floor and rint only -- operations IEEE 754 defines bit for bit -- and rounded
+ * in double precision from +, -, *, /, sqrt, fusedMultiplyAdd, floor and rint only -- operations IEEE 754 defines bit for bit -- and rounded
  * to float once.  The same text is compiled into the CPU oracle (oracle/pm_math.h) and into the HIP kernels
  * (raymarching-engine_amd/csrc/rm_pm_math.hpp; tests/test_host_cpu.py checks that the two files agree), both with
  * -ffp-contract=off, so the strict build and the oracle agree on every transcendental bit for bit, on any libm / ocml.
@@ -9,7 +9,8 @@
  * (series truncated below 1e-13; arguments of sin/cos up to ~1e6 in magnitude), so the float is the correctly rounded
  * one except for about one argument in 10^5.  Series coefficients are the exact Taylor / Gregory rationals, not fitted.
  *
- * The including file defines PM_FN (function qualifiers), PM_D2U / PM_U2D (bit casts double <-> 64-bit unsigned) and
+ * (Round 4: the Horner steps of the series are fused multiply-adds -- half the double-precision instructions on the GPU.)
+ * The including file defines PM_FN (function qualifiers), PM_FMA / PM_FMAK (IEEE fusedMultiplyAdd of doubles; K: the addend is a constant), PM_D2U / PM_U2D (bit casts double <-> 64-bit unsigned) and
  * PM_F2U (float -> 32-bit unsigned). */
 
 #define PM_PIO2_HI 1.5707963267341256      /* the first 31 bits of pi/2: k * PM_PIO2_HI is exact for |k| < 2^22 */
@@ -24,15 +25,16 @@
  * correct digit left (|x| beyond ~1e15), for +-Inf and for NaN.  The path's arguments are a few turns at most. */
 PM_FN void pm_sincos_d(double x, double* s, double* c) {
   const double k = rint(x * 0.6366197723675814);               /* nearest multiple of pi/2 */
-  const double r = (x - k * PM_PIO2_HI) - k * PM_PIO2_LO;      /* |r| <= pi/4 */
+  const double r = PM_FMA(-k, PM_PIO2_LO, PM_FMA(-k, PM_PIO2_HI, x));  /* |r| <= pi/4 (k * PM_PIO2_HI is exact) */
   if (!(r >= -1.0 && r <= 1.0)) { *s = *c = (double)__builtin_nanf(""); return; }  /* |x| beyond ~1e15, Inf, NaN */
   const double z = r * r;
-  const double sr = r + r * z * (-0.16666666666666666 + z * (0.008333333333333333 + z * (
-      -0.0001984126984126984 + z * (2.7557319223985893e-06 + z * (-2.505210838544172e-08 + z * (
-      1.6059043836821613e-10 + z * (-7.647163731819816e-13)))))));
-  const double cr = 1.0 - 0.5 * z + z * z * (0.041666666666666664 + z * (-0.001388888888888889 + z * (
-      2.48015873015873e-05 + z * (-2.755731922398589e-07 + z * (2.08767569878681e-09 + z * (
-      -1.1470745597729725e-11 + z * (4.779477332387385e-14)))))));
+  const double sr = PM_FMA(r * z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, -7.647163731819816e-13,
+      1.6059043836821613e-10), -2.505210838544172e-08), 2.7557319223985893e-06), -0.0001984126984126984),
+      0.008333333333333333), -0.16666666666666666), r);
+  const double cr = PM_FMA(z * z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, 4.779477332387385e-14,
+      -1.1470745597729725e-11), 2.08767569878681e-09), -2.755731922398589e-07), 2.48015873015873e-05),
+      -0.001388888888888889), 0.041666666666666664),
+      PM_FMAK(-0.5, z, 1.0));
   const double q = k - 4.0 * floor(k * 0.25);                  /* quadrant 0..3 (NaN for a NaN argument) */
   if (q == 1.0) { *s = cr; *c = -sr; }
   else if (q == 2.0) { *s = -sr; *c = -cr; }
@@ -48,21 +50,20 @@ PM_FN double pm_log_d(double x) {
   if (m > 1.4142135623730951) { m = m * 0.5; e = e + 1.0; }                /* [sqrt 1/2, sqrt 2] */
   const double t = (m - 1.0) / (m + 1.0);                                    /* log m = 2 atanh t, |t| <= 0.1716 */
   const double z = t * t;
-  const double p = z * (0.3333333333333333 + z * (0.2 + z * (0.14285714285714285 + z * (
-      0.1111111111111111 + z * (0.09090909090909091 + z * (0.07692307692307693 + z * (
-      0.06666666666666667 + z * (0.058823529411764705 + z * (0.05263157894736842 + z * (
-      0.047619047619047616))))))))));
-  return (e * PM_LN2_HI + 2.0 * t) + (2.0 * t * p + e * PM_LN2_LO);
+  const double p = z * PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z,
+      0.047619047619047616, 0.05263157894736842), 0.058823529411764705), 0.06666666666666667), 0.07692307692307693),
+      0.09090909090909091), 0.1111111111111111), 0.14285714285714285), 0.2), 0.3333333333333333);
+  return PM_FMA(e, PM_LN2_HI, 2.0 * t) + PM_FMA(2.0 * t, p, e * PM_LN2_LO);
 }
 
 /* e^t for -150 <= t <= 150 */
 PM_FN double pm_exp_d(double t) {
   const double k = rint(t * 1.4426950408889634);
-  const double r = (t - k * PM_LN2_HI) - k * PM_LN2_LO;        /* |r| <= ln 2 / 2 */
-  const double p = 1.0 + r + r * r * (0.5 + r * (0.16666666666666666 + r * (0.041666666666666664 + r * (
-      0.008333333333333333 + r * (0.001388888888888889 + r * (0.0001984126984126984 + r * (
-      2.48015873015873e-05 + r * (2.7557319223985893e-06 + r * (2.755731922398589e-07 + r * (
-      2.505210838544172e-08 + r * (2.08767569878681e-09 + r * (1.6059043836821613e-10))))))))))));
+  const double r = PM_FMA(-k, PM_LN2_LO, PM_FMA(-k, PM_LN2_HI, t));  /* |r| <= ln 2 / 2 (k * PM_LN2_HI is exact) */
+  const double p = PM_FMA(r * r, PM_FMAK(r, PM_FMAK(r, PM_FMAK(r, PM_FMAK(r, PM_FMAK(r, PM_FMAK(r, PM_FMAK(r, PM_FMAK(r, PM_FMAK(r, PM_FMAK(r,
+      PM_FMAK(r, 1.6059043836821613e-10, 2.08767569878681e-09), 2.505210838544172e-08), 2.755731922398589e-07),
+      2.7557319223985893e-06), 2.48015873015873e-05), 0.0001984126984126984), 0.001388888888888889),
+      0.008333333333333333), 0.041666666666666664), 0.16666666666666666), 0.5), 1.0 + r);
   const double scale = PM_U2D((unsigned long long)((int)k + 1023) << 52);  /* 2^k, normal: |k| <= 217 */
   return p * scale;
 }
@@ -73,11 +74,11 @@ PM_FN double pm_atan_pos_d(double t) {
   if (t > 2.414213562373095) { t = -1.0 / t; base = PM_PI_2; }                      /* atan t = pi/2 - atan(1/t) */
   else if (t > 0.41421356237309503) { t = (t - 1.0) / (t + 1.0); base = PM_PI_4; }  /* atan t = pi/4 + atan((t-1)/(t+1)) */
   const double z = t * t;                                                              /* |t| <= tan(pi/8) */
-  return base + (t + t * z * (-0.3333333333333333 + z * (0.2 + z * (-0.14285714285714285 + z * (
-      0.1111111111111111 + z * (-0.09090909090909091 + z * (0.07692307692307693 + z * (
-      -0.06666666666666667 + z * (0.058823529411764705 + z * (-0.05263157894736842 + z * (
-      0.047619047619047616 + z * (-0.043478260869565216 + z * (0.04 + z * (-0.037037037037037035 + z * (
-      0.034482758620689655 + z * (-0.03225806451612903))))))))))))))));
+  return base + PM_FMA(t * z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z,
+      PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, -0.03225806451612903, 0.034482758620689655), -0.037037037037037035),
+      0.04), -0.043478260869565216), 0.047619047619047616), -0.05263157894736842), 0.058823529411764705),
+      -0.06666666666666667), 0.07692307692307693), -0.09090909090909091), 0.1111111111111111), -0.14285714285714285),
+      0.2), -0.3333333333333333), t);
 }
 
 PM_FN float pm_sin(float x) { double s, c; pm_sincos_d((double)x, &s, &c); return (float)s; }

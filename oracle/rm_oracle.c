@@ -91,6 +91,8 @@ static inline float o_rounded(float v) {
 }
 
 #define PM_FN static inline
+#define PM_FMA(a, b, c) fma((a), (b), (c)) /* IEEE fusedMultiplyAdd: one rounding, in hardware (-mfma) or in libm, the same bits */
+#define PM_FMAK(a, b, k) fma((a), (b), (k)) /* ... with a constant addend (the kernels issue it with the constant in scalar registers) */
 static inline unsigned long long PM_D2U(double x) { unsigned long long u; memcpy(&u, &x, 8); return u; }
 static inline double PM_U2D(unsigned long long u) { double x; memcpy(&x, &u, 8); return x; }
 static inline unsigned int PM_F2U(float x) { unsigned int u; memcpy(&u, &x, 4); return u; }

@@ -6,6 +6,16 @@
 // parity build is not the fast path; the fast build uses these only in the shading between the marches.
 #pragma once
 #define PM_FN static __device__ __forceinline__
+// explicit fused operations, not contractions (the builds compile with -ffp-contract=off).  A Horner step's addend is a constant: left to
+// itself hipcc keeps all sixty of them in VGPRs for v_fmac_f64 and spills (strict C3b 56 -> 217 ms); as one VOP3 instruction with the
+// constant in scalar registers the step is what it should be
+#define PM_FMA(a, b, c) __builtin_fma((a), (b), (c))
+static __device__ __forceinline__ double pm_fmak(double a, double b, double k) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+  return r;
+}
+#define PM_FMAK(a, b, k) pm_fmak((a), (b), (k))
 #define PM_D2U(x) ((unsigned long long)__double_as_longlong(x))
 #define PM_U2D(u) __longlong_as_double((long long)(u))
 #define PM_F2U(x) __float_as_uint(x)
@@ -22,15 +32,16 @@
  * correct digit left (|x| beyond ~1e15), for +-Inf and for NaN.  The path's arguments are a few turns at most. */
 PM_FN void pm_sincos_d(double x, double* s, double* c) {
   const double k = rint(x * 0.6366197723675814);               /* nearest multiple of pi/2 */
-  const double r = (x - k * PM_PIO2_HI) - k * PM_PIO2_LO;      /* |r| <= pi/4 */
+  const double r = PM_FMA(-k, PM_PIO2_LO, PM_FMA(-k, PM_PIO2_HI, x));  /* |r| <= pi/4 (k * PM_PIO2_HI is exact) */
   if (!(r >= -1.0 && r <= 1.0)) { *s = *c = (double)__builtin_nanf(""); return; }  /* |x| beyond ~1e15, Inf, NaN */
   const double z = r * r;
-  const double sr = r + r * z * (-0.16666666666666666 + z * (0.008333333333333333 + z * (
-      -0.0001984126984126984 + z * (2.7557319223985893e-06 + z * (-2.505210838544172e-08 + z * (
-      1.6059043836821613e-10 + z * (-7.647163731819816e-13)))))));
-  const double cr = 1.0 - 0.5 * z + z * z * (0.041666666666666664 + z * (-0.001388888888888889 + z * (
-      2.48015873015873e-05 + z * (-2.755731922398589e-07 + z * (2.08767569878681e-09 + z * (
-      -1.1470745597729725e-11 + z * (4.779477332387385e-14)))))));
+  const double sr = PM_FMA(r * z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, -7.647163731819816e-13,
+      1.6059043836821613e-10), -2.505210838544172e-08), 2.7557319223985893e-06), -0.0001984126984126984),
+      0.008333333333333333), -0.16666666666666666), r);
+  const double cr = PM_FMA(z * z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, 4.779477332387385e-14,
+      -1.1470745597729725e-11), 2.08767569878681e-09), -2.755731922398589e-07), 2.48015873015873e-05),
+      -0.001388888888888889), 0.041666666666666664),
+      PM_FMAK(-0.5, z, 1.0));
   const double q = k - 4.0 * floor(k * 0.25);                  /* quadrant 0..3 (NaN for a NaN argument) */
   if (q == 1.0) { *s = cr; *c = -sr; }
   else if (q == 2.0) { *s = -sr; *c = -cr; }
@@ -46,21 +57,20 @@ PM_FN double pm_log_d(double x) {
   if (m > 1.4142135623730951) { m = m * 0.5; e = e + 1.0; }                /* [sqrt 1/2, sqrt 2] */
   const double t = (m - 1.0) / (m + 1.0);                                    /* log m = 2 atanh t, |t| <= 0.1716 */
   const double z = t * t;
-  const double p = z * (0.3333333333333333 + z * (0.2 + z * (0.14285714285714285 + z * (
-      0.1111111111111111 + z * (0.09090909090909091 + z * (0.07692307692307693 + z * (
-      0.06666666666666667 + z * (0.058823529411764705 + z * (0.05263157894736842 + z * (
-      0.047619047619047616))))))))));
-  return (e * PM_LN2_HI + 2.0 * t) + (2.0 * t * p + e * PM_LN2_LO);
+  const double p = z * PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z,
+      0.047619047619047616, 0.05263157894736842), 0.058823529411764705), 0.06666666666666667), 0.07692307692307693),
+      0.09090909090909091), 0.1111111111111111), 0.14285714285714285), 0.2), 0.3333333333333333);
+  return PM_FMA(e, PM_LN2_HI, 2.0 * t) + PM_FMA(2.0 * t, p, e * PM_LN2_LO);
 }
 
 /* e^t for -150 <= t <= 150 */
 PM_FN double pm_exp_d(double t) {
   const double k = rint(t * 1.4426950408889634);
-  const double r = (t - k * PM_LN2_HI) - k * PM_LN2_LO;        /* |r| <= ln 2 / 2 */
-  const double p = 1.0 + r + r * r * (0.5 + r * (0.16666666666666666 + r * (0.041666666666666664 + r * (
-      0.008333333333333333 + r * (0.001388888888888889 + r * (0.0001984126984126984 + r * (
-      2.48015873015873e-05 + r * (2.7557319223985893e-06 + r * (2.755731922398589e-07 + r * (
-      2.505210838544172e-08 + r * (2.08767569878681e-09 + r * (1.6059043836821613e-10))))))))))));
+  const double r = PM_FMA(-k, PM_LN2_LO, PM_FMA(-k, PM_LN2_HI, t));  /* |r| <= ln 2 / 2 (k * PM_LN2_HI is exact) */
+  const double p = PM_FMA(r * r, PM_FMAK(r, PM_FMAK(r, PM_FMAK(r, PM_FMAK(r, PM_FMAK(r, PM_FMAK(r, PM_FMAK(r, PM_FMAK(r, PM_FMAK(r, PM_FMAK(r,
+      PM_FMAK(r, 1.6059043836821613e-10, 2.08767569878681e-09), 2.505210838544172e-08), 2.755731922398589e-07),
+      2.7557319223985893e-06), 2.48015873015873e-05), 0.0001984126984126984), 0.001388888888888889),
+      0.008333333333333333), 0.041666666666666664), 0.16666666666666666), 0.5), 1.0 + r);
   const double scale = PM_U2D((unsigned long long)((int)k + 1023) << 52);  /* 2^k, normal: |k| <= 217 */
   return p * scale;
 }
@@ -71,11 +81,11 @@ PM_FN double pm_atan_pos_d(double t) {
   if (t > 2.414213562373095) { t = -1.0 / t; base = PM_PI_2; }                      /* atan t = pi/2 - atan(1/t) */
   else if (t > 0.41421356237309503) { t = (t - 1.0) / (t + 1.0); base = PM_PI_4; }  /* atan t = pi/4 + atan((t-1)/(t+1)) */
   const double z = t * t;                                                              /* |t| <= tan(pi/8) */
-  return base + (t + t * z * (-0.3333333333333333 + z * (0.2 + z * (-0.14285714285714285 + z * (
-      0.1111111111111111 + z * (-0.09090909090909091 + z * (0.07692307692307693 + z * (
-      -0.06666666666666667 + z * (0.058823529411764705 + z * (-0.05263157894736842 + z * (
-      0.047619047619047616 + z * (-0.043478260869565216 + z * (0.04 + z * (-0.037037037037037035 + z * (
-      0.034482758620689655 + z * (-0.03225806451612903))))))))))))))));
+  return base + PM_FMA(t * z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z,
+      PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, PM_FMAK(z, -0.03225806451612903, 0.034482758620689655), -0.037037037037037035),
+      0.04), -0.043478260869565216), 0.047619047619047616), -0.05263157894736842), 0.058823529411764705),
+      -0.06666666666666667), 0.07692307692307693), -0.09090909090909091), 0.1111111111111111), -0.14285714285714285),
+      0.2), -0.3333333333333333), t);
 }
 
 PM_FN float pm_sin(float x) { double s, c; pm_sincos_d((double)x, &s, &c); return (float)s; }

@@ -259,6 +259,8 @@ def test_portable_math_is_correctly_rounded_on_samples():
 #include <math.h>
 #include <string.h>
 #define PM_FN static inline
+#define PM_FMA(a, b, c) fma((a), (b), (c))
+#define PM_FMAK(a, b, k) fma((a), (b), (k))
 static inline unsigned long long PM_D2U(double x) { unsigned long long u; memcpy(&u, &x, 8); return u; }
 static inline double PM_U2D(unsigned long long u) { double x; memcpy(&x, &u, 8); return x; }
 static inline unsigned int PM_F2U(float x) { unsigned int u; memcpy(&u, &x, 4); return u; }
