@@ -68,4 +68,4 @@ txt = (header(name, rd(P, name).split("\n\n", 1)[1][:20]) + rd(F, "log.txt") + "
        + rd(F, "log_seeds.txt") + "\n-- GL-stack jobs (RM_RANDOM_GL_JOBS=8000, seed 9)\n" + rd(F, "log_gl.txt") + "\n-- tools/dbg/abuse_fuzz.py 4000, seeds 41-44\n" + rd(F, "log_abuse.txt"))
 open(os.path.join(P, name), "w").write(txt)
 bad = [l for l in txt.splitlines() if "failed" in l or "error" in l.lower()]
-print("fuzz log:", "ALL GREEN" if not bad else bad)
+print("fuzz log:", "ALL GREEN" if not bad else bad, "(addenda appended by hand to the previous log are not carried over)")
