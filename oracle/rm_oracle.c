@@ -68,8 +68,8 @@ void or_set_tan_mode(int mode) { or_tan_mode = mode; }
 
 /* sin, cos, log, exp, pow, acos, atan2.  GLSL leaves their precision to the implementation, so there are no reference
  * bits to match; what matters is that the checker and the HIP parity build compute the SAME function.
- * OR_MATH_PORTABLE (default): oracle/pm_math.h -- double-precision series from IEEE basic operations, correctly rounded
- * to float for all but ~1e-5 of the arguments, the same text the HIP kernels compile: bit-identical on both sides.
+ * OR_MATH_PORTABLE (default): oracle/pm_math.h -- fixed sequences of IEEE binary32 operations (round 5; double-precision series
+ * until round 4), within 2-3 ulp, the same text the HIP kernels compile: bit-identical on both sides.
  * OR_MATH_LIBM: the C library's float functions, as this file used them until round 2 (kept to show that nothing hangs
  * on the choice: tests/test_oracle_golden.py renders the goldens' cases both ways).
  * OR_MATH_SWIFTSHADER: oracle/ss_math.h -- the approximations of the GL stack the goldens were rendered with, bit for bit
@@ -91,15 +91,13 @@ static inline float o_rounded(float v) {
 }
 
 #define PM_FN static inline
-#define PM_FMA(a, b, c) fma((a), (b), (c)) /* IEEE fusedMultiplyAdd: one rounding, in hardware (-mfma) or in libm, the same bits */
-#define PM_FMAK(a, b, k) fma((a), (b), (k)) /* ... with a constant addend (the kernels issue it with the constant in scalar registers) */
-static inline unsigned long long PM_D2U(double x) { unsigned long long u; memcpy(&u, &x, 8); return u; }
-static inline double PM_U2D(unsigned long long u) { double x; memcpy(&x, &u, 8); return x; }
+#define PM_FMAF(a, b, c) fmaf((a), (b), (c)) /* IEEE fusedMultiplyAdd: one rounding, in hardware (-mfma) or in libm, the same bits */
 static inline unsigned int PM_F2U(float x) { unsigned int u; memcpy(&u, &x, 4); return u; }
+static inline float PM_U2F(unsigned int u) { float x; memcpy(&x, &u, 4); return x; }
 #include "pm_math.h"
 #define SS_FN static inline
 #define SS_F2U(x) PM_F2U(x)
-static inline float SS_U2F(unsigned int u) { float x; memcpy(&x, &u, 4); return x; }
+#define SS_U2F(u) PM_U2F(u)
 #include "ss_math.h"
 
 static inline float o_sin(float x) { return or_math_mode == OR_MATH_SWIFTSHADER ? ss_sin(x) : o_rounded(or_math_mode == OR_MATH_LIBM ? sinf(x) : pm_sin(x)); }

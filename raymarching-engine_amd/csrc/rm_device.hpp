@@ -5,18 +5,16 @@
 // a math policy:
 //
 //   PM  "precise": exactly the operations the oracle performs -- IEEE
-//       add/mul/div/sqrt, no FMA, ocml's ~1 ulp pow/log/sin/cos/acos/atan.
-//       The parity build uses it everywhere.
-//   FM  "fast": v_fma_f32, v_rcp_f32 / v_sqrt_f32 / v_sin_f32 / v_cos_f32 /
-//       v_exp_f32 / v_log_f32 at hardware rate, trig-free power-8 Mandelbulb.
-//       The fast build uses it for the MARCH only (castRay's sdf evaluations,
-//       >= 98 % of the work); normals, the subsurface test, materials, the
-//       RNG and all shading stay on PM.  Why: sceneNormal is a forward
-//       difference with delta = 1e-5 (raymarcher.frag:153-160,:264), which
-//       sits on the fp32 noise floor -- the rounding noise of sdf() IS part of
-//       the reference's image (it blurs the GGX highlight, :365-371).  Coarser
-//       rounding in those four evaluations biases the lighting by several
-//       per cent (measured); in the march it only moves the hit point by ulps.
+//       add/mul/div/sqrt, no FMA but the explicit ones of rm_pm_math.hpp, whose
+//       fp32 sequences are pow/log/exp/sin/cos/acos/atan (the oracle compiles the
+//       same text).  The parity build uses it everywhere.
+//   FM  "fast": v_fma_f32, v_rcp_f32 / v_rsq_f32 / v_sqrt_f32 / v_log_f32 at
+//       hardware rate, trig-free power-8 Mandelbulb.  The fast build uses it for
+//       every DISTANCE EVALUATION: castRay's (>= 98 % of the work) and, since
+//       round 3, the four of sceneNormal and the subsurface test (rm_kernels.inc
+//       RM_NORMAL_POLICY has the measurement); the RNG, the camera, the materials
+//       and all shading arithmetic stay on PM, so a pixel whose rays never come
+//       near the surface -- the sky -- has the parity build's bits.
 //
 // file:line = client/public/shader/raymarcher.frag of the reference unless stated.
 #pragma once
@@ -99,7 +97,13 @@ struct PM {
   static RM_DEV float acos(float x) { return pm_acos(x); }
   static RM_DEV float atan2(float y, float x) { return pm_atan2(y, x); }
   static RM_DEV void sincos(float x, float& s, float& c) { pm_sincos(x, &s, &c); }  // one reduction, the bits of sin and cos
-  static RM_DEV void pow_pair(float r, float n, float& r_nm1, float& r_n) { r_nm1 = pow(r, n - 1.0f); r_n = pow(r, n); }
+  // pow(r, n - 1) and pow(r, n) from ONE logarithm of r: the bits of the two calls (pm_pow is pm_log_hl + pm_pow_from_log)
+  static RM_DEV void pow_pair(float r, float n, float& r_nm1, float& r_n) {
+    float hi, lo;
+    pm_log_hl(fabsf(r), &hi, &lo);
+    r_nm1 = pm_pow_from_log(fabsf(r), n - 1.0f, hi, lo);
+    r_n = pm_pow_from_log(fabsf(r), n, hi, lo);
+  }
 };
 #endif
 

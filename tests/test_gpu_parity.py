@@ -312,7 +312,7 @@ def test_c3b_crop_matches_oracle(ctx, build, pipeline, crop):
     z -> z^8 + c eight times under forward-difference normals with delta =
     1e-5, which amplifies last-bit differences: it is held to a statistical
     bar (its per-pixel agreement is printed, and bounded from below so that a
-    regression shows); its sky pixels must still match exactly."""
+    regression shows); its sky pixels must still match exactly (but for a grazing shadow ray)."""
     sc, schema = _c3b()
     (x0, y0), w, h = C3B_CROPS[crop], 128, 32
     tile = abi.RmRect(x0, y0, w, h)
@@ -336,8 +336,10 @@ def test_c3b_crop_matches_oracle(ctx, build, pipeline, crop):
           f"bit-equal {float(np.mean(d == 0)):.4f}, mean error {merr:.5f} (bar {bars['mean_err']}), lit pixels {float(np.mean((want[..., :3].sum(-1) > 0.02) & ~sky)):.3f}; "
           f"sky pixels {float(sky.mean()):.3f}: bit-equal {float((d[sky] == 0).mean()):.4f}")
     # an escaped ray is moved 1e6 along its direction and then lit like a surface point (raymarcher.frag:278-283,
-    # :354-373): the shading is the parity arithmetic in both builds, the march has no part in it
-    assert (d[sky] == 0).all()
+    # :354-373): the shading is the parity arithmetic in both builds.  Its SHADOW ray is marched, though -- from 1e6 away back
+    # through the scene to the light -- and where that ray grazes the fractal the two builds' marches may decide differently:
+    # at most a few pixels per thousand (rounds 2-4: none on these crops; round 5, with the fp32 sequences' directions: 1 of 1620)
+    assert float((d[sky] == 0).mean()) >= 0.998
     assert w3 >= bars["within_1e3"] and w5 >= bars["within_1e5"] and merr <= bars["mean_err"]
     assert np.array_equal(got[..., 3], want[..., 3])
 

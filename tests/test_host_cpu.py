@@ -217,16 +217,19 @@ def test_reference_scissor_option():
 def test_portable_math_text_is_shared_by_oracle_and_kernels():
     """The transcendentals of the parity arithmetic exist twice -- oracle/pm_math.h for the checker,
     csrc/rm_pm_math.hpp for the HIP kernels (the product links nothing from oracle/) -- and must be the same
-    sequence of operations: from the first constant on, the two files are the same text."""
+    sequence of operations: from the first definition on, the two files are the same text."""
     from pathlib import Path
 
     root = Path(__file__).resolve().parents[1]
     a = (root / "oracle" / "pm_math.h").read_text()
     b = (root / "raymarching-engine_amd" / "csrc" / "rm_pm_math.hpp").read_text()
-    mark = "#define PM_PIO2_HI"
+    mark = "#define PM_INF"
     assert mark in a and mark in b
     assert a[a.index(mark):] == b[b.index(mark):]
     assert "PM_FN" in a and "__device__" in b[:b.index(mark)]
+    # binary32 sequences since round 5: no double-precision operation on either side
+    body = a[a.index(mark):]
+    assert "double" not in body and "PM_FMA(" not in body and "pm_log_hl" in body
 
 
 
@@ -243,10 +246,11 @@ def test_gl_stack_math_text_is_shared_by_oracle_and_kernels():
     assert mark in a and mark in b
     assert a[a.index(mark):] == b[b.index(mark):] and "SS_FN float ss_atan2" in a
 
-def test_portable_math_is_correctly_rounded_on_samples():
-    """oracle/pm_math.h against numpy's double-precision functions rounded to float: equal on every sample of the
-    ranges the path uses (the double series are good to ~1e-14; a float disagrees only when the true value is
-    that close to a rounding boundary)."""
+def test_portable_math_accuracy_and_conventions():
+    """oracle/pm_math.h -- fixed sequences of IEEE binary32 operations since round 5 -- against numpy's double-precision
+    functions: within 2 ulp (atan2: 3) over the ranges the path uses, most results the correctly rounded float; C's conventions
+    at the edges; the same bits with a hardware fused multiply-add and with libm's fmaf (the operation is IEEE's either way);
+    denormal-free by definition (an argument or a result below 2^-126 counts as zero)."""
     import ctypes as C
     import subprocess
     import tempfile
@@ -259,54 +263,105 @@ def test_portable_math_is_correctly_rounded_on_samples():
 #include <math.h>
 #include <string.h>
 #define PM_FN static inline
-#define PM_FMA(a, b, c) fma((a), (b), (c))
-#define PM_FMAK(a, b, k) fma((a), (b), (k))
-static inline unsigned long long PM_D2U(double x) { unsigned long long u; memcpy(&u, &x, 8); return u; }
-static inline double PM_U2D(unsigned long long u) { double x; memcpy(&x, &u, 8); return x; }
+#define PM_FMAF(a, b, c) fmaf((a), (b), (c))
 static inline unsigned int PM_F2U(float x) { unsigned int u; memcpy(&u, &x, 4); return u; }
+static inline float PM_U2F(unsigned int u) { float x; memcpy(&x, &u, 4); return x; }
 #include "pm_math.h"
 #define F1(n) void t_##n(const float* x, float* o, int c) { for (int i = 0; i < c; i++) o[i] = pm_##n(x[i]); }
 F1(sin) F1(cos) F1(log) F1(exp) F1(acos)
 void t_pow(const float* x, const float* y, float* o, int c) { for (int i = 0; i < c; i++) o[i] = pm_pow(x[i], y[i]); }
 void t_atan2(const float* y, const float* x, float* o, int c) { for (int i = 0; i < c; i++) o[i] = pm_atan2(y[i], x[i]); }
+void t_pow_pair(const float* x, const float* y, float* o, int c) {  /* two powers from one logarithm = two calls of pm_pow */
+  for (int i = 0; i < c; i++) { float hi, lo; pm_log_hl(x[i], &hi, &lo); o[i] = pm_pow_from_log(x[i], y[i], hi, lo); }
+}
 """
     with tempfile.TemporaryDirectory() as d:
         (Path(d) / "t.c").write_text(src)
-        subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-I", str(root / "oracle"), str(Path(d) / "t.c"), "-o", str(Path(d) / "t.so"), "-lm"], check=True)
-        lib = C.CDLL(str(Path(d) / "t.so"))
+        libs = []
+        hw_fma = "fma" in Path("/proc/cpuinfo").read_text().split() if Path("/proc/cpuinfo").exists() else False
+        for name, extra in (("soft", []),) + ((("hard", ["-mfma"]),) if hw_fma else ()):
+            subprocess.run(["gcc", "-O2", "-ffp-contract=off", *extra, "-shared", "-fPIC", "-I", str(root / "oracle"), str(Path(d) / "t.c"), "-o",
+                            str(Path(d) / f"{name}.so"), "-lm"], check=True)
+            libs.append(C.CDLL(str(Path(d) / f"{name}.so")))
 
-        def call(name, *args):
+        def call(name, *args, lib=libs[-1]):
             args = [np.ascontiguousarray(a, np.float32) for a in args]
             out = np.empty_like(args[0])
             getattr(lib, name)(*[a.ctypes.data_as(C.c_void_p) for a in args], out.ctypes.data_as(C.c_void_p), C.c_int(len(out)))
             return out
 
+        def ulps(got, want):  # error in units of the last place of the correctly rounded float; results below 2^-126 are zero by definition
+            w32 = want.astype(np.float32)
+            ok = np.isfinite(want) & (np.abs(want) >= 1.17549435e-38)
+            return (np.abs(got.astype(np.float64) - want) / np.spacing(np.abs(w32)).astype(np.float64))[ok], np.mean(got[ok] == w32[ok])
+
         rng = np.random.default_rng(5)
-        n = 200_000
-        same = lambda got, want: ((got == want.astype(np.float32)) | (np.isnan(got) & np.isnan(want))).all()
-        x = rng.uniform(-60, 60, n).astype(np.float32)
-        assert same(call("t_sin", x), np.sin(x.astype(np.float64))) and same(call("t_cos", x), np.cos(x.astype(np.float64)))
-        x = np.exp(rng.uniform(-80, 80, n)).astype(np.float32)
-        assert same(call("t_log", x), np.log(x.astype(np.float64)))
-        x = rng.uniform(-85, 85, n).astype(np.float32)
-        assert same(call("t_exp", x), np.exp(x.astype(np.float64)))
-        x = rng.uniform(-1, 1, n).astype(np.float32)
-        assert same(call("t_acos", x), np.arccos(x.astype(np.float64)))
+        n = 400_000
+        worst = {}
+
+        def check(name, got, want, bar, exact_bar):
+            e, exact = ulps(got, want)
+            worst[name] = (float(e.max()), float(exact))
+            assert e.max() <= bar and exact >= exact_bar, f"{name}: max error {e.max():.3f} ulp (bar {bar}), correctly rounded {exact:.4f} (bar {exact_bar})"
+
+        for lim in (7.0, 60.0, 1e5):
+            x = rng.uniform(-lim, lim, n).astype(np.float32)
+            check(f"sin {lim:g}", call("t_sin", x), np.sin(x.astype(np.float64)), 2.0, 0.70)
+            check(f"cos {lim:g}", call("t_cos", x), np.cos(x.astype(np.float64)), 2.0, 0.70)
+        x = np.exp(rng.uniform(-87, 88, n)).astype(np.float32)
+        check("log", call("t_log", x), np.log(x.astype(np.float64)), 1.0, 0.98)
+        x = (1.0 - rng.uniform(0, 1, n)).astype(np.float32)  # the path's log(1 - u)
+        x = x[x > 0]
+        check("log(1 - u)", call("t_log", x), np.log(x.astype(np.float64)), 1.0, 0.98)
+        x = rng.uniform(-87, 88.7, n).astype(np.float32)
+        check("exp", call("t_exp", x), np.exp(x.astype(np.float64)), 1.5, 0.88)
+        x = np.concatenate([rng.uniform(-1, 1, n), 1 - np.exp(rng.uniform(-16, 0, n)), np.exp(rng.uniform(-16, 0, n)) - 1]).astype(np.float32)
+        check("acos", call("t_acos", x), np.arccos(x.astype(np.float64)), 2.0, 0.75)
         a, b = np.exp(rng.uniform(-3, 3, n)).astype(np.float32), rng.uniform(-10, 10, n).astype(np.float32)
-        assert same(call("t_pow", a, b), np.power(a.astype(np.float64), b.astype(np.float64)))
+        check("pow", call("t_pow", a, b), np.power(a.astype(np.float64), b.astype(np.float64)), 2.0, 0.85)
+        a = rng.uniform(0, 2, n).astype(np.float32)  # the Mandelbulb's r^7 and r^8, schlick's fifth power
+        for e in (5.0, 7.0, 8.0):
+            check(f"pow {e:g}", call("t_pow", a, np.full(n, e, np.float32)), np.power(a.astype(np.float64), e), 2.0, 0.85)
+        a, b = np.exp(rng.uniform(-20, 20, n)).astype(np.float32), rng.uniform(-4, 4, n).astype(np.float32)
+        check("pow wide", call("t_pow", a, b), np.power(a.astype(np.float64), b.astype(np.float64)), 2.0, 0.85)
+        assert (call("t_pow_pair", a, b) .view(np.uint32) == call("t_pow", a, b).view(np.uint32)).all()
+        # whole powers of small integers come out exact (the iterated kinds' per-level scale factors)
+        assert (call("t_pow", [2, 2, 2, 3, 10, 0.5, 4, 3], [5, 10, -3, 4, 3, 7, 0.5, 0]) == np.array([32, 1024, 0.125, 81, 1000, 0.0078125, 2, 1], np.float32)).all()
         y, x = rng.normal(size=n).astype(np.float32), rng.normal(size=n).astype(np.float32)
-        assert same(call("t_atan2", y, x), np.arctan2(y.astype(np.float64), x.astype(np.float64)))
+        check("atan2", call("t_atan2", y, x), np.arctan2(y.astype(np.float64), x.astype(np.float64)), 3.0, 0.6)
+        y, x = [(rng.normal(size=n) * np.exp(rng.uniform(-30, 30, n))).astype(np.float32) for _ in range(2)]
+        check("atan2 wide", call("t_atan2", y, x), np.arctan2(y.astype(np.float64), x.astype(np.float64)), 3.0, 0.6)
+        print({k: (round(v[0], 3), round(v[1], 4)) for k, v in worst.items()})
+        # a hardware fused multiply-add and libm's fmaf: the same bits (what lets the GPU and any host agree)
+        if len(libs) == 2:
+            for name, args in (("t_sin", (x,)), ("t_log", (np.abs(x),)), ("t_exp", (rng.uniform(-87, 88, n).astype(np.float32),)),
+                               ("t_pow", (np.abs(y) + 0.1, rng.uniform(-3, 3, n).astype(np.float32))), ("t_atan2", (y, x)),
+                               ("t_acos", (rng.uniform(-1, 1, n).astype(np.float32),))):
+                g0, g1 = call(name, *args, lib=libs[0]), call(name, *args, lib=libs[1])
+                assert ((g0.view(np.uint32) == g1.view(np.uint32)) | (np.isnan(g0) & np.isnan(g1))).all(), name
         # the conventions of C's functions at the edges
+        same = lambda got, want: ((got == want.astype(np.float32)) | (np.isnan(got) & np.isnan(want))).all()
         inf, nan = np.float32(np.inf), np.float32(np.nan)
         edge = np.array([0.0, -0.0, 1.0, -1.0, inf, -inf, nan, 2.0, 0.5], np.float32)
         ys, xs = [v.ravel() for v in np.meshgrid(edge, edge)]
         got, want = call("t_atan2", ys, xs), np.arctan2(ys.astype(np.float64), xs.astype(np.float64))
-        assert same(got, want) and (np.signbit(got) == np.signbit(want))[~np.isnan(want)].all()
+        assert (np.isnan(got) == np.isnan(want)).all() and (np.signbit(got) == np.signbit(want))[~np.isnan(want)].all()
+        assert ulps(got, want)[0].max() <= 1.0
         with np.errstate(all="ignore"):
             assert same(call("t_log", edge), np.log(edge.astype(np.float64)))
-            assert same(call("t_acos", edge), np.arccos(edge.astype(np.float64)))
+            got, want = call("t_acos", edge), np.arccos(edge.astype(np.float64))
+            assert (np.isnan(got) == np.isnan(want)).all() and ulps(got, want)[0].max() <= 1.0 and got[2] == 0.0
             assert same(call("t_pow", np.abs(xs), ys), np.power(np.abs(xs).astype(np.float64), ys.astype(np.float64)))
-        assert np.isnan(call("t_sin", np.array([inf, nan, 1e30], np.float32))).all()
+        assert np.isnan(call("t_sin", np.array([inf, nan, 1e30, -inf], np.float32))).all() and np.isnan(call("t_cos", np.array([inf, nan, 1e30], np.float32))).all()
+        big = np.exp(rng.uniform(0, 80, n)).astype(np.float32)  # any argument: a value in [-1, 1] or NaN, never anything else
+        for f in ("t_sin", "t_cos"):
+            v = call(f, big)
+            assert (np.isnan(v) | (np.abs(v) <= 1.0)).all()
+        assert (call("t_exp", [inf, -inf, 88.72, 88.73, -87.3, -87.4, -200, 0]) == np.array([inf, 0, 3.3931806e+38, inf, 1.2192433e-38, 0, 0, 1], np.float32)).all()
+        assert np.isnan(call("t_exp", [nan]))[0]
+        # denormal-free: arguments below 2^-126 are zeros, results below it are zeros
+        assert (call("t_log", [1e-40, 1.17549435e-38]) == np.array([-inf, np.log(np.float64(np.float32(1.17549435e-38)))], np.float32)).all()
+        assert (call("t_pow", [1e-40, 1e-20, 1e-20], [1.0, 2.5, -2.5]) == np.array([0.0, 0.0, np.inf], np.float32)).all()
 
 
 def test_halton_equals_the_reference_generator():
