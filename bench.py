@@ -460,6 +460,7 @@ def main():
                      else shard.owned_rows(H, world, rank))
         px_launch = len(rows_held) * W
         flops_launch, flops_px, fixture = instrumented_flops(args.workload, rows_held)
+        useful_launch, useful_px, useful_fixture = instrumented_flops(args.workload + "_pruned", rows_held)  # ... of the PRUNED algorithm (frac_useful)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(sc, schema)
@@ -488,6 +489,11 @@ def main():
                     "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,
                     "frac_nominal": nominal_px * px_launch / sec / 1e12 / PEAK_FP32_VALU_TFLOPS,
                     "frac_executed": executed / sec / 1e12 / PEAK_FP32_VALU_TFLOPS if executed else None,
+                    # the arithmetic the marches NEED, instrumented by the same oracle: a ray is counted up to its bitwise fixed point
+                    # (settled, or overflowed to its end state) and not beyond -- a numerator the kernel cannot beat by skipping steps,
+                    # so this fraction cannot exceed 1 (frac can: 4.5 on C4)
+                    "frac_useful": useful_launch / sec / 1e12 / PEAK_FP32_VALU_TFLOPS if useful_launch else None,
+                    "flops_per_pixel_sample_useful": useful_px,
                     "counters_from": counters_from, "valu_issue_busy": issue_busy, "fma_share": fma_share,
                     "flops_per_pixel_sample_instrumented": flops_px, "flops_per_pixel_sample_nominal": nominal_px,
                     "flops_per_launch_instrumented": flops_launch,
@@ -497,7 +503,9 @@ def main():
                     "hbm_algorithmic_GBs": 96.0 * px_launch / sec / 1e9, "hbm_peak_GBs": PEAK_HBM_GBS,
                     "note": "frac prices the REFERENCE algorithm (every step of its fixed-count marches, SURVEY 8(d)) at the kernel's time; the kernel skips, "
                             "exactly, the steps whose outcome is known -- a ray that stopped moving, an escaping ray's way to overflow -- so frac can "
-                            "exceed 1 on frames that are mostly sky; frac_executed is the hardware's own count of the arithmetic done.  traffic, frac_executed, "
+                            "exceed 1 on frames that are mostly sky; frac_useful prices the same algorithm with every march counted up to its bitwise "
+                            "fixed point only (profiles/flops_per_pixel.json[<workload>_pruned]; tools/count_flops.py --pruned): at most 1 by construction; "
+                            "frac_executed is the hardware's own count of the arithmetic done.  traffic, frac_executed, "
                             "valu_issue_busy and fma_share are REPLAYED from counters_from, not measured in this run: frac_executed = (ADD + MUL + 2 FMA + TRANS) "
                             "x 64 x lanes active / kernel time / peak; with fma_share of the VALU instructions being FMAs (2 flops) and the rest 1 or 0, and "
                             "valu_issue_busy of the issue slots taken, that is what bounds it"}

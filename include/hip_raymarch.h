@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RM_ABI_VERSION 6 /* 6: rm_present_striped_rows, rm_present_sharded_start / _finish, rm_ctx_last_warning, RM_PROBE_CAST_SHADOW, RM_PRIM_KIND (additions only); 3: rm_ctx_set_sample_batch, rm_buffer_*; 4: rm_ctx_set_gl_stack; 5: RmSurface / RmSceneDesc.surfaces (the struct grew), rm_pack_present_rows, rm_present_sharded, rm_ctx_last_pipeline, RM_RENDER_NO_FAR_JUMP, RM_RENDER_NO_CULL (additions only) */
+#define RM_ABI_VERSION 7 /* 7: rm_present_sharded_finish / rm_present_sharded take the size of the host buffer (a changed signature), rm_ctx_set_cull_min_pixels, rm_ctx_cull_stats; 6: rm_present_striped_rows, rm_present_sharded_start / _finish, rm_ctx_last_warning, RM_PROBE_CAST_SHADOW, RM_PRIM_KIND (additions only); 3: rm_ctx_set_sample_batch, rm_buffer_*; 4: rm_ctx_set_gl_stack; 5: RmSurface / RmSceneDesc.surfaces (the struct grew), rm_pack_present_rows, rm_present_sharded, rm_ctx_last_pipeline, RM_RENDER_NO_FAR_JUMP, RM_RENDER_NO_CULL (additions only) */
 
 #define RM_MAX_BOUNCES 10 /* raymarchingStepCountsArray[10], raymarcher.frag:31 */
 #define RM_MAX_LIGHTS 10  /* lightPositions[10],             raymarcher.frag:37-39 */
@@ -305,6 +305,15 @@ int rm_ctx_set_retire_eps(rm_ctx* ctx, float eps);
  * reference's UNMODIFIED shader text computes under it, random stream and camera included (that switch is one per DEVICE:
  * the GL-stack contexts of a device share it, and changing it waits for the device). */
 int rm_ctx_set_gl_stack(rm_ctx* ctx, int on);
+/* Culling grids (long primitive tables without domain rows; RM_RENDER_NO_CULL): a scene's grid is built -- on the context's
+ * stream, in front of the render that asks for it -- once the scene has been asked for `pixels` pixel-samples since it was
+ * created (default 4 Mi: a 4K frame's first sample builds it, a host that shows a NEW scene in every 1080p frame, like the
+ * reference's sliders do (index.tsx:121-182), never pays for a grid it would not earn back); 0 = with the first render.  The
+ * same bits with and without a grid.  rm_ctx_cull_stats: out4 = {grids built so far, bytes held now, grids held now, the
+ * budget in bytes (a sixteenth of the device's memory, at most 1 GiB: beyond it the least recently rendered scene gives its
+ * grid up and renders on without one)}. */
+int rm_ctx_set_cull_min_pixels(rm_ctx* ctx, long long pixels);
+int rm_ctx_cull_stats(const rm_ctx* ctx, unsigned long long* out4);
 /* Diagnostics of the wavefront march, filled only by builds compiled with
  * -DRM_WF_STATS (zeros otherwise): out16[8*shadow + 4*pass2 + {0,1,2}] =
  * rays marched, lane-steps, wave-steps since the last reset. */
@@ -519,13 +528,15 @@ int rm_present_striped_rows(rm_ctx* ctx, const void* color, const void* normal_d
  *     canvas is copied to pinned host memory.  Nothing is waited for.  One present at a time: finish before the next start.
  *   rm_present_sharded_finish: waits for THAT present only (an event; renders enqueued since keep running) and copies
  *     the canvas to out_rgba8 = height*width*4 bytes of HOST memory, row 0 = bottom: the bytes rm_present gives for the
- *     same samples on one framebuffer.
+ *     same samples on one framebuffer.  out_bytes = the size of that buffer: RM_ERR_INVALID, with the present still pending,
+ *     when it is smaller than the canvas of the present that was STARTED (the library knows that size, the caller of a
+ *     finish alone may not: round 4's signature trusted it).
  *   rm_present_sharded: both, one after the other (synchronous).
  * (Hosts with a process per GPU -- bench.py, job.RenderJobContext(group=...) -- move the same rows over RCCL instead:
  * raymarching_engine_amd/dist.py.) */
 int rm_present_sharded_start(rm_ctx* const* ctxs, rm_fb* const* fbs, int parts, int samples, int dof);
-int rm_present_sharded_finish(rm_ctx* const* ctxs, int parts, uint8_t* out_rgba8);
-int rm_present_sharded(rm_ctx* const* ctxs, rm_fb* const* fbs, int parts, int samples, int dof, uint8_t* out_rgba8);
+int rm_present_sharded_finish(rm_ctx* const* ctxs, int parts, uint8_t* out_rgba8, size_t out_bytes);
+int rm_present_sharded(rm_ctx* const* ctxs, rm_fb* const* fbs, int parts, int samples, int dof, uint8_t* out_rgba8, size_t out_bytes);
 
 #ifdef __cplusplus
 }

@@ -94,6 +94,11 @@ def ss_math(name: str, a: np.ndarray, b: np.ndarray = None) -> np.ndarray:
     return out
 
 
+def set_count_pruned(on: bool) -> None:
+    """The counting oracle only: do not count the steps of a march behind its bitwise fixed point (rm_oracle.c or_set_count_pruned)."""
+    _lib(True).or_set_count_pruned(1 if on else 0)
+
+
 def set_math_round_bits(bits: int) -> None:
     """Sensitivity probe (0 = off): sin / cos / log / exp / pow / acos results rounded to `bits` significant bits."""
     _lib(False).or_set_math_round_bits(bits)

@@ -44,8 +44,27 @@
  * division = 1, pow = 2.  Counted where the work is done, so data-dependent
  * branches (Mandelbulb bailout) are included. */
 static _Thread_local uint64_t or_flops;
-#define FL(n) (or_flops += (uint64_t)(n))
+/* Pruned count (or_set_count_pruned; tools/count_flops.py --pruned; bench.py's frac_useful): the steps of a march that cannot
+ * change its result -- every step after the position has become a bitwise fixed point of p <- p + dir * sdf(p) (settled on a
+ * surface, or overflowed to a stable Inf / NaN pattern) -- are not counted: what is left is the arithmetic a march NEEDS, the
+ * numerator of a roofline fraction that cannot exceed 1.  The image is the same: only the counter pauses. */
+static int or_count_pruned = 0;
+static _Thread_local int or_count_paused;
+void or_set_count_pruned(int on) { or_count_pruned = on; }
+/* ... and the steps of a ray that is certain never to come back: outside a sphere that holds the scene twice over and not moving
+ * inward (what the kernels' far-field exits test, without their step budgets: a perfect march stops there whatever it has left).
+ * The radius: the Mandelbulb's bailout (no round runs beyond it), a table's shapes + its largest smooth-union radius; other
+ * kinds have no such sphere here and are counted to their fixed point only. */
+static float count_far_r2(const RmSceneDesc* sc);
+#define FL(n) (or_flops += or_count_paused ? 0u : (uint64_t)(n))
+#define FL_SETTLED(a, b) do { if (or_count_pruned && memcmp(&(a), &(b), sizeof(a)) == 0) or_count_paused = 1; } while (0)
+#define FL_ESCAPING(p, dir, far_r2) do { if (or_count_pruned && (far_r2) > 0.0f && (p).x * (p).x + (p).y * (p).y + (p).z * (p).z > (far_r2) && \
+                                             (p).x * (dir).x + (p).y * (dir).y + (p).z * (dir).z >= 0.0f) or_count_paused = 1; } while (0)
+#define FL_RESUME() (or_count_paused = 0)
 #else
+#define FL_SETTLED(a, b) ((void)(a), (void)(b))
+#define FL_ESCAPING(p, dir, far_r2) ((void)0)
+#define FL_RESUME() ((void)0)
 #define FL(n) ((void)0)
 #endif
 
@@ -494,6 +513,28 @@ static float scene_sdf(const RmSceneDesc* sc, v3 p) {
   }
 }
 
+#ifdef OR_COUNT_FLOPS
+static float count_far_r2(const RmSceneDesc* sc) {
+  if (sc->kind == RM_SCENE_MANDELBULB) {
+    const float b = sc->params[RM_P_BULB_BAILOUT];
+    return b * b > 4.0f ? b * b : 4.0f;
+  }
+  if (sc->kind != RM_SCENE_TABLE) return 0.0f;
+  double reach = 0.0, kmax = 0.0;
+  for (int i = 0; i < sc->nprims; i++) {
+    const RmPrim* q = &sc->prims[i];
+    const int type = q->type & 0xff;
+    if (type != RM_PRIM_SPHERE && type != RM_PRIM_BOX) return 0.0f; /* domain rows, kind rows: no bound claimed */
+    const double e = type == RM_PRIM_SPHERE ? fabs((double)q->size[0]) : sqrt((double)q->size[0] * q->size[0] + (double)q->size[1] * q->size[1] + (double)q->size[2] * q->size[2]);
+    const double c = sqrt((double)q->center[0] * q->center[0] + (double)q->center[1] * q->center[1] + (double)q->center[2] * q->center[2]);
+    if (c + e > reach) reach = c + e;
+    if (((q->type >> 8) & 0xff) == RM_OP_SMOOTH_UNION && q->k > kmax) kmax = q->k;
+  }
+  const double r = 2.0 * (reach + 1.01 * kmax) + 1.0; /* the kernels' (2 R' + 1) */
+  return (float)(r * r);
+}
+#endif
+
 /* ---- material functions: Validate.tsx:18-51 with the constants in RmMaterial */
 
 /* Position-dependent materials of a composed scene (include/hip_raymarch.h RmSurface; the reference's contract is seven
@@ -593,10 +634,17 @@ static v3 scene_normal(const RmSceneDesc* sc, v3 p, float delta) {
 
 /* :163-170 -- fixed step count, no early exit */
 static v3 cast_ray(const RmSceneDesc* sc, v3 p, v3 dir, float steps) {
+#ifdef OR_COUNT_FLOPS
+  const float far_r2 = or_count_pruned ? count_far_r2(sc) : 0.0f;
+#endif
   for (float i = 0.0f; i < steps; i += 1.0f) {
+    FL_ESCAPING(p, dir, far_r2);
     float d = scene_sdf(sc, p);
+    const v3 before = p;
     p = vadd(p, vscale(dir, d));
+    FL_SETTLED(before, p); /* (pruned count: a fixed point -- the remaining steps repeat this one) */
   }
+  FL_RESUME();
   return p;
 }
 
@@ -670,8 +718,13 @@ static void pixel_main(const RmSceneDesc* sc, const RmUniforms* u, int W, int H,
 
   if (u->renderMode == 1) { /* preview, :207-244 */
     float steps_taken = 0.0f, depth = 0.0f;
+#ifdef OR_COUNT_FLOPS
+    const float far_r2 = or_count_pruned ? count_far_r2(sc) : 0.0f;
+#endif
     for (float i = 0.0f; i < steps_arr[0]; i += 1.0f) {
+      FL_ESCAPING(pos, dir, far_r2);
       float d = scene_sdf(sc, pos);
+      const v3 before = pos;
       FL(2);
       if (d < 100000000000.0f) {
         pos = vadd(pos, vscale(dir, d));
@@ -679,7 +732,9 @@ static void pixel_main(const RmSceneDesc* sc, const RmUniforms* u, int W, int H,
         depth += delta_z * d;
       }
       if (d > 0.0001f) steps_taken = i;
+      FL_SETTLED(before, pos);
     }
+    FL_RESUME();
     FL(3);
     float shade = 1.0f - steps_taken / steps_arr[0];
     v3 out = vadd(vscale(vadd(scene_diffuse(sc, pos), scene_specular(sc, pos)), shade), scene_emission(sc, pos));

@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-RM_ABI_VERSION = 6
+RM_ABI_VERSION = 7
 RM_MAX_BOUNCES = 10
 RM_MAX_LIGHTS = 10
 RM_MAX_PRIMS = 256

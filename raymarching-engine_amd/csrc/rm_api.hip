@@ -114,6 +114,16 @@ struct rm_ctx {
   bool shard_pending = false;                                // root: a start without its finish
   int shard_w = 0, shard_h = 0;                              // root: the canvas of the pending present
   unsigned long long peer_enabled = 0;  // devices this context's GPU has been given peer access to
+  // Culling grids of this context's scenes (scene_cull_grid): built once a scene has been asked for cull_min_pixels pixel-samples
+  // (rm_ctx_set_cull_min_pixels), held within cull_budget bytes -- the least recently rendered scene gives its grid up first, and
+  // renders on without one (same bits) -- and their buffers recycled: no hipMalloc / hipFree, which wait for the device, per scene.
+  long long cull_min_pixels = 4ll << 20;
+  size_t cull_budget = 0, cull_bytes = 0;
+  unsigned long long cull_built = 0, use_clock = 0;
+  std::vector<rm_scene*> cull_scenes;
+  struct CullBuffer { unsigned long long* p; size_t bytes; };
+  std::vector<CullBuffer> cull_pool;
+  hipEvent_t cull_event = nullptr;  // behind the last build on the context's stream: what the side streams' renders wait for
   std::string error;
   std::string warning;  // rm_ctx_last_warning: advice that came with a call that SUCCEEDED (never an error)
 };
@@ -130,6 +140,9 @@ struct rm_scene {
   bool cull_wanted = false;
   CullGrid cull_grid{};
   CullBuild cull_build{};
+  size_t cull_bytes = 0;           // of d_cull
+  long long px_seen = 0;           // pixel-samples asked of this scene while it had no grid
+  unsigned long long last_use = 0; // rm_ctx::use_clock at the last render / probe
 };
 
 struct rm_fb {
@@ -208,6 +221,13 @@ int rm_ctx_create(int device, rm_ctx** out) {
   if (const char* v = std::getenv("RM_WF_BLOCKS_PER_CU")) { int n = std::atoi(v); if (n >= 1 && n <= 8) ctx->wf_blocks_per_cu = n; }
   if (const char* v = std::getenv("RM_WF_BANDS")) { int n = std::atoi(v); if (n >= 1 && n <= 8) ctx->wf_bands = n; }
   if (const char* v = std::getenv("RM_PASS2_BLOCKS_PER_CU")) { int n = std::atoi(v); if (n >= 1 && n <= 8) ctx->pass2_blocks_per_cu = n; }
+  if (const char* v = std::getenv("RM_CULL_MIN_PIXELS")) { long long n = std::atoll(v); if (n >= 0) ctx->cull_min_pixels = n; }  // (the tests: 0, so that small renders go through the grid)
+  {  // the culling grids of this context's scenes: a sixteenth of the device's memory, at most 1 GiB (a 256-row table's grid is 126 MB)
+    size_t free_b = 0, total_b = 0;
+    ctx->cull_budget = (size_t)1 << 30;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b / 16 < ctx->cull_budget) ctx->cull_budget = total_b / 16;
+    else (void)hipGetLastError();
+  }
   *out = ctx;
   return RM_OK;
 }
@@ -255,6 +275,8 @@ void rm_ctx_destroy(rm_ctx* ctx) {
   if (ctx->shard_snap) (void)hipEventDestroy(ctx->shard_snap);
   if (ctx->shard_done) (void)hipEventDestroy(ctx->shard_done);
   if (ctx->shard_ev) (void)hipEventDestroy(ctx->shard_ev);
+  for (auto& b : ctx->cull_pool) (void)hipFree(b.p);
+  if (ctx->cull_event) (void)hipEventDestroy(ctx->cull_event);
   for (auto& b : ctx->buffers) (void)hipFree(b.first);  // rm_buffer_create'd memory the host did not destroy
   if (ctx->switch_ev) (void)hipEventDestroy(ctx->switch_ev);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -437,7 +459,10 @@ static void table_far_field(const RmSceneDesc* desc, DevScene* dev) {
 #define RM_CULL_N_SMOOTH 128  // C4 12.4 ms without the grid, 9.8 with 64^3 cells, 9.1 with 128^3 (profiles/r04_smooth_union_culling.txt)
 #endif
 #ifndef RM_CULL_SMOOTH_LEVELS
-#define RM_CULL_SMOOTH_LEVELS 8  // out to 128 scene widths (a camera further away folds every row until its rays get there): 134 MB of cells
+#define RM_CULL_SMOOTH_LEVELS 8  // out to 128 scene widths (a camera further away folds every row until its rays get there)
+#endif
+#ifndef RM_CULL_OUTER_DIV
+#define RM_CULL_OUTER_DIV 2  // the levels around the first: cells twice as wide (1: as fine as level 0 -- rounds 3-4, 134 MB per 64 rows instead of 31.5)
 #endif
 #ifndef RM_CULL_MAX_LEVELS
 #define RM_CULL_MAX_LEVELS 18
@@ -482,12 +507,14 @@ static bool table_cull_params(const RmSceneDesc* desc, CullGrid* g, CullBuild* b
   build->nprims = n;
   const int cells = smooth_spheres ? (n >= 32 ? RM_CULL_N_SMOOTH : RM_CULL_N_SMOOTH / 2) : RM_CULL_N;  // (17 MB instead of 134 for the shorter tables)
   build->n = cells;
+  build->n_outer = smooth_spheres ? cells / RM_CULL_OUTER_DIV : cells;  // (the hard operators' sharper test works on large cells as it is)
   build->levels = levels;
   build->words = (n + 63) / 64;
   for (int a = 0; a < 3; a++) g->centre[a] = (float)build->centre[a];
   g->inv_half0 = (float)(1.0 / half);
   g->scale0 = (float)(cells / (2.0 * half));
   g->n = cells;
+  g->n_outer = build->n_outer;
   g->levels = levels;
   g->words = build->words;
   return true;
@@ -674,7 +701,6 @@ int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out) {
     if (e == hipSuccess) e = hipMemcpy(s->d_surfaces, all, bytes, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
       if (s->d_surfaces) (void)hipFree(s->d_surfaces);
-      if (s->d_cull) (void)hipFree(s->d_cull);
       if (s->d_prims) (void)hipFree(s->d_prims);
       delete s;
       return fail(ctx, RM_ERR_DEVICE, std::string("rm_scene_create: ") + hipGetErrorString(e));
@@ -686,13 +712,14 @@ int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out) {
   return RM_OK;
 }
 
+static void cull_release(rm_ctx* ctx, rm_scene* s);
 void rm_scene_destroy(rm_scene* scene) {
   if (!scene) return;
   (void)hipSetDevice(scene->ctx->device);
   (void)hipStreamSynchronize(scene->ctx->stream);
   if (scene->d_prims) (void)hipFree(scene->d_prims);
   if (scene->d_surfaces) (void)hipFree(scene->d_surfaces);
-  if (scene->d_cull) (void)hipFree(scene->d_cull);
+  cull_release(scene->ctx, scene);  // (to the context's pool: the next scene's grid is usually the same size)
   delete scene;
 }
 
@@ -893,23 +920,92 @@ int rm_buffer_upload(rm_ctx* ctx, void* device_ptr, const void* host, size_t byt
   return RM_OK;
 }
 
-// The culling grid of a scene that has one coming (rm_scene_create), before the first call that reads it (either build; not the GL stack's arithmetic): one allocation,
-// one build kernel and one wait on the context's stream, once per scene.  A failure to allocate is not an error: the fold of every
-// row gives the same bits.
-static void scene_cull_grid(rm_ctx* ctx, rm_scene* s, int flags) {
-  if (!s->cull_wanted || (flags & RM_RENDER_NO_CULL) || (ctx->gl_stack && !(flags & RM_RENDER_FAST))) return;
-  s->cull_wanted = false;
+// The culling grid of a scene that has one coming (rm_scene_create), before a call that reads it (either build; not the GL stack's
+// arithmetic).  Round 5: built once the scene has been asked for ctx->cull_min_pixels pixel-samples (until then it renders without
+// one: the same bits, and a host that shows a new scene every frame at a small size never pays for a grid it would not earn back);
+// the build kernel is enqueued on the context's stream in front of the render that triggered it -- no wait on the host -- into a
+// buffer recycled from the context's pool; the grids of a context stay within its budget, the least recently used scene giving its
+// grid up first.  Running out of memory is not an error (the fold of every row gives the same bits); any other failure is.
+static void cull_release(rm_ctx* ctx, rm_scene* s) {  // the scene's grid back to the pool (the caller has ordered the stream)
+  if (!s->d_cull) return;
+  size_t pooled = 0;
+  for (auto& b : ctx->cull_pool) pooled += b.bytes;
+  if (ctx->cull_pool.size() < 4 && pooled + s->cull_bytes <= ctx->cull_budget / 2) ctx->cull_pool.push_back({s->d_cull, s->cull_bytes});
+  else (void)hipFree(s->d_cull);
+  ctx->cull_bytes -= s->cull_bytes;
+  for (size_t i = 0; i < ctx->cull_scenes.size(); i++)
+    if (ctx->cull_scenes[i] == s) { ctx->cull_scenes.erase(ctx->cull_scenes.begin() + (long)i); break; }
+  s->d_cull = nullptr;
+  s->cull_bytes = 0;
+  s->dev.cull.cells = nullptr;
+}
+
+static int scene_cull_grid(rm_ctx* ctx, rm_scene* s, int flags, long long pixels) {
+  s->last_use = ++ctx->use_clock;
+  if (!s->cull_wanted || (flags & RM_RENDER_NO_CULL) || (ctx->gl_stack && !(flags & RM_RENDER_FAST))) return RM_OK;
+  s->px_seen += pixels;
+  if (s->px_seen < ctx->cull_min_pixels) return RM_OK;
   CullGrid g = s->cull_grid;
   CullBuild build = s->cull_build;
-  const size_t bytes = ((size_t)g.n * g.n * g.n * (size_t)g.levels + 1) * (size_t)g.words * sizeof(unsigned long long);
-  if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&s->d_cull), bytes) != hipSuccess) { (void)hipGetLastError(); s->d_cull = nullptr; return; }
+  const size_t bytes = (size_t)(rm_cull_cells(g.n, g.n_outer, g.levels) + 1) * (size_t)g.words * sizeof(unsigned long long);
+  s->cull_wanted = false;
+  if (bytes > ctx->cull_budget) return RM_OK;
+  RM_HIP(ctx, hipSetDevice(ctx->device));
+  while (ctx->cull_bytes + bytes > ctx->cull_budget && !ctx->cull_scenes.empty()) {  // the least recently used grid goes (a kernel still
+    rm_scene* victim = ctx->cull_scenes[0];                                            // reading it is ahead of the next build on this stream)
+    for (rm_scene* c : ctx->cull_scenes)
+      if (c->last_use < victim->last_use) victim = c;
+    cull_release(ctx, victim);
+    victim->cull_wanted = true;  // ... and may earn it back
+    victim->px_seen = 0;
+  }
+  unsigned long long* cells = nullptr;
+  for (size_t i = 0; i < ctx->cull_pool.size(); i++)
+    if (ctx->cull_pool[i].bytes == bytes) { cells = ctx->cull_pool[i].p; ctx->cull_pool.erase(ctx->cull_pool.begin() + (long)i); break; }
+  if (!cells) {
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&cells), bytes);
+    if (e == hipErrorOutOfMemory) {  // give the pool back and try once more
+      (void)hipGetLastError();
+      for (auto& b : ctx->cull_pool) (void)hipFree(b.p);
+      ctx->cull_pool.clear();
+      e = hipMalloc(reinterpret_cast<void**>(&cells), bytes);
+    }
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return RM_OK; }
+    if (e != hipSuccess) return fail(ctx, RM_ERR_DEVICE, std::string("culling grid: ") + hipGetErrorString(e));
+  }
   build.prims = s->d_prims;
-  build.cells = s->d_cull;
+  build.cells = cells;
   hipError_t e = rm::launch_cull_build(build, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  if (e != hipSuccess) { (void)hipGetLastError(); (void)hipFree(s->d_cull); s->d_cull = nullptr; return; }
-  g.cells = s->d_cull;
+  if (e == hipSuccess && !ctx->cull_event) e = hipEventCreateWithFlags(&ctx->cull_event, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventRecord(ctx->cull_event, ctx->stream);
+  if (e != hipSuccess) {
+    (void)hipFree(cells);
+    return fail(ctx, RM_ERR_DEVICE, std::string("culling grid: ") + hipGetErrorString(e));
+  }
+  s->d_cull = cells;
+  s->cull_bytes = bytes;
+  g.cells = cells;
   s->dev.cull = g;
+  ctx->cull_bytes += bytes;
+  ctx->cull_built++;
+  ctx->cull_scenes.push_back(s);
+  return RM_OK;
+}
+
+int rm_ctx_set_cull_min_pixels(rm_ctx* ctx, long long pixels) {
+  if (!ctx) return RM_ERR_INVALID;
+  if (pixels < 0) return fail(ctx, RM_ERR_INVALID, "rm_ctx_set_cull_min_pixels: pixels must be >= 0");
+  ctx->cull_min_pixels = pixels;
+  return RM_OK;
+}
+
+int rm_ctx_cull_stats(const rm_ctx* ctx, unsigned long long* out4) {
+  if (!ctx || !out4) return RM_ERR_INVALID;
+  out4[0] = ctx->cull_built;
+  out4[1] = (unsigned long long)ctx->cull_bytes;
+  out4[2] = (unsigned long long)ctx->cull_scenes.size();
+  out4[3] = (unsigned long long)ctx->cull_budget;
+  return RM_OK;
 }
 
 // ---- the hot path ---------------------------------------------------------------
@@ -941,7 +1037,7 @@ static int build_params(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniform
     l1 = (y1 > fb->row_begin + fb->row_count ? fb->row_begin + fb->row_count : y1) - fb->row_begin;
   }
   *empty = x1 <= x0 || l1 <= l0;
-  scene_cull_grid(ctx, scene, flags);
+  if (int rc = scene_cull_grid(ctx, scene, flags, *empty ? 0ll : (long long)(x1 - x0) * (long long)(l1 - l0))) return rc;
   P->u = *u;
   P->scene = scene->dev;
   P->color = fb->plane[0];
@@ -1224,11 +1320,13 @@ static hipError_t launch_pixels_in_flight(rm_ctx* ctx, const KParams& P, int fla
   hipStream_t side = ctx->sp_stream[slot];
   // the render reads no plane: it only has to wait until the blend that last used this staging buffer is done
   if ((e = hipStreamWaitEvent(side, ctx->sp_free[slot], 0)) != hipSuccess) return e;
+  if (ctx->cull_event && (e = hipStreamWaitEvent(side, ctx->cull_event, 0)) != hipSuccess) return e;  // ... and for the scene's culling grid, built on the context's stream
   ctx->lpt[slot].launches = 0;
   if ((e = launch_pixels_ordered(ctx, Q, flags, side, slot)) != hipSuccess) return e;
   if ((e = hipEventRecord(ctx->sp_done[slot], side)) != hipSuccess) return e;
   if (ctx->lpt[slot].launches > 0) {  // the launch recorded tile costs: sort them now, behind the completion event
-    if ((e = rm::launch_order(ctx->lpt[slot].cost, ctx->lpt[slot].order, (int)ctx->lpt[slot].launches, side)) != hipSuccess) return e;
+    rm_ctx::Lpt& Ls = ctx->lpt[slot];
+    if ((e = rm::launch_order(Ls.cost, Ls.order, Ls.order + Ls.capacity, (int)Ls.launches, side)) != hipSuccess) return e;
   }
   if ((e = hipStreamWaitEvent(ctx->stream, ctx->sp_done[slot], 0)) != hipSuccess) return e;
   if ((e = rm::launch_combine(Q, ctx->stream)) != hipSuccess) return e;
@@ -1260,10 +1358,11 @@ static hipError_t launch_pixels_ordered(rm_ctx* ctx, const KParams& P, int flags
     L.cost = L.order = L.cost2 = L.order2 = nullptr;
     L.capacity = 0;
     if ((e = hipMalloc(reinterpret_cast<void**>(&L.cost), sizeof(unsigned int) * (size_t)tiles)) != hipSuccess) return e;
-    if ((e = hipMalloc(reinterpret_cast<void**>(&L.order), sizeof(unsigned int) * (size_t)tiles)) != hipSuccess) return e;
+    const size_t order_elems = (size_t)tiles + rm::rm_order_scratch_elems(tiles);  // the sort's per-workgroup histograms behind the order
+    if ((e = hipMalloc(reinterpret_cast<void**>(&L.order), sizeof(unsigned int) * order_elems)) != hipSuccess) return e;
     if (async_sort) {
       if ((e = hipMalloc(reinterpret_cast<void**>(&L.cost2), sizeof(unsigned int) * (size_t)tiles)) != hipSuccess) return e;
-      if ((e = hipMalloc(reinterpret_cast<void**>(&L.order2), sizeof(unsigned int) * (size_t)tiles)) != hipSuccess) return e;
+      if ((e = hipMalloc(reinterpret_cast<void**>(&L.order2), sizeof(unsigned int) * order_elems)) != hipSuccess) return e;
     }
     L.capacity = (int)tiles;
     L.have_cost = false;
@@ -1275,7 +1374,7 @@ static hipError_t launch_pixels_ordered(rm_ctx* ctx, const KParams& P, int flags
   KParams Q = P;
   if (!async_sort) {
     // a sample-in-flight slot: the costs are sorted on the slot's own stream right AFTER the render (sort_slot_costs,
-    // called once the render's completion event is recorded), so the 15 us of the one-workgroup sort sit in the
+    // called once the render's completion event is recorded), so the sort's two small launches sit in the
     // shadow of the other slots' renders instead of in front of this slot's next one
     Q.block_cost = L.cost;
     if (L.have_cost) Q.block_order = L.order;
@@ -1312,7 +1411,7 @@ static hipError_t launch_pixels_ordered(rm_ctx* ctx, const KParams& P, int flags
   if ((e = fast ? rm::launch_pixels_fast(Q, stream) : ctx->gl_stack ? rm_gl_launch_pixels(&Q, stream) : rm::launch_pixels_strict(Q, stream)) != hipSuccess) return e;
   if ((e = hipEventRecord(L.rendered[cur], stream)) != hipSuccess) return e;
   if ((e = hipStreamWaitEvent(ctx->lpt_stream, L.rendered[cur], 0)) != hipSuccess) return e;
-  if ((e = rm::launch_order(cost_cur, order_cur, (int)tiles, ctx->lpt_stream)) != hipSuccess) return e;  // sorts and zeroes the costs
+  if ((e = rm::launch_order(cost_cur, order_cur, order_cur + L.capacity, (int)tiles, ctx->lpt_stream)) != hipSuccess) return e;  // sorts and zeroes the costs
   if ((e = hipEventRecord(L.sorted[cur], ctx->lpt_stream)) != hipSuccess) return e;
   L.launches++;
   return hipSuccess;
@@ -1635,27 +1734,37 @@ int rm_present_sharded_start(rm_ctx* const* ctxs, rm_fb* const* fbs, int parts, 
   return RM_OK;
 }
 
-int rm_present_sharded_finish(rm_ctx* const* ctxs, int parts, uint8_t* out_rgba8) {
+int rm_present_sharded_finish(rm_ctx* const* ctxs, int parts, uint8_t* out_rgba8, size_t out_bytes) {
   rm_ctx* root = (ctxs && parts >= 1) ? ctxs[0] : nullptr;
   if (!root || !out_rgba8) return fail(root, RM_ERR_INVALID, "rm_present_sharded_finish: NULL argument");
   if (!root->shard_pending) return fail(root, RM_ERR_INVALID, "rm_present_sharded_finish: no present was started");
+  const size_t bytes = (size_t)root->shard_h * (size_t)root->shard_w * sizeof(uchar4);
+  if (out_bytes < bytes) {  // (the present stays pending: the caller can come back with the right buffer)
+    char buf[160];
+    std::snprintf(buf, sizeof buf, "rm_present_sharded_finish: the pending present is %d x %d (%zu bytes), the buffer holds %zu", root->shard_w, root->shard_h, bytes, out_bytes);
+    return fail(root, RM_ERR_INVALID, buf);
+  }
   root->shard_pending = false;
   RM_HIP(root, hipSetDevice(root->device));
   RM_HIP(root, hipEventSynchronize(root->shard_done));  // the present's own work only: the renders enqueued since go on
-  std::memcpy(out_rgba8, root->shard_host, (size_t)root->shard_h * (size_t)root->shard_w * sizeof(uchar4));
+  std::memcpy(out_rgba8, root->shard_host, bytes);
   return RM_OK;
 }
 
-int rm_present_sharded(rm_ctx* const* ctxs, rm_fb* const* fbs, int parts, int samples, int dof, uint8_t* out_rgba8) {
-  if (!out_rgba8) return fail((ctxs && parts >= 1) ? ctxs[0] : nullptr, RM_ERR_INVALID, "rm_present_sharded: NULL argument");
+int rm_present_sharded(rm_ctx* const* ctxs, rm_fb* const* fbs, int parts, int samples, int dof, uint8_t* out_rgba8, size_t out_bytes) {
+  rm_ctx* root = (ctxs && parts >= 1) ? ctxs[0] : nullptr;
+  if (!out_rgba8) return fail(root, RM_ERR_INVALID, "rm_present_sharded: NULL argument");
+  if (fbs && parts >= 1 && fbs[0] && out_bytes < (size_t)fbs[0]->width * (size_t)fbs[0]->height * sizeof(uchar4))
+    return fail(root, RM_ERR_INVALID, "rm_present_sharded: the buffer is smaller than width * height * 4 bytes");  // (before anything is started)
   if (int rc = rm_present_sharded_start(ctxs, fbs, parts, samples, dof)) return rc;
-  return rm_present_sharded_finish(ctxs, parts, out_rgba8);
+  return rm_present_sharded_finish(ctxs, parts, out_rgba8, out_bytes);
 }
 
 // ---- probes ----------------------------------------------------------------------
 
 int rm_probe(rm_ctx* ctx, rm_scene* scene, int what, const float* in, int n, float param, int flags, float* out) {
   if (!ctx || !scene || !in || !out) return fail(ctx, RM_ERR_INVALID, "rm_probe: NULL argument");
+  if (scene->ctx != ctx) return fail(ctx, RM_ERR_INVALID, "rm_probe: the scene belongs to another context");
   if (what < RM_PROBE_SDF || what > RM_PROBE_CAST_SHADOW) return fail(ctx, RM_ERR_INVALID, "rm_probe: unknown probe");
   if (n <= 0) return RM_OK;
   static const int in_w[6] = {3, 6, 3, 3, 6, 9}, out_w[6] = {1, 3, 3, 12, 1, 1};
@@ -1665,8 +1774,8 @@ int rm_probe(rm_ctx* ctx, rm_scene* scene, int what, const float* in, int n, flo
   RM_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&d_in), in_bytes));
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_out), out_bytes);
   if (e == hipSuccess) e = hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && scene_cull_grid(ctx, scene, flags, 1ll << 40) != RM_OK) e = hipErrorUnknown;  // (a probe is a test's call: with the grid)
   if (e == hipSuccess) {
-    scene_cull_grid(ctx, scene, flags);
     ProbeParams P{scene->dev, d_in, d_out, n, what, param, (flags & RM_RENDER_FAST) ? ctx->retire_eps : 0.0f, (flags & RM_RENDER_NO_FAR_JUMP) ? 1 : 0};
     if (P.no_far_jump) P.scene.far_end = 0, P.scene.clear_rho = 0.0f;
     if (flags & RM_RENDER_NO_CULL) P.scene.cull.cells = nullptr;

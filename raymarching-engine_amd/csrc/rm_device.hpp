@@ -603,13 +603,16 @@ struct Sdf<RM_SCENE_TABLE> {
     const int level = t < 1.0f ? 0 : e;
     // (v_max drops a NaN, so t does not see one: the 1-norm does -- NaN or Inf for a point with a non-finite coordinate)
     const bool inside = fabsf(x) + fabsf(y) + fabsf(z) < 3.0e38f && level < g.levels;
-    const float scale = g.scale0 * __uint_as_float((unsigned int)(127 - (inside ? level : 0)) << 23);  // scale0 * 2^-level
-    const float h = 0.5f * (float)g.n;
-    const int top = g.n - 1;
+    const bool outer = inside && level > 0;
+    const int nl = outer ? g.n_outer : g.n;  // cells across this point's level
+    // scale0 * 2^-level, and half of that where the outer levels' cells are twice as wide (n_outer is n or n / 2)
+    const float scale = g.scale0 * __uint_as_float((unsigned int)(127 - (inside ? level : 0) - (outer && g.n_outer != g.n ? 1 : 0)) << 23);
+    const float h = 0.5f * (float)nl;
+    const int top = nl - 1;
     const int ix = min(max(__float2int_rd(FM::fma(x, scale, h)), 0), top), iy = min(max(__float2int_rd(FM::fma(y, scale, h)), 0), top),
               iz = min(max(__float2int_rd(FM::fma(z, scale, h)), 0), top);
-    const int per_level = g.n * g.n * g.n;
-    const int idx = inside ? level * per_level + (iz * g.n + iy) * g.n + ix : g.levels * per_level;
+    const int level0 = g.n * g.n * g.n, per_outer = g.n_outer * g.n_outer * g.n_outer;
+    const int idx = !inside ? level0 + (g.levels - 1) * per_outer : (outer ? level0 + (level - 1) * per_outer : 0) + (iz * nl + iy) * nl + ix;
     return g.cells + (size_t)idx * (size_t)g.words;
   }
   // the union of the active lanes' row sets, as a scalar: the first lane's set, then -- a few times -- the set of the first lane that

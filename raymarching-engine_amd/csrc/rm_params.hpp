@@ -15,26 +15,31 @@
 
 #define RM_BATCH_MAX 8  /* samples one pixel-kernel launch can render (KParams::batch) */
 
-// Row culling for primitive tables without domain rows (round 3; fast policy; rm_kernels.inc rm_cull_build_kernel fills it when
-// the scene is created, rm_device.hpp Sdf<RM_SCENE_TABLE>::culled_rows reads it).  Nested uniform grids about the shapes' bounding
-// box: level l is a cube of n^3 cells with half-width half0 * 2^l about `centre`, and a point belongs to the lowest level that
-// holds it.  Per cell one bit per row -- clear = the row's operator cannot change the running value of the fold anywhere in the
-// cell (an exact no-op there), so an evaluation may skip it.  cells = [levels][n^3 cells][words] 64-bit words, then one cell that
-// lists every row (points beyond the last level, non-finite points).
+// Row culling for primitive tables without domain rows (round 3; both builds since round 4; rm_kernels.inc rm_cull_build_kernel fills
+// it before the first launch that can use it, rm_device.hpp Sdf<RM_SCENE_TABLE>::culled_rows reads it).  Nested uniform grids about
+// the shapes' bounding box: level l is a cube with half-width half0 * 2^l about `centre`, of n^3 cells for level 0 and n_outer^3 for
+// the levels around it (round 5: a ray spends its steps near the shapes, where the cells have to be small; the levels it merely
+// crosses on its way in take cells twice as wide -- 31.5 MB instead of 134 for CSG-64), and a point belongs to
+// the lowest level that holds it.  Per cell one bit per row -- clear = the row's operator cannot change the running value of the fold
+// anywhere in the cell (an exact no-op there), so an evaluation may skip it.  cells = [level 0: n^3][levels 1 ..: n_outer^3 each][words]
+// 64-bit words, then one cell that lists every row (points beyond the last level, non-finite points).
 struct CullGrid {
   const unsigned long long* cells;  // device pointer; nullptr = no culling
   float centre[3];
   float inv_half0;  // 1 / half0
   float scale0;     // cells per unit length at level 0: n / (2 half0)
-  int n, levels, words;
+  int n, n_outer, levels, words;  // n_outer is n or n / 2
 };
 struct CullBuild {  // argument block of rm_cull_build_kernel
   const RmPrim* prims;
   unsigned long long* cells;
-  int nprims, n, levels, words;
+  int nprims, n, n_outer, levels, words;
   double centre[3], half0;
   double reach;  // the largest |coordinate| of a shape: scale of the fp32 error allowance
 };
+__host__ __device__ inline long long rm_cull_cells(int n, int n_outer, int levels) {  // without the cell that lists every row
+  return (long long)n * n * n + (long long)(levels - 1) * n_outer * n_outer * n_outer;
+}
 
 // the fp32 allowance of the culling tests: n + 8 roundings at the magnitude of the coordinates involved
 __host__ __device__ inline double rm_cull_margin(int nprims, double magnitude) { return 1e-4 + 1.2e-7 * (nprims + 8) * magnitude; }
@@ -71,6 +76,9 @@ __host__ __device__ inline double rm_cull_shape_distance(const RmPrim& p, const 
 // identities there) -- which is what lets a wave fold the union of its lanes' lists.  About half of CSG-64's 64 rows stay per cell.
 // tests/test_cull_rule_cpu.py checks the rule against fp32 restatements of both builds' folds; the GPU suite holds the culled fold
 // to RM_RENDER_NO_CULL bit for bit.
+// the exponent of a positive, finite, normal double, read off its exponent field (round 5; rounds 3-4 called the library's
+// logarithm -- three times per row and cell, most of the build kernel's 8.9 ms on CSG-64's grid)
+__host__ __device__ inline int rm_exponent(double v) { return ilogb(v); }
 __host__ __device__ inline double rm_smooth_min(double a, double b, double k) {  // examples/smooth-tree.glsl:20-22, in double
   double h = 0.5 + 0.5 * (b - a) / k;
   h = h < 0.0 ? 0.0 : (h > 1.0 ? 1.0 : h);
@@ -104,11 +112,11 @@ __host__ __device__ inline void rm_cull_cell(const RmPrim* prims, int nprims, in
         B = NONE;  // possibly near: whatever grid d was on, it leaves it
       } else {
         const double emin = lo_i - U - 2.0 * margin, emax = hi_i - L + 2.0 * margin;  // t = di - d over the cell, both > 0
-        const int bmin = (int)floor(log2(emin * (1.0 - 1e-5))), bmax = (int)floor(log2(emax * (1.0 + 1e-5)));
+        const int bmin = rm_exponent(emin * (1.0 - 1e-5)), bmax = rm_exponent(emax * (1.0 + 1e-5));
         // the lowest binade of |di| over the cell; a far row's distance may be negative (the running value is then further inside
         // still) or change sign in the cell: then |di| has no lowest binade and nothing is claimed
         const double lo_m = lo_i - margin, hi_m = hi_i + margin;
-        const int bdi = lo_m > 0.0 ? (int)floor(log2(lo_m * (1.0 - 1e-5))) : (hi_m < 0.0 ? (int)floor(log2(-hi_m * (1.0 - 1e-5))) : NONE);
+        const int bdi = lo_m > 0.0 ? rm_exponent(lo_m * (1.0 - 1e-5)) : (hi_m < 0.0 ? rm_exponent(-hi_m * (1.0 - 1e-5)) : NONE);
         if (B != NONE && B >= bmax && bmax <= bdi) {
           keep = false;  // an exact no-op everywhere in the cell
         } else {
@@ -280,7 +288,9 @@ struct WfParams {
 hipError_t wf_launch_march_strict(const WfParams& W, bool preview, int pass, int blocks, hipStream_t stream);
 hipError_t wf_launch_march_fast(const WfParams& W, bool preview, int pass, int blocks, hipStream_t stream);
 hipError_t launch_combine(const KParams& P, hipStream_t stream);
-hipError_t launch_order(unsigned int* cost, unsigned int* order, int n, hipStream_t stream);
+// scratch: 64 counters per RM_ORDER_TILES_PER_GROUP tiles (rm_order_scratch_elems)
+hipError_t launch_order(unsigned int* cost, unsigned int* order, unsigned int* scratch, int n, hipStream_t stream);
+inline size_t rm_order_scratch_elems(long long tiles) { return (size_t)(64 * ((tiles + 4095) / 4096)); }
 hipError_t launch_cull_build(const CullBuild& B, hipStream_t stream);
 void pixel_grid(const KParams& P, int* gx, int* gy);  // workgroup grid the pixel kernel uses for this job
 hipError_t wf_launch_shade_strict(const WfParams& W, hipStream_t stream);

@@ -262,6 +262,9 @@ class ShardedFramebuffer:
         import torch
 
         self.torch = torch
+        if not group.sharded:  # one rank and no `force`: nothing is gathered (FrameGatherer allocates nothing) and present() would have no frame
+            raise ValueError("ShardedFramebuffer: a group of one rank does not shard a frame -- use native.Context.create_framebuffer "
+                             "(job.RenderJobContext does), or ShardGroup(force=True) to run the collective path with one rank")
         self.ctx, self.group = native_ctx, group
         self.width, self.height = width, height
         self.fb = native_ctx.create_striped_framebuffer(width, height, group.stripe_rows, group.world, group.rank)
@@ -317,6 +320,12 @@ class ShardedFramebuffer:
         # assembled (colour.rgb, dofRadius) buffer is both of its planes (display.frag reads .rgb of one, .w of the other) --
         # straight into the snapshot of an RGBA8 gather, which then is the one of a job without depth of field
         gr = self.group
+        if not frame.is_cuda and not getattr(self.ctx, "takes_host_pointers", False):
+            # the library's present pass reads DEVICE memory; a CPU group (gloo) only exists in the tests, whose stand-in context says so
+            raise RuntimeError("ShardedFramebuffer.finish_present: the gathered frame is in host memory (a CPU group) and the render context "
+                               "is a real one: rm_present_striped_rows takes device pointers")
+        # (the blur of this rank's stripes and the RGBA8 gather behind it run here, back to back: of a depth-of-field present only the
+        # all-gather of the packed rows overlaps the next samples; every rank holds recv_all + frame, two full-frame float4 buffers)
         g8 = self.gatherer("rgba8")
         g8.start(None, gr.dist, fill=lambda snap, stream: self.ctx.present_striped_rows(frame.data_ptr(), frame.data_ptr(), self.width, self.height, samples,
                                                                                         gr.stripe_rows, gr.world, gr.rank, snap.data_ptr(), stream))

@@ -242,9 +242,12 @@ class RenderJobContext:
                 torch.cuda.set_stream(self.stream)
                 self.native.set_stream(self.stream.cuda_stream)
         # programCache: by description; bounded (the reference's cache grows with every edit of the shader text -- a page's lifetime; a
-        # long-running host that animates scene parameters would otherwise keep a device table, and for long CSG tables a culling
-        # grid of 5-14 MB, per distinct scene).  Least recently used out first, its handle destroyed.
+        # long-running host that animates scene parameters would otherwise keep a device table per distinct scene; the culling grids
+        # of long CSG tables -- 31.5 MB per 64 rows -- are bounded by the library itself, by bytes: include/hip_raymarch.h
+        # rm_ctx_cull_stats).  Least recently used out first, its handle destroyed -- but never a scene a job still renders
+        # (do_render_job pins its scene while its generator lives: jobs yield between samples).
         self._scenes: "OrderedDict[bytes, object]" = OrderedDict()
+        self._pins: Dict[bytes, int] = {}
         self._live: Dict[Tuple[int, int, int], object] = {}
         self._purgatory: list = []
 
@@ -260,13 +263,38 @@ class RenderJobContext:
             except native.RmError as e:  # cached like a failed compile
                 hit = {"type": "fragment", "infoLog": str(e)}
             self._scenes[key] = hit
-            while len(self._scenes) > SCENE_CACHE_ENTRIES:
-                _, old = self._scenes.popitem(last=False)
-                if not isinstance(old, dict) and hasattr(old, "destroy"):
-                    old.destroy()  # (rm_scene_destroy waits for the renders that use it)
+            self._evict()
         else:
             self._scenes.move_to_end(key)
         return hit
+
+    def _evict(self):
+        spare = len(self._scenes) - SCENE_CACHE_ENTRIES
+        pins = self.__dict__.setdefault("_pins", {})
+        for k in [k for k in self._scenes if k not in pins][:max(spare, 0)]:  # least recently used first; pinned scenes stay
+            old = self._scenes.pop(k)
+            if not isinstance(old, dict) and hasattr(old, "destroy"):
+                old.destroy()  # (rm_scene_destroy waits for the renders that use it)
+
+    def pin_scene(self, scene: Scene):
+        """get_scene for the lifetime of a job: the handle (or the cached error value) stays out of the cache's eviction until
+        unpin_scene -- a suspended job's scene is not destroyed under it by the 64 scenes other jobs bring in."""
+        from . import native
+
+        hit = self.get_scene(scene)
+        key = native.scene_key(scene)
+        pins = self.__dict__.setdefault("_pins", {})
+        pins[key] = pins.get(key, 0) + 1
+        return key, hit
+
+    def unpin_scene(self, key):
+        pins = self.__dict__.setdefault("_pins", {})
+        n = pins.get(key, 0) - 1
+        if n > 0:
+            pins[key] = n
+        else:
+            pins.pop(key, None)
+            self._evict()
 
     def close(self):
         """Destroys the cached scenes and framebuffers and, for a sharded context on a GPU, makes the stream that was torch's
@@ -367,6 +395,19 @@ def do_render_job(schema: dict, context: RenderJobContext):
         fb.dof = schema["dof"]["amount"] != 0.0  # selects what the ranks gather for a present (dist.ShardedFramebuffer)
 
     def gen(present: Callable):
+        # the scene stays pinned in the context's cache while this generator lives (it yields between samples, and other jobs may
+        # bring more scenes than the cache holds in the meantime); looked up again here: the generator may start long after the call
+        key, handle = context.pin_scene(scene)
+        try:
+            if isinstance(handle, dict):
+                return {"success": False, "why": handle}
+            return (yield from run(present, handle))
+        finally:
+            context.unpin_scene(key)
+
+    def run(present: Callable, handle):
+        from . import native as _native
+
         samples = 0
         n = r["subdivisions"]
         for y_part in range(n):  # :148-162
@@ -383,10 +424,13 @@ def do_render_job(schema: dict, context: RenderJobContext):
                     k = min(left, r["sampleYieldInterval"] - samples % r["sampleYieldInterval"])
                     noise = [next_rand_noise() for _ in range(k)]
                     u = uniforms_from_schema(schema, noise[0])
-                    if k == 1:
-                        context.native.render_sample(handle, fb, u, tile, context.flags)  # :181-326
-                    else:
-                        context.native.render_samples(handle, fb, u, noise, tile, context.flags)
+                    try:
+                        if k == 1:
+                            context.native.render_sample(handle, fb, u, tile, context.flags)  # :181-326
+                        else:
+                            context.native.render_samples(handle, fb, u, noise, tile, context.flags)
+                    except _native.RmError as e:  # errors are values (RenderJobExecutor.tsx:56-68)
+                        return {"success": False, "why": {"type": "general", "infoLog": "render failed: " + str(e)}}
                     samples += k
                     left -= k
         context.fbo_delete(r["width"], r["height"], r["frameid"])  # :333-337

@@ -227,20 +227,34 @@ function tileRect(schema, xp, yp) {
 
 // A scene cache keeps this many entries (a Map iterates in insertion order: the first key is the least recently used).  The
 // reference's programCache grows with every edit of the shader text, for a page's lifetime; a long-running host that animates scene
-// parameters would otherwise keep a device table -- and for a long CSG table a culling grid of 5-14 MB -- per distinct scene.
+// parameters would otherwise keep a device table per distinct scene (the culling grids of long CSG tables -- 31.5 MB per 64 rows --
+// are bounded by the library itself, by bytes: rm_ctx_cull_stats).  A scene a job still renders is pinned (doRenderJob: jobs yield
+// between samples) and is never the one that goes.
 const SCENE_CACHE_ENTRIES = 64;
-function evictScenes(map, destroy) { while (map.size > SCENE_CACHE_ENTRIES) { const k = map.keys().next().value; const v = map.get(k); map.delete(k); destroy(v); } }
+function evictScenes(map, destroy, pins) {
+  let spare = map.size - SCENE_CACHE_ENTRIES;
+  for (const k of Array.from(map.keys())) {
+    if (spare <= 0) break;
+    if (pins && pins.get(k) > 0) continue;
+    const v = map.get(k); map.delete(k); destroy(v); spare--;
+  }
+}
+const scenePins = {  // mixed into both contexts: pinScene(scene) -> [key, handle or error value]; unpinScene(key)
+  pinScene(scene) { const hit = this.getScene(scene), key = scene.key(); this.pins.set(key, (this.pins.get(key) || 0) + 1); return [key, hit]; },
+  unpinScene(key) { const n = (this.pins.get(key) || 0) - 1; if (n > 0) this.pins.set(key, n); else { this.pins.delete(key); this.evict(); } },
+};
 
 class RenderJobContext {  // RenderJobContext + loadRenderJobContext (LoadRenderJobContext.tsx:162-287)
   constructor(device = 0, flags = RM.RENDER_STRICT) {
-    this.ctx = addon.ctxCreate(device); this.flags = flags; this.scenes = new Map(); this.live = new Map(); this.purgatory = [];
+    this.ctx = addon.ctxCreate(device); this.flags = flags; this.scenes = new Map(); this.pins = new Map(); this.live = new Map(); this.purgatory = [];
   }
+  evict() { evictScenes(this.scenes, (s) => { if (!(s && s.infoLog)) addon.sceneDestroy(s); }, this.pins); }
   getScene(scene) {  // programCache.getProgram: results AND errors are cached (ShaderCache.tsx:91-119); bounded, least recently used out first
     const key = scene.key();
     if (!this.scenes.has(key)) {
       try { const d = scene.desc(); this.scenes.set(key, addon.sceneCreate(this.ctx, d.desc, d.prims, d.surfaces)); }
       catch (e) { this.scenes.set(key, { type: "fragment", infoLog: String(e.message) }); }
-      evictScenes(this.scenes, (s) => { if (!(s && s.infoLog)) addon.sceneDestroy(s); });
+      this.evict();
     } else { const hit = this.scenes.get(key); this.scenes.delete(key); this.scenes.set(key, hit); }
     return this.scenes.get(key);
   }
@@ -286,15 +300,16 @@ class ShardedRenderJobContext {
     this.ctxs = devices.map((d) => addon.ctxCreate(d));
     for (const c of this.ctxs) addon.setSamplesInFlight(c, samplesInFlight);
     this.ctx = this.ctxs[0];
-    this.scenes = new Map(); this.live = new Map(); this.purgatory = [];
+    this.scenes = new Map(); this.pins = new Map(); this.live = new Map(); this.purgatory = [];
   }
+  evict() { evictScenes(this.scenes, (s) => { if (s.handles) for (const h of s.handles) addon.sceneDestroy(h); }, this.pins); }
   getScene(scene) {  // one handle per context; a failure (on any of them) is cached like a failed compile
     const key = scene.key();
     if (!this.scenes.has(key)) {
       const made = [];
       try { const d = scene.desc(); for (const c of this.ctxs) made.push(addon.sceneCreate(c, d.desc, d.prims, d.surfaces)); this.scenes.set(key, { handles: made }); }
       catch (e) { for (const h of made) addon.sceneDestroy(h); this.scenes.set(key, { type: "fragment", infoLog: String(e.message) }); }
-      evictScenes(this.scenes, (s) => { if (s.handles) for (const h of s.handles) addon.sceneDestroy(h); });
+      this.evict();
     } else { const hit = this.scenes.get(key); this.scenes.delete(key); this.scenes.set(key, hit); }
     return this.scenes.get(key);
   }
@@ -317,7 +332,11 @@ class ShardedRenderJobContext {
                    // `present` callback that calls it lets doRenderJob hand out the next samples while the frame travels; finishPresent
                    // (at the next callback, or whenever the canvas is wanted) returns the canvas of THAT present.  One at a time.
                    startPresent: (samples, dof = info.dof) => { addon.presentShardedStart(this.ctxs, fbs, samples, !!dof); info.pendingPresent = true; },
-                   finishPresent: () => { const out = new Uint8Array(w * h * 4); addon.presentShardedFinish(this.ctxs, out); info.pendingPresent = false; return out; },
+                   finishPresent: () => {
+                     // the pending present lives on the contexts, not on this framebuffer set: only the set that started it may finish it
+                     // (another set's canvas may be smaller; the library checks the buffer's size as well)
+                     if (!info.pendingPresent) throw new Error("finishPresent: this framebuffer set has no present pending (startPresent was called on another set, or not at all)");
+                     const out = new Uint8Array(w * h * 4); addon.presentShardedFinish(this.ctxs, out); info.pendingPresent = false; return out; },
                    pendingPresent: false,
                    toDataURL: (samples) => "data:image/png;base64," + encodePng(info.present(samples), w, h).toString("base64") };
     this.live.set(key, info);
@@ -338,6 +357,9 @@ class ShardedRenderJobContext {
   }
 }
 
+Object.assign(RenderJobContext.prototype, scenePins);
+Object.assign(ShardedRenderJobContext.prototype, scenePins);
+
 async function doRenderJob(schema, context) {  // RenderJobExecutor.tsx:77
   const fail = (why) => function* () { return { success: false, why }; };
   const r = schema.render;
@@ -345,19 +367,24 @@ async function doRenderJob(schema, context) {  // RenderJobExecutor.tsx:77
   try { framebuffers = context.fboCreate(r.width, r.height, r.frameid); }
   catch (e) { return fail({ type: "general", infoLog: "Failed to load framebuffers. " + e.message }); }
   if (!schema.sdfScene) return fail({ type: "fragment", infoLog: "no sdfScene: the HIP back end takes a composed scene, not GLSL text" });
-  const scene = context.getScene(schema.sdfScene);
-  if (scene && scene.infoLog !== undefined) return fail(scene);
+  const compiled = context.getScene(schema.sdfScene);
+  if (compiled && compiled.infoLog !== undefined) return fail(compiled);
   let samples = 0;
   // a sharded context: the same calls on every GPU's context, each with its part of the stripes (the tile is clipped to them)
   const ctxs = framebuffers.sharded ? context.ctxs : [context.ctx];
   const fbs = framebuffers.sharded ? framebuffers.fbs : [framebuffers.fb];
-  const scenes = framebuffers.sharded ? scene.handles : [scene];
   if (framebuffers.sharded) framebuffers.dof = schema.dof.amount !== 0;  // what a present gathers (rm_present_sharded)
   // (a sharded set's present is ordered on the contexts' streams behind the samples: no host-side wait before it, so that a
   // callback using startPresent overlaps the travelling frame with the next samples; the single context waits as it always did)
   const syncAll = () => { if (!framebuffers.sharded) for (const c of ctxs) addon.sync(c); };
   const syncEnd = () => { for (const c of ctxs) addon.sync(c); };
   return function* (present) {
+    // the scene stays pinned in the context's cache while this generator lives (it yields between samples; other jobs may bring in
+    // more scenes than the cache holds meanwhile); looked up again here: the generator may start long after the call above
+    const [pinKey, scene] = context.pinScene(schema.sdfScene);
+    try {
+    if (scene && scene.infoLog !== undefined) return { success: false, why: scene };
+    const scenes = framebuffers.sharded ? scene.handles : [scene];
     for (let yp = 0; yp < r.subdivisions; yp++) for (let xp = 0; xp < r.subdivisions; xp++) {
       const tile = tileRect(schema, xp, yp);
       for (let left = r.samplesPerPixel; left > 0;) {
@@ -378,6 +405,7 @@ async function doRenderJob(schema, context) {  // RenderJobExecutor.tsx:77
     syncEnd();  // the job's last word: an asynchronous failure becomes this call's exception (the caller's {success: false})
     present(schema, context, framebuffers, samples);
     return { success: true };
+    } finally { context.unpinScene(pinKey); }
   };
 }
 

@@ -355,8 +355,8 @@ static napi_value PresentShardedImpl(napi_env env, napi_callback_info info, bool
     napi_get_value_bool(env, argv[3], &dof);
     if (rm_present_sharded_start(ctxs, fbs, (int)n, samples, dof ? 1 : 0) != RM_OK) return throw_rm(env, ctxs[0], "rm_present_sharded_start");
   }
-  // (presentShardedFinish: the library knows the canvas of the pending present; index.js allocates `out` from the framebuffer set's size)
-  if (finish && rm_present_sharded_finish(ctxs, (int)n, static_cast<uint8_t*>(d)) != RM_OK) return throw_rm(env, ctxs[0], "rm_present_sharded_finish");
+  // (presentShardedFinish: the library knows the canvas of the pending present and refuses a smaller `out`, leaving the present pending)
+  if (finish && rm_present_sharded_finish(ctxs, (int)n, static_cast<uint8_t*>(d), len) != RM_OK) return throw_rm(env, ctxs[0], "rm_present_sharded_finish");
   return nullptr;
 }
 static napi_value PresentSharded(napi_env env, napi_callback_info info) { return PresentShardedImpl(env, info, true, true); }

@@ -32,7 +32,7 @@ LIB_PATH = Path(os.environ.get("RM_LIB") or Path(__file__).resolve().parent / "l
 # every symbol include/hip_raymarch.h declares
 EXPORTS = [
     "rm_abi_version", "rm_material_default", "rm_ctx_create", "rm_ctx_destroy", "rm_last_error", "rm_ctx_set_stream",
-    "rm_ctx_set_retire_eps", "rm_ctx_set_samples_in_flight", "rm_ctx_last_warning", "rm_ctx_set_cost_order", "rm_debug_counters", "rm_device_memory", "rm_sync", "rm_scene_create", "rm_scene_destroy", "rm_fb_create", "rm_fb_create_striped", "rm_fb_rows", "rm_fb_width", "rm_fb_height", "rm_fb_wrap", "rm_fb_clear", "rm_fb_destroy",
+    "rm_ctx_set_retire_eps", "rm_ctx_set_samples_in_flight", "rm_ctx_last_warning", "rm_ctx_set_cost_order", "rm_ctx_set_cull_min_pixels", "rm_ctx_cull_stats", "rm_debug_counters", "rm_device_memory", "rm_sync", "rm_scene_create", "rm_scene_destroy", "rm_fb_create", "rm_fb_create_striped", "rm_fb_rows", "rm_fb_width", "rm_fb_height", "rm_fb_wrap", "rm_fb_clear", "rm_fb_destroy",
     "rm_fb_download", "rm_fb_upload", "rm_fb_device_ptr", "rm_buffer_create", "rm_buffer_destroy", "rm_buffer_download", "rm_buffer_upload", "rm_render_sample", "rm_render_samples", "rm_ctx_set_sample_batch", "rm_ctx_set_gl_stack", "rm_render_timed",
     "rm_probe", "rm_probe_camera", "rm_probe_rng", "rm_assemble_striped", "rm_assemble_striped_bytes", "rm_present", "rm_present_planes", "rm_present_device", "rm_present_rows", "rm_pack_present_rows", "rm_ctx_last_pipeline", "rm_present_sharded", "rm_present_sharded_start", "rm_present_sharded_finish", "rm_present_striped_rows", "rm_debug_cull_cell",
 ]
@@ -117,6 +117,8 @@ def load_library():
         "rm_buffer_download": (ip, [vp, vp, vp, C.c_size_t]),
         "rm_buffer_upload": (ip, [vp, vp, vp, C.c_size_t]),
         "rm_ctx_set_cost_order": (ip, [vp, C.c_int]),
+        "rm_ctx_set_cull_min_pixels": (ip, [vp, C.c_longlong]),
+        "rm_ctx_cull_stats": (ip, [vp, C.POINTER(C.c_ulonglong)]),
         "rm_debug_counters": (ip, [vp, C.POINTER(C.c_ulonglong), ip]),
         "rm_debug_cull_cell": (ip, [C.POINTER(abi.RmSceneDesc), C.POINTER(C.c_double), C.c_double, C.c_double, C.POINTER(C.c_ulonglong)]),
         "rm_sync": (ip, [vp]),
@@ -145,9 +147,9 @@ def load_library():
         "rm_present_rows": (ip, [vp, vp, ip, vp, vp]),
         "rm_pack_present_rows": (ip, [vp, vp, vp, vp]),
         "rm_ctx_last_pipeline": (ip, [vp]),
-        "rm_present_sharded": (ip, [C.POINTER(vp), C.POINTER(vp), ip, ip, ip, C.POINTER(C.c_uint8)]),
+        "rm_present_sharded": (ip, [C.POINTER(vp), C.POINTER(vp), ip, ip, ip, C.POINTER(C.c_uint8), C.c_size_t]),
         "rm_present_sharded_start": (ip, [C.POINTER(vp), C.POINTER(vp), ip, ip, ip]),
-        "rm_present_sharded_finish": (ip, [C.POINTER(vp), ip, C.POINTER(C.c_uint8)]),
+        "rm_present_sharded_finish": (ip, [C.POINTER(vp), ip, C.POINTER(C.c_uint8), C.c_size_t]),
         "rm_present_striped_rows": (ip, [vp, vp, vp, ip, ip, ip, ip, ip, ip, vp, vp]),
         "rm_present": (ip, [vp, vp, ip, C.POINTER(C.c_uint8)]),
         "rm_present_planes": (ip, [vp, vp, vp, ip, ip, ip, C.POINTER(C.c_uint8)]),
@@ -169,7 +171,7 @@ def present_sharded(contexts, framebuffers, samples: int, dof: bool) -> np.ndarr
     cs = (C.c_void_p * n)(*[c.h for c in contexts])
     fs = (C.c_void_p * n)(*[f.h for f in framebuffers])
     out = np.empty((framebuffers[0].height, framebuffers[0].width, 4), np.uint8)
-    contexts[0]._check(contexts[0].lib.rm_present_sharded(cs, fs, n, int(samples), 1 if dof else 0, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+    contexts[0]._check(contexts[0].lib.rm_present_sharded(cs, fs, n, int(samples), 1 if dof else 0, out.ctypes.data_as(C.POINTER(C.c_uint8)), out.nbytes))
     return out
 
 
@@ -187,7 +189,7 @@ def present_sharded_finish(contexts, width: int, height: int) -> np.ndarray:
     n = len(contexts)
     cs = (C.c_void_p * n)(*[c.h for c in contexts])
     out = np.empty((height, width, 4), np.uint8)
-    contexts[0]._check(contexts[0].lib.rm_present_sharded_finish(cs, n, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+    contexts[0]._check(contexts[0].lib.rm_present_sharded_finish(cs, n, out.ctypes.data_as(C.POINTER(C.c_uint8)), out.nbytes))
     return out
 
 
@@ -332,6 +334,15 @@ class Context:
     def set_cost_order(self, on: bool):
         """Start the tiles of a job most-expensive-first by their cost in the previous sample (scheduling only)."""
         self._check(self.lib.rm_ctx_set_cost_order(self.h, 1 if on else 0))
+
+    def set_cull_min_pixels(self, pixels: int):
+        """Pixel-samples a scene has to be asked for before its culling grid is built (0: with the first render; same bits)."""
+        self._check(self.lib.rm_ctx_set_cull_min_pixels(self.h, int(pixels)))
+
+    def cull_stats(self) -> dict:
+        out = (C.c_ulonglong * 4)()
+        self._check(self.lib.rm_ctx_cull_stats(self.h, out))
+        return dict(built=int(out[0]), bytes=int(out[1]), grids=int(out[2]), budget=int(out[3]))
 
     def set_retire_eps(self, eps: float):
         self._check(self.lib.rm_ctx_set_retire_eps(self.h, float(eps)))

@@ -7,6 +7,11 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# a scene's culling grid is built once the scene has earned it (4 Mi pixel-samples: include/hip_raymarch.h
+# rm_ctx_set_cull_min_pixels); the tests' renders are small and are about the grid's bits: with the first render
+os.environ.setdefault("RM_CULL_MIN_PIXELS", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -1809,6 +1809,51 @@ def test_row_culling_of_smooth_sphere_tables_is_exact(ctx, build):
                     assert same_bits(got[k], ref[k]).all(), f"table {it}, plane {k}: {int((~same_bits(got[k], ref[k])).sum())} values differ"
 
 
+def test_a_scene_earns_its_culling_grid_and_a_new_scene_every_frame_stays_exact(ctx):
+    """Round 5.  (1) A scene's grid is built once the scene has been asked for rm_ctx_set_cull_min_pixels pixel-samples -- not before,
+    exactly once, on the context's stream in front of the render that crosses the threshold -- and the frames before and after it
+    have the bits of RM_RENDER_NO_CULL.  (2) The job the reference's sliders produce (index.tsx:121-182: a NEW scene in every frame):
+    twelve CSG tables in a row, each rendered once with its grid built in front of it, each with the bits of the fold of every
+    row; the grids' buffers are recycled (one allocation's worth held at a time once the old scene is destroyed) and stay within the
+    context's budget."""
+    NC = abi.RM_RENDER_NO_CULL
+    rng = np.random.default_rng(4401 + SEED_OFFSET)
+    sc = S.csg64()
+    schema = J.make_schema(sc, 256, 256, counts=(96, 32), render_mode="full", position=(0.0, 0.0, -5.0), lights=GC.LIGHT)
+    noises = GC.halton_pairs(5)
+    ref = render_gpu(ctx, sc, schema, noises, FAST | MK | NC)
+    try:
+        ctx.set_cull_min_pixels(4 * 256 * 256 - 1)  # the fourth sample crosses it
+        built0 = ctx.cull_stats()["built"]
+        h = ctx.create_scene(sc)
+        fb = ctx.create_framebuffer(256, 256)
+        for i, n in enumerate(noises):
+            ctx.render_sample(h, fb, J.uniforms_from_schema(schema, tuple(n)), None, FAST | MK | abi.RM_RENDER_NO_OVERLAP)
+            assert ctx.cull_stats()["built"] - built0 == (1 if i >= 3 else 0), f"after sample {i}"
+        got = [fb.download(k) for k in range(3)]
+        for k in range(3):
+            assert same_bits(got[k], ref[k]).all(), f"plane {k}"
+        st = ctx.cull_stats()
+        assert st["grids"] >= 1 and 0 < st["bytes"] <= st["budget"]
+        fb.destroy()
+        h.destroy()
+        # (2) a new scene every frame, samples in flight as a live host runs them
+        ctx.set_cull_min_pixels(0)
+        built0 = ctx.cull_stats()["built"]
+        for frame in range(12):
+            t = _smooth_sphere_table(rng, 64, one_k=frame % 3 != 2) if frame else S.csg64()
+            sch = J.make_schema(t, 384, 256, counts=(128,), render_mode="full", position=(0.0, 0.0, -5.0) if frame == 0 else (0.3, 0.2, -6.0), lights=GC.LIGHT)
+            n1 = GC.halton_pairs(1)
+            want = render_gpu(ctx, t, sch, n1, FAST | MK | NC)
+            got = render_gpu(ctx, t, sch, n1, FAST)
+            for k in range(3):
+                assert same_bits(got[k], want[k]).all(), f"frame {frame}, plane {k}"
+        st = ctx.cull_stats()
+        assert st["built"] - built0 == 12 and st["bytes"] <= st["budget"] and st["grids"] <= 1  # (render_gpu destroys its scene: its grid went back to the pool)
+    finally:
+        ctx.set_cull_min_pixels(0)
+
+
 def test_fast_build_tolerance_is_anchored_to_the_spread_between_glsl_legal_arithmetics(ctx):
     """Headline frame (3840x2160, full, [256], the light), 4 samples per pixel, same random stream in all three renders:
     fast against strict, and GL-stack strict against default strict.  For the whole frame, for the pixels that show the

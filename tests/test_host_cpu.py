@@ -442,6 +442,68 @@ def test_render_job_host_replays_the_reference_loop_call_by_call():
         compare_host_events(k, schema, events, want)
 
 
+def test_a_suspended_job_keeps_its_scene_through_the_cache_eviction():
+    """The scene cache of a context holds 64 scenes, least recently used out first (job.SCENE_CACHE_ENTRIES) -- but a job yields
+    between samples, and the scenes other jobs bring in meanwhile must not destroy the one it still renders (round 4 did: the
+    next render of the suspended job then passed a destroyed handle).  do_render_job pins its scene while its generator lives;
+    the pin goes with the generator, finished or closed."""
+    from raymarching_engine_amd import job as J, scene as S
+
+    destroyed, drawn = [], []
+
+    class Handle:
+        def __init__(self, name): self.name = name
+        def destroy(self): destroyed.append(self.name)
+
+    class FakeFb:
+        def destroy(self): pass
+
+    class FakeNative:
+        def create_scene(self, scene): return Handle(scene.radius)
+        def create_framebuffer(self, w, h, *a): return FakeFb()
+        def sync(self): pass
+        def render_sample(self, handle, fb, u, tile, flags):
+            assert handle.name not in destroyed, "a destroyed scene handle reached the library"
+            drawn.append(handle.name)
+
+    class Ctx(J.RenderJobContext):
+        def __init__(self):
+            self.native, self.flags, self.rows, self.stripes, self.group, self.stream = FakeNative(), 0, None, None, None, None
+            from collections import OrderedDict
+            self._scenes, self._pins, self._live, self._purgatory = OrderedDict(), {}, {}, []
+
+    # distinct scenes: spheres of different radii (scene_key hashes the description)
+    def sphere(radius):
+        t = S.CsgScene(); t.sphere((0.0, 0.0, 0.0), float(radius)); t.radius = radius
+        return t
+
+    ctx = Ctx()
+    schema = J.make_schema(sphere(1.0), 16, 16, counts=(8,), render_mode="preview", samples_per_pixel=3)
+    gen = J.do_render_job(schema, ctx)(lambda *a: None)
+    next(gen)  # the job's first present: the generator is suspended with its scene pinned
+    for i in range(J.SCENE_CACHE_ENTRIES + 8):  # other jobs bring in more scenes than the cache holds
+        ctx.get_scene(sphere(2.0 + i))
+    assert 1.0 not in destroyed and len(destroyed) == 9 and len(ctx._scenes) == J.SCENE_CACHE_ENTRIES  # the oldest UNPINNED ones went
+    result = J.drain(gen)
+    assert result == {"success": True} and drawn == [1.0, 1.0, 1.0]
+    assert not ctx._pins and 1.0 not in destroyed
+    ctx.get_scene(sphere(999.0))  # unpinned, it is the oldest entry: the next scene pushes it out
+    assert destroyed[-1] == 1.0 and len(ctx._scenes) == J.SCENE_CACHE_ENTRIES
+    # a generator that is closed mid-job lets go of its pin too
+    gen = J.do_render_job(J.make_schema(sphere(1.5), 16, 16, counts=(8,), render_mode="preview", samples_per_pixel=3), ctx)(lambda *a: None)
+    next(gen)
+    assert len(ctx._pins) == 1
+    gen.close()
+    assert not ctx._pins
+    # a failing render is the job's value, not an exception out of the generator (errors are values: RenderJobExecutor.tsx:56-68)
+    from raymarching_engine_amd import native as N
+
+    def boom(*a): raise N.RmError(3, "device lost")
+    ctx.native.render_sample = boom
+    out = J.drain(J.do_render_job(J.make_schema(sphere(1.25), 16, 16, counts=(8,), render_mode="preview", samples_per_pixel=2), ctx)(lambda *a: None))
+    assert out["success"] is False and "device lost" in out["why"]["infoLog"] and not ctx._pins
+
+
 def compare_host_events(k, schema, events, want):
     """events: ("present", n) | ("yield", 1) | ("draw", (x, y, w, h), bytes of RmUniforms) | ("fboDelete", (w, h, id)) | ("done", value)
     against the reference's recorded events of the same job (tests/golden/host_reference.json.gz)."""

@@ -57,6 +57,8 @@ class OracleFb:
 class OracleNative:
     """the methods of native.Context the sharded job uses, on host memory"""
 
+    takes_host_pointers = True  # (dist.ShardedFramebuffer refuses to hand a real context the host memory of a CPU group)
+
     def __init__(self, O, shard):
         self.O, self.shard = O, shard
         self.scenes = {}

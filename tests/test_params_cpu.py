@@ -133,3 +133,37 @@ def test_reference_examples_map_to_their_kinds():
         assert type(sc) is cls and sc.params()[: len(head)] == head, name
     assert P.scene_from_example((ex / "smooth-tree.glsl").read_text()).smoothen is True
     assert tuple(P.scene_from_example((ex / "guide.glsl").read_text()).material.diffuse) == (0.5, 0.5, 0.5)
+
+
+def test_scanner_equals_the_transliteration_on_random_texts():
+    """The product's scanner (a lexer with comment modes + a table builder, raymarching-engine_amd/params.py) against the
+    statement-for-statement restatement of the reference's loop kept as a checker (oracle/ts/params_transliteration.py, itself
+    pinned to the reference's recorded outputs by the fixture above): 4 000 texts thrown together from the pieces the scanner
+    cares about -- comment delimiters in every order, annotations with quoted, unquoted, empty, numeric and broken values,
+    `uniform` with and without declarations, stray `=` and `@`, line breaks, non-ASCII spaces."""
+    import random
+
+    from oracle.ts import params_transliteration as T
+
+    pieces = ["uniform ", "uniform", " float a", " vec3 bee", " ivec2 c_1", " uint u", " uvec4 w", " mat3 m", ";", "\n", " ", "\t", "//", "/*", "*/", "/", "*",
+              "@min=", "@max=", "@step=", "@sensitivity=", "@default=", "@name=", "@tooltip=", "@format=", "@scale=", "@bogus=", "@", "=", '"', "'",
+              "1", "2.5", "-3e2", "0x1F", "abc", "1,2,3", "0.5,0.25", "color", "numerical/color", "position/what", "log", "linear", "Infinity", ".5", "1*/", '"a b"',
+              '"x\ny"', "\u00a0", "\u2028", "float", "uniformity", " = ", ",", "@min =  7 ", "@default = \"1, 2\"", "float x float y"]
+    rnd = random.Random(20261004)
+    for it in range(4000):
+        text = "".join(rnd.choice(pieces) for _ in range(rnd.randint(1, 40)))
+        a, b = P.get_custom_shader_params(text), T.get_custom_shader_params(text)
+        assert [_norm(e) for e in a] == [_norm(e) for e in b], repr(text)
+
+
+def test_lexer_modes():
+    """tokens(): the comment delimiters are units in every mode, annotations exist in comments only, declarations behind a
+    `uniform` only."""
+    kinds = lambda text: [(t.kind, t.a, t.b) for t in P.tokens(text)]
+    assert kinds("uniform float a; // @min=1") == [("uniform", "", ""), ("declaration", "float", "a"), ("annotation", "min", "1")]
+    assert kinds("@min=1 float a;") == []  # neither in code
+    assert kinds("/* uniform float a */") == []  # a keyword in a comment is text
+    assert kinds("/* @min=1*/ uniform float a") == [("annotation", "min", "1*/")]  # the value swallowed the comment's end: what follows is still comment
+    assert kinds("// @name=\"two\nlines\" @max=2\nuniform int n") == [("annotation", "name", '"two\nlines"'), ("annotation", "max", "2"), ("uniform", "", ""), ("declaration", "int", "n")]
+    assert kinds("uniform /* c */ vec2 v") == [("uniform", "", ""), ("declaration", "vec2", "v")]  # a comment between keyword and declaration
+    assert kinds("/* a *// @min=1") == []  # `*/` taken whole: one slash is left, not a line comment

@@ -9,6 +9,7 @@ can price a striped shard by the rows it holds.
 
     python tools/count_flops.py c3b --stride 1        # the headline frame, every row (about 10 min on 8 cores)
     python tools/count_flops.py c4 --stride 64
+    python tools/count_flops.py c3b --stride 1 --pruned   # ... of the PRUNED algorithm (entry c3b_pruned): bench.py's frac_useful
 
 Runs in the build container or anywhere else: it needs only the oracle (CPU).
 """
@@ -29,6 +30,7 @@ def main():
     ap.add_argument("workload")
     ap.add_argument("--stride", type=int, default=16)
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--pruned", action="store_true", help="do not count a march's steps behind its bitwise fixed point: the entry <workload>_pruned, the numerator of bench.py's frac_useful")
     args = ap.parse_args()
 
     import bench
@@ -37,6 +39,7 @@ def main():
 
     O.build()
     O.set_tan_mode(O.TAN_PORTABLE)
+    O.set_count_pruned(args.pruned)
     wl, sc, schema = bench.make_workload(args.workload)
     W, H = wl["width"], wl["height"]
     u = J.uniforms_from_schema(schema, (0.5, 1.0 / 3.0))
@@ -63,10 +66,12 @@ def main():
         "convention": "SURVEY.md 8(d): add/sub/mul/min/max/abs/compare/select 1, fma 2, transcendental or division 1, pow 2",
         "sample": "randNoise (1/2, 1/3), oracle/rm_oracle.c -DOR_COUNT_FLOPS, portable tangent", "seconds": round(time.time() - t0, 1),
     }
+    if args.pruned:
+        entry["pruned"] = "steps behind a march's bitwise fixed point are not counted (or_set_count_pruned): the arithmetic the marches need"
     data = {}
     if os.path.exists(OUT):
         data = json.load(open(OUT))
-    data[args.workload] = entry
+    data[args.workload + ("_pruned" if args.pruned else "")] = entry
     json.dump(data, open(OUT, "w"), indent=0)
     print(f"{args.workload}: {entry['flops_per_pixel_sample']:.1f} flop per pixel-sample over {len(rows)} rows (stride {args.stride})")
 
