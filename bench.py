@@ -217,7 +217,7 @@ def main():
     ap.add_argument("--stripe-of", type=int, default=0, help="one GPU standing in for rank 0 of an N-way split: render its 8-row stripes of the frame (no collective)")
     ap.add_argument("--strict", action="store_true", help="parity build instead of the fast build")
     ap.add_argument("--megakernel", action="store_true", help="force the one-thread-one-pixel kernel (default: the library picks per job)")
-    ap.add_argument("--wavefront", action="store_true", help="force the wavefront pipeline")
+    ap.add_argument("--wavefront", action="store_true", help="the wavefront pipeline (the tests' second implementation: loads tests/_xcheck/libhip_raymarch_xcheck.so instead of the product library)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap-leg", action="store_true",
                     help="also time the same K steps with 3 samples in flight on this one GPU (reported as `overlap`, never as `value`)")
@@ -239,6 +239,9 @@ def main():
                     help="sharded runs: after the timed legs rank 0 renders the same samples on ONE framebuffer, presents it and compares "
                          "the bytes with the frame it assembled from the gathered rows (reported as `frame_check`)")
     args = ap.parse_args()
+    if args.wavefront and not os.environ.get("RM_LIB"):
+        # the wavefront pipeline is not in the product library (round 5): it is timed from the tests' cross-check build of the same sources
+        os.environ["RM_LIB"] = os.path.join(ROOT, "tests", "_xcheck", "libhip_raymarch_xcheck.so")
 
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")

@@ -211,12 +211,13 @@ enum {
   RM_RENDER_FAST = 1,        /* hardware-rate math in the distance evaluations; same image statistics, not the same bits */
   RM_RENDER_COLOR_ONLY = 2,  /* do not read/write the two G-buffer planes (benchmark "single colour frame" mode) */
   RM_RENDER_MEGAKERNEL = 4,  /* force the one-thread-one-pixel kernel (whole main() per thread) */
-  RM_RENDER_WAVEFRONT = 16,  /* ask for the wavefront pipeline (ray-compacting persistent march) -- a REQUEST: a table whose shapes
-                                name surfaces (RmSurface) always takes the pixel kernel, the pipeline has no per-shape materials;
-                                rm_ctx_last_pipeline tells which implementation a call ran.  With neither flag the
-                                library takes the single kernel: since round 4 it is the faster one for every measured job
-                                in both builds (rm_api.hip prefer_wavefront has the table).  Same results either way. */
-  RM_RENDER_NO_COST_CLASSES = 8, /* wavefront march in one pass even for scene kinds whose sdf cost depends on the
+  RM_RENDER_WAVEFRONT = 16,  /* NOT in this library since round 5 (RM_ERR_INVALID): the wavefront pipeline -- the same per-pixel program cut
+                                at its marches into queue-driven stages -- is the tests' second implementation and is compiled into
+                                their cross-check build of these sources only (tests/_xcheck/libhip_raymarch_xcheck.so, -DRM_WITH_WAVEFRONT=1;
+                                rm_api.hip says why).  There the flag is a request: tables with surfaces or kind rows take the pixel
+                                kernel whatever is asked (rm_ctx_last_pipeline tells).  The product's own cross-check of its exact
+                                shortcuts is the stepwise march: RM_RENDER_NO_FAR_JUMP | RM_RENDER_NO_CULL (same bits). */
+  RM_RENDER_NO_COST_CLASSES = 8, /* (cross-check build) wavefront march in one pass even for scene kinds whose sdf cost depends on the
                                    point (Mandelbulb); a measurement switch, same results */
   RM_RENDER_NO_OVERLAP = 32, /* this sample runs alone on the context's stream and blends in its own kernel (see
                                 rm_ctx_set_samples_in_flight); for timing one launch.  Same results. */

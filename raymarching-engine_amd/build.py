@@ -65,6 +65,17 @@ def build_native(force: bool = False, verbose: bool = False, extra=(), out: Path
     return lib
 
 
+# The tests' second implementation of the per-pixel program -- the wavefront pipeline (csrc/rm_wavefront.inc: the same program cut
+# at its marches into queue-driven stages) -- is not in the product library: the same sources with -DRM_WITH_WAVEFRONT=1 make
+# tests/_xcheck/libhip_raymarch_xcheck.so, which only tests/ (and the tools that time both implementations) load.
+XCHECK_LIB = HERE.parent / "tests" / "_xcheck" / "libhip_raymarch_xcheck.so"
+
+
+def build_crosscheck(force: bool = False, verbose: bool = False) -> Path:
+    XCHECK_LIB.parent.mkdir(parents=True, exist_ok=True)
+    return build_native(force=force, verbose=verbose, extra=("-DRM_WITH_WAVEFRONT=1",), out=XCHECK_LIB, tag="_xcheck")
+
+
 def build_node_addon(force: bool = False) -> Path:
     """The N-API addon of the JS host (js/rm_napi.cc), against the system Node headers."""
     src, out = HERE / "js" / "rm_napi.cc", HERE / "js" / "rm_napi.node"
@@ -80,4 +91,5 @@ def build_node_addon(force: bool = False) -> Path:
 
 if __name__ == "__main__":
     print(build_native(force="--force" in sys.argv, verbose=True))
+    print(build_crosscheck(force="--force" in sys.argv, verbose=True))
     print(build_node_addon(force="--force" in sys.argv))

@@ -19,6 +19,10 @@
 #include "../../include/hip_raymarch.h"
 #include "rm_params.hpp"
 
+#ifndef RM_WITH_WAVEFRONT
+#define RM_WITH_WAVEFRONT 0  // 1: the tests' cross-check build (see "the wavefront pipeline" below)
+#endif
+
 #define RM_SP_MAX 8
 
 // rm_glstack.hip: the parity build in the GL stack's arithmetic, behind C entry points (its types live in another namespace)
@@ -121,9 +125,13 @@ struct rm_ctx {
   size_t cull_budget = 0, cull_bytes = 0;
   unsigned long long cull_built = 0, use_clock = 0;
   std::vector<rm_scene*> cull_scenes;
-  struct CullBuffer { unsigned long long* p; size_t bytes; };
+  struct CullBuffer { unsigned long long* p; size_t bytes; bool idle; };  // idle: nothing enqueued anywhere still reads it
   std::vector<CullBuffer> cull_pool;
-  hipEvent_t cull_event = nullptr;  // behind the last build on the context's stream: what the side streams' renders wait for
+  // builds run on a stream of their own, NOT behind the context's: a new scene's grid is then built while the previous frame still
+  // renders, and the new frame's render -- which waits for cull_event, on whichever stream it runs -- overlaps that frame's tail as
+  // it would without a build (on the context's stream the build sat behind the previous frame's blend, i.e. behind its render)
+  hipStream_t cull_stream = nullptr;
+  hipEvent_t cull_event = nullptr, cull_order = nullptr;
   std::string error;
   std::string warning;  // rm_ctx_last_warning: advice that came with a call that SUCCEEDED (never an error)
 };
@@ -275,8 +283,10 @@ void rm_ctx_destroy(rm_ctx* ctx) {
   if (ctx->shard_snap) (void)hipEventDestroy(ctx->shard_snap);
   if (ctx->shard_done) (void)hipEventDestroy(ctx->shard_done);
   if (ctx->shard_ev) (void)hipEventDestroy(ctx->shard_ev);
+  if (ctx->cull_stream) { (void)hipStreamSynchronize(ctx->cull_stream); (void)hipStreamDestroy(ctx->cull_stream); }
   for (auto& b : ctx->cull_pool) (void)hipFree(b.p);
   if (ctx->cull_event) (void)hipEventDestroy(ctx->cull_event);
+  if (ctx->cull_order) (void)hipEventDestroy(ctx->cull_order);
   for (auto& b : ctx->buffers) (void)hipFree(b.first);  // rm_buffer_create'd memory the host did not destroy
   if (ctx->switch_ev) (void)hipEventDestroy(ctx->switch_ev);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -712,14 +722,14 @@ int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out) {
   return RM_OK;
 }
 
-static void cull_release(rm_ctx* ctx, rm_scene* s);
+static void cull_release(rm_ctx* ctx, rm_scene* s, bool idle);
 void rm_scene_destroy(rm_scene* scene) {
   if (!scene) return;
   (void)hipSetDevice(scene->ctx->device);
   (void)hipStreamSynchronize(scene->ctx->stream);
   if (scene->d_prims) (void)hipFree(scene->d_prims);
   if (scene->d_surfaces) (void)hipFree(scene->d_surfaces);
-  cull_release(scene->ctx, scene);  // (to the context's pool: the next scene's grid is usually the same size)
+  cull_release(scene->ctx, scene, true);  // (to the context's pool: the next scene's grid is usually the same size; the stream has been waited for above)
   delete scene;
 }
 
@@ -923,15 +933,15 @@ int rm_buffer_upload(rm_ctx* ctx, void* device_ptr, const void* host, size_t byt
 // The culling grid of a scene that has one coming (rm_scene_create), before a call that reads it (either build; not the GL stack's
 // arithmetic).  Round 5: built once the scene has been asked for ctx->cull_min_pixels pixel-samples (until then it renders without
 // one: the same bits, and a host that shows a new scene every frame at a small size never pays for a grid it would not earn back);
-// the build kernel is enqueued on the context's stream in front of the render that triggered it -- no wait on the host -- into a
+// the build kernel is enqueued on a stream of its own, the render that triggered it waits for it on the device -- no wait on the host -- into a
 // buffer recycled from the context's pool; the grids of a context stay within its budget, the least recently used scene giving its
 // grid up first.  Running out of memory is not an error (the fold of every row gives the same bits); any other failure is.
-static void cull_release(rm_ctx* ctx, rm_scene* s) {  // the scene's grid back to the pool (the caller has ordered the stream)
+static void cull_release(rm_ctx* ctx, rm_scene* s, bool idle) {  // the scene's grid back to the pool; idle: the caller has waited for the renders that read it
   if (!s->d_cull) return;
   size_t pooled = 0;
   for (auto& b : ctx->cull_pool) pooled += b.bytes;
-  if (ctx->cull_pool.size() < 4 && pooled + s->cull_bytes <= ctx->cull_budget / 2) ctx->cull_pool.push_back({s->d_cull, s->cull_bytes});
-  else (void)hipFree(s->d_cull);
+  if (ctx->cull_pool.size() < 4 && pooled + s->cull_bytes <= ctx->cull_budget / 2) ctx->cull_pool.push_back({s->d_cull, s->cull_bytes, idle});
+  else (void)hipFree(s->d_cull);  // (waits for the device)
   ctx->cull_bytes -= s->cull_bytes;
   for (size_t i = 0; i < ctx->cull_scenes.size(); i++)
     if (ctx->cull_scenes[i] == s) { ctx->cull_scenes.erase(ctx->cull_scenes.begin() + (long)i); break; }
@@ -955,13 +965,14 @@ static int scene_cull_grid(rm_ctx* ctx, rm_scene* s, int flags, long long pixels
     rm_scene* victim = ctx->cull_scenes[0];                                            // reading it is ahead of the next build on this stream)
     for (rm_scene* c : ctx->cull_scenes)
       if (c->last_use < victim->last_use) victim = c;
-    cull_release(ctx, victim);
+    cull_release(ctx, victim, false);
     victim->cull_wanted = true;  // ... and may earn it back
     victim->px_seen = 0;
   }
   unsigned long long* cells = nullptr;
+  bool idle = true;
   for (size_t i = 0; i < ctx->cull_pool.size(); i++)
-    if (ctx->cull_pool[i].bytes == bytes) { cells = ctx->cull_pool[i].p; ctx->cull_pool.erase(ctx->cull_pool.begin() + (long)i); break; }
+    if (ctx->cull_pool[i].bytes == bytes) { cells = ctx->cull_pool[i].p; idle = ctx->cull_pool[i].idle; ctx->cull_pool.erase(ctx->cull_pool.begin() + (long)i); break; }
   if (!cells) {
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&cells), bytes);
     if (e == hipErrorOutOfMemory) {  // give the pool back and try once more
@@ -975,9 +986,17 @@ static int scene_cull_grid(rm_ctx* ctx, rm_scene* s, int flags, long long pixels
   }
   build.prims = s->d_prims;
   build.cells = cells;
-  hipError_t e = rm::launch_cull_build(build, ctx->stream);
+  hipError_t e = hipSuccess;
+  if (!ctx->cull_stream) e = hipStreamCreateWithFlags(&ctx->cull_stream, hipStreamNonBlocking);
   if (e == hipSuccess && !ctx->cull_event) e = hipEventCreateWithFlags(&ctx->cull_event, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventRecord(ctx->cull_event, ctx->stream);
+  if (e == hipSuccess && !ctx->cull_order) e = hipEventCreateWithFlags(&ctx->cull_order, hipEventDisableTiming);
+  if (e == hipSuccess && !idle) {  // a grid given up for the budget's sake: renders enqueued before now may still read it -- every one of them is
+    e = hipEventRecord(ctx->cull_order, ctx->stream);  // followed by its blend on the context's stream, so behind this point they are done
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->cull_stream, ctx->cull_order, 0);
+  }
+  if (e == hipSuccess) e = rm::launch_cull_build(build, ctx->cull_stream);
+  if (e == hipSuccess) e = hipEventRecord(ctx->cull_event, ctx->cull_stream);
+  if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->cull_event, 0);  // what runs on the context's own stream; the side streams wait where they launch
   if (e != hipSuccess) {
     (void)hipFree(cells);
     return fail(ctx, RM_ERR_DEVICE, std::string("culling grid: ") + hipGetErrorString(e));
@@ -1015,6 +1034,9 @@ static int build_params(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniform
   if (!ctx || !scene || !fb || !u) return fail(ctx, RM_ERR_INVALID, "render: NULL argument");
   if (scene->ctx != ctx || fb->ctx != ctx) return fail(ctx, RM_ERR_INVALID, "render: scene/framebuffer belong to another context");
   if (u->renderMode != 0 && u->renderMode != 1) return fail(ctx, RM_ERR_INVALID, "render: renderMode must be 0 (full) or 1 (preview)");
+  if (!RM_WITH_WAVEFRONT && (flags & RM_RENDER_WAVEFRONT))
+    return fail(ctx, RM_ERR_INVALID, "render: RM_RENDER_WAVEFRONT -- this library is built without the wavefront pipeline (it is the tests' second implementation: "
+                                     "tests/_xcheck/libhip_raymarch_xcheck.so); the product's own cross-check is RM_RENDER_NO_FAR_JUMP | RM_RENDER_NO_CULL");
   if (!(u->reflections >= 0.0f && u->reflections <= (float)RM_MAX_BOUNCES)) return fail(ctx, RM_ERR_INVALID, "render: reflections must be in 0..10 (raymarchingStepCountsArray[10])");
   if (u->lightCount < 0 || u->lightCount > RM_MAX_LIGHTS) return fail(ctx, RM_ERR_INVALID, "render: lightCount must be in 0..10");
   // `for (float i = 0.; i < steps; i++)` (raymarcher.frag:165, :210) never ends once i stops growing at 2^24
@@ -1062,6 +1084,14 @@ static int build_params(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniform
 
 #define RM_BATCH_TARGET_TILES 16384ll  // workgroups a batch launch of rm_render_samples aims for
 
+// ---- the wavefront pipeline (rm_wavefront.inc): compiled into the tests' CROSS-CHECK build only (round 5) ---------------------------
+// The same per-pixel program cut at its marches into queue-driven stages.  Rounds 1-3 the library picked it for some jobs; since round
+// 4 the pixel kernel is the faster one for every measured job in both builds, and it alone grew per-shape surfaces, kind rows and
+// the GL stack's arithmetic.  It stays what it is good for -- a second implementation of the marches, bounces and lights that the
+// tests hold the pixel kernel to, bit for bit -- in tests/_xcheck/libhip_raymarch_xcheck.so (build.py build_crosscheck,
+// -DRM_WITH_WAVEFRONT=1); libhip_raymarch.so, the product, has neither its kernels nor this orchestration, and refuses
+// RM_RENDER_WAVEFRONT.  The product's own cross-check is the stepwise march: RM_RENDER_NO_FAR_JUMP | RM_RENDER_NO_CULL.
+#if RM_WITH_WAVEFRONT
 #define RM_MAX_MARCHES (RM_MAX_BOUNCES * (1 + RM_MAX_LIGHTS))
 #define RM_COUNTERS_PER_MARCH 8  // queue heads and parked counts of the launches of one march
 
@@ -1224,6 +1254,8 @@ static hipError_t launch_wavefront(rm_ctx* ctx, const KParams& P, int flags) {
   return hipSuccess;
 }
 
+#endif  // RM_WITH_WAVEFRONT
+
 // Which implementation of the per-pixel program runs a job (same results either way).
 // Measured on MI355X (fast build, ms per sample, pixel kernel / wavefront pipeline).  Round 2:
 //   Mandelbulb 3840x2160 full      2.49 / 4.5         sphere 1080p preview 0.11 / 1.4
@@ -1249,6 +1281,7 @@ static bool prefer_wavefront(const KParams&, int) { return false; }
 // position-dependent materials (RM_TABLE_HAS_SURFACES): the pipeline's stages carry one material block per scene -- its light
 // stage has no scene table staged -- so such scenes render with the pixel kernel whatever the flags ask for (same results).
 static bool uses_wavefront(const rm_ctx* ctx, const KParams& P, int flags) {
+  if (!RM_WITH_WAVEFRONT) return false;  // the product library (build_params refuses the flag)
   if (ctx->gl_stack && !(flags & RM_RENDER_FAST)) return false;
   if (P.scene.table_flags & (RM_TABLE_HAS_SURFACES | RM_TABLE_HAS_KIND)) return false;
   return (flags & RM_RENDER_WAVEFRONT) ? true : (flags & RM_RENDER_MEGAKERNEL) ? false : prefer_wavefront(P, flags);
@@ -1420,7 +1453,9 @@ static hipError_t launch_pixels_ordered(rm_ctx* ctx, const KParams& P, int flags
 static hipError_t launch(rm_ctx* ctx, const KParams& P, int flags) {
   const bool wavefront = uses_wavefront(ctx, P, flags);
   ctx->last_pipeline = wavefront ? RM_PIPELINE_WAVEFRONT : RM_PIPELINE_PIXEL_KERNEL;
+#if RM_WITH_WAVEFRONT
   if (wavefront) return launch_wavefront(ctx, P, flags);
+#endif
   // full mode with at least one bounce: the kernel's only use of the planes is the final blend, which can be split off
   if (ctx->samples_in_flight > 1 && !(flags & RM_RENDER_NO_OVERLAP) && P.u.renderMode == 0 && P.u.reflections > 0.0f) {
     const hipError_t e = launch_pixels_in_flight(ctx, P, flags);

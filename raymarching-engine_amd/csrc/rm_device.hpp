@@ -539,6 +539,24 @@ struct Sdf<RM_SCENE_TABLE> {
         continue;
       }
       if (w == 0) u &= ~1ull;
+#ifndef RM_CULL_LOOP4
+#define RM_CULL_LOOP4 0  // 1 (measurement builds): four listed rows per trip, their LDS reads in flight together
+#endif
+#if RM_CULL_LOOP4
+      while (__builtin_popcountll(u) >= 4) {
+        const int j0 = 64 * w + __builtin_ctzll(u); u &= u - 1ull;
+        const int j1 = 64 * w + __builtin_ctzll(u); u &= u - 1ull;
+        const int j2 = 64 * w + __builtin_ctzll(u); u &= u - 1ull;
+        const int j3 = 64 * w + __builtin_ctzll(u); u &= u - 1ull;
+        const float4 r0 = rows[j0], r1 = rows[j1], r2 = rows[j2], r3 = rows[j3];
+        const float d0 = sphere_row1(r0, p), d1 = sphere_row1(r1, p);
+        d = smooth_row(d, d0, k, half_inv_k);
+        d = smooth_row(d, d1, k, half_inv_k);
+        const float d2 = sphere_row1(r2, p), d3 = sphere_row1(r3, p);
+        d = smooth_row(d, d2, k, half_inv_k);
+        d = smooth_row(d, d3, k, half_inv_k);
+      }
+#endif
       while (u != 0ull) {
         const int j0 = 64 * w + __builtin_ctzll(u);
         u &= u - 1ull;
@@ -619,12 +637,19 @@ struct Sdf<RM_SCENE_TABLE> {
   // still has a row outside it (lanes of a wave sit in the same or in neighbouring cells); 0 when that does not cover the wave (the
   // word that holds row 0 is never 0 otherwise)
 #ifndef RM_CULL_UNION_ROUNDS
-#define RM_CULL_UNION_ROUNDS 3
+#define RM_CULL_UNION_ROUNDS 8  // (round 5: C4 9.35 -> 9.08 ms, C5 141.1 -> 140.0; 16 and an unbounded loop gain no more; rounds 3-4: 3)
 #endif
   static RM_DEV unsigned long long wave_union(unsigned long long mine) {
     const unsigned int lo = (unsigned int)mine, hi = (unsigned int)(mine >> 32);
     unsigned long long u = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)hi) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)lo);
+#ifndef RM_CULL_UNION_LOOP
+#define RM_CULL_UNION_LOOP 0  // 1 (measurement builds): the rounds as a loop, not unrolled
+#endif
+#if RM_CULL_UNION_LOOP
+#pragma unroll 1
+#else
 #pragma unroll
+#endif
     for (int it = 0; it < RM_CULL_UNION_ROUNDS; it++) {
       const unsigned long long more = ballot((mine & ~u) != 0ull);
       if (more == 0ull) return u;

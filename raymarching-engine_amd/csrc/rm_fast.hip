@@ -5,7 +5,13 @@
 #include <type_traits>
 #include "rm_device.hpp"
 #include "rm_kernels.inc"
+#include "rm_frame_kernels.inc"
+#ifndef RM_WITH_WAVEFRONT
+#define RM_WITH_WAVEFRONT 0  // 1: the tests' cross-check build (rm_api.hip "the wavefront pipeline")
+#endif
+#if RM_WITH_WAVEFRONT
 #include "rm_wavefront.inc"
+#endif
 
 #ifdef RM_LANE_STATS
 // diagnostic build only: Mandelbulb evaluations of this TU, {lane-rounds used, lane-rounds issued, lanes active, lanes issued}

@@ -10,7 +10,7 @@
 #include <type_traits>
 #include "rm_device.hpp"
 #include "rm_kernels.inc"
-#include "rm_wavefront.inc"
+#include "rm_frame_kernels.inc"
 #undef rm
 
 extern "C" {

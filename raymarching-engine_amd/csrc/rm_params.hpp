@@ -43,9 +43,27 @@ __host__ __device__ inline long long rm_cull_cells(int n, int n_outer, int level
 
 // the fp32 allowance of the culling tests: n + 8 roundings at the magnitude of the coordinates involved
 __host__ __device__ inline double rm_cull_margin(int nprims, double magnitude) { return 1e-4 + 1.2e-7 * (nprims + 8) * magnitude; }
-__host__ __device__ inline double rm_cull_shape_distance(const RmPrim& p, const double* c) {
-  const double x = c[0] - p.center[0], y = c[1] - p.center[1], z = c[2] - p.center[2];
-  if ((p.type & 0xff) == RM_PRIM_SPHERE) return sqrt(x * x + y * y + z * z) - p.size[0];
+// a shape row as the rule reads it: the table's floats widened once, and what the rule derives from them per row and not per cell
+// (round 5: the build kernel stages these in LDS once per workgroup; rounds 3-4 read the 32-byte RmPrim from memory and divided
+// by k twice, per row AND cell)
+struct CullRow {
+  double c[3], size[3], k, half_inv_k;
+  double reach;  // a box's half-diagonal (0 for a sphere): how far its nearest point can be from its centre
+  int shape, op;
+};
+__host__ __device__ inline CullRow rm_cull_row(const RmPrim& p) {
+  CullRow r;
+  for (int a = 0; a < 3; a++) { r.c[a] = p.center[a]; r.size[a] = p.size[a]; }
+  r.k = (double)p.k;
+  r.half_inv_k = 0.5 / r.k;  // (Inf for k = 0: only read for smooth unions, whose k > 0)
+  r.shape = p.type & 0xff;
+  r.op = (p.type >> 8) & 0xff;
+  r.reach = r.shape == RM_PRIM_SPHERE ? 0.0 : sqrt(r.size[0] * r.size[0] + r.size[1] * r.size[1] + r.size[2] * r.size[2]);
+  return r;
+}
+__host__ __device__ inline double rm_cull_shape_distance(const CullRow& p, const double* c) {
+  const double x = c[0] - p.c[0], y = c[1] - p.c[1], z = c[2] - p.c[2];
+  if (p.shape == RM_PRIM_SPHERE) return sqrt(x * x + y * y + z * z) - p.size[0];
   const double qx = fabs(x) - p.size[0], qy = fabs(y) - p.size[1], qz = fabs(z) - p.size[2];  // sdBox, raymarcher.frag:108-112
   const double ox = fmax(qx, 0.0), oy = fmax(qy, 0.0), oz = fmax(qz, 0.0);
   return sqrt(ox * ox + oy * oy + oz * oz) + fmin(fmax(qx, fmax(qy, qz)), 0.0);
@@ -79,8 +97,8 @@ __host__ __device__ inline double rm_cull_shape_distance(const RmPrim& p, const 
 // the exponent of a positive, finite, normal double, read off its exponent field (round 5; rounds 3-4 called the library's
 // logarithm -- three times per row and cell, most of the build kernel's 8.9 ms on CSG-64's grid)
 __host__ __device__ inline int rm_exponent(double v) { return ilogb(v); }
-__host__ __device__ inline double rm_smooth_min(double a, double b, double k) {  // examples/smooth-tree.glsl:20-22, in double
-  double h = 0.5 + 0.5 * (b - a) / k;
+__host__ __device__ inline double rm_smooth_min(double a, double b, double k, double half_inv_k) {  // examples/smooth-tree.glsl:20-22, in double (0.5 / k given)
+  double h = 0.5 + (b - a) * half_inv_k;
   h = h < 0.0 ? 0.0 : (h > 1.0 ? 1.0 : h);
   return b + h * (a - b) - k * h * (1.0 - h);
 }
@@ -91,7 +109,7 @@ __host__ __device__ inline bool rm_cull_mostly_smooth(const RmPrim* prims, int n
   return 2 * smooth > nprims;
 }
 
-__host__ __device__ inline void rm_cull_cell(const RmPrim* prims, int nprims, int words, const double* c, double rad, double margin, unsigned long long* out) {
+__host__ __device__ inline void rm_cull_cell_rows(const CullRow* prims, int nprims, int words, const double* c, double rad, double margin, unsigned long long* out) {
   const int NONE = -100000;
   for (int w = 0; w < words; w++) out[w] = 0ull;
   const double d0 = rm_cull_shape_distance(prims[0], c);
@@ -101,12 +119,12 @@ __host__ __device__ inline void rm_cull_cell(const RmPrim* prims, int nprims, in
   int B = NONE;  // the running value is certainly a multiple of 2^(B - 23)
   out[0] |= 1ull;
   for (int i = 1; i < nprims; i++) {
-    const RmPrim p = prims[i];
-    const int op = (p.type >> 8) & 0xff;
+    const CullRow& p = prims[i];
+    const int op = p.op;
     const double di = rm_cull_shape_distance(p, c), lo_i = di - rad, hi_i = di + rad;
     bool keep;
     if (op == RM_OP_SMOOTH_UNION) {
-      const double k = (double)p.k;  // > 0 (rm_scene_create)
+      const double k = p.k;  // > 0 (rm_scene_create)
       keep = true;
       if (!(lo_i - U >= 1.002 * k + 2.0 * margin)) {
         B = NONE;  // possibly near: whatever grid d was on, it leaves it
@@ -125,21 +143,20 @@ __host__ __device__ inline void rm_cull_cell(const RmPrim* prims, int nprims, in
           B = g != NONE && big * (1.0 + 1e-5) < ldexp(1.0, g + 1) ? g : NONE;  // the grid this row leaves d on, when d' = dm - t is exact
         }
       }
-      const double u_smooth = rm_smooth_min(U, hi_i, k) + margin;
+      const double u_smooth = rm_smooth_min(U, hi_i, k, p.half_inv_k) + margin;
       U = fmin(fmin(U, hi_i), u_smooth);
-      L = rm_smooth_min(L, lo_i, k) - margin;  // (at most k / 4 below the minimum)
+      L = rm_smooth_min(L, lo_i, k, p.half_inv_k) - margin;  // (at most k / 4 below the minimum)
       if (best < 0 || di < best_d) { best = i; best_d = di; }
     } else if (op == RM_OP_UNION) {
       const double k = 0.0;
       keep = !(lo_i >= U + margin);
       if (keep && best >= 0) {
-        const RmPrim q = prims[best];
-        const double sx = (double)p.center[0] - q.center[0], sy = (double)p.center[1] - q.center[1], sz = (double)p.center[2] - q.center[2];
+        const CullRow& q = prims[best];
+        const double sx = p.c[0] - q.c[0], sy = p.c[1] - q.c[1], sz = p.c[2] - q.c[2];
         // the point the gradient of a shape's distance points away from: a sphere's centre; the nearest point of a box (within its
         // half-diagonal of the centre, at the distance itself -- which has to be positive over the ball)
-        const bool ps = (p.type & 0xff) == RM_PRIM_SPHERE, qs = (q.type & 0xff) == RM_PRIM_SPHERE;
-        const double pe = ps ? 0.0 : sqrt((double)p.size[0] * p.size[0] + (double)p.size[1] * p.size[1] + (double)p.size[2] * p.size[2]);
-        const double qe = qs ? 0.0 : sqrt((double)q.size[0] * q.size[0] + (double)q.size[1] * q.size[1] + (double)q.size[2] * q.size[2]);
+        const bool ps = p.shape == RM_PRIM_SPHERE, qs = q.shape == RM_PRIM_SPHERE;
+        const double pe = p.reach, qe = q.reach;
         const double s = sqrt(sx * sx + sy * sy + sz * sz) + pe + qe;
         const double a = (ps ? di + p.size[0] : di) - rad, b = (qs ? best_d + q.size[0] : best_d) - rad;
         if (a > 0.0 && b > 0.0) {
@@ -164,6 +181,13 @@ __host__ __device__ inline void rm_cull_cell(const RmPrim* prims, int nprims, in
     }
     if (keep) out[i >> 6] |= 1ull << (i & 63);
   }
+}
+
+// ... from the table's own rows (the host's rm_debug_cull_cell; at most RM_MAX_PRIMS of them)
+__host__ __device__ inline void rm_cull_cell(const RmPrim* prims, int nprims, int words, const double* c, double rad, double margin, unsigned long long* out) {
+  CullRow rows[RM_MAX_PRIMS];
+  for (int i = 0; i < nprims; i++) rows[i] = rm_cull_row(prims[i]);
+  rm_cull_cell_rows(rows, nprims, words, c, rad, margin, out);
 }
 
 struct DevScene {

@@ -59,6 +59,10 @@ class RmError(RuntimeError):
 
 
 _lib = None
+_libs: dict = {}
+# the tests' cross-check build of the same sources (build.py build_crosscheck): the library plus the wavefront pipeline.  NOT what a
+# host loads: Context(library=XCHECK_LIB_PATH) is for tests/ and the tools that time both implementations.
+XCHECK_LIB_PATH = Path(__file__).resolve().parent.parent / "tests" / "_xcheck" / "libhip_raymarch_xcheck.so"
 
 
 def _share_torch_hip_runtime():
@@ -88,16 +92,18 @@ def _share_torch_hip_runtime():
                 return
 
 
-def load_library():
-    """dlopen the HIP library (loading needs no GPU; creating a context does)."""
+def load_library(path=None):
+    """dlopen the HIP library (loading needs no GPU; creating a context does).  `path`: another build of the same library (the
+    tests' cross-check build); default = the product."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not LIB_PATH.exists():
-        raise RmError(abi.RM_ERR_DEVICE, f"{LIB_PATH} is missing: build it with `python raymarching-engine_amd/build.py` "
+    path = Path(path) if path is not None else LIB_PATH
+    if str(path) in _libs:
+        return _libs[str(path)]
+    if not path.exists():
+        raise RmError(abi.RM_ERR_DEVICE, f"{path} is missing: build it with `python raymarching-engine_amd/build.py` "
                                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
     _share_torch_hip_runtime()
-    lib = C.CDLL(str(LIB_PATH))
+    lib = C.CDLL(str(path))
     vp, fp, ip = C.c_void_p, C.POINTER(C.c_float), C.c_int
     sig = {
         "rm_abi_version": (ip, []),
@@ -159,7 +165,9 @@ def load_library():
             continue  # an experiment build of an older source tree (tools/): the debug entries are not part of what it measures
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    _lib = lib
+    _libs[str(path)] = lib
+    if path == LIB_PATH:
+        _lib = lib
     return lib
 
 
@@ -235,14 +243,15 @@ class DeviceBuffer:
 class Context:
     gl_stack_on = False
 
-    def __init__(self, device: int = 0):
-        self.lib = load_library()
+    def __init__(self, device: int = 0, library=None):
+        self.lib = load_library(library)
         h = C.c_void_p()
         rc = self.lib.rm_ctx_create(device, C.byref(h))
         if rc != abi.RM_OK:
             raise RmError(rc, self.lib.rm_last_error(None).decode())
         self.h = h
         self.device = device
+        self.settings = {}  # setter name -> arguments, as last called: what a second context needs to behave like this one (tests)
 
     def _check(self, rc: int):
         if rc != abi.RM_OK:
@@ -265,6 +274,7 @@ class Context:
 
     def set_samples_in_flight(self, n: int):
         """Consecutive full-mode samples that may overlap on the GPU (1 = none); the planes get the same bits."""
+        self.settings["set_samples_in_flight"] = (n,)
         self._check(self.lib.rm_ctx_set_samples_in_flight(self.h, int(n)))
         note = self.lib.rm_ctx_last_warning(self.h).decode()
         if note.startswith("warning:"):  # accepted, but the process environment will keep the samples from overlapping
@@ -290,6 +300,7 @@ class Context:
 
     def set_sample_batch(self, n: int):
         """Samples per launch of render_samples (0 = automatic, 1 = one launch per sample, up to 8); same bits."""
+        self.settings["set_sample_batch"] = (n,)
         self._check(self.lib.rm_ctx_set_sample_batch(self.h, int(n)))
 
     def assemble_striped(self, src_ptr: int, parts: int, max_rows: int, width: int, height: int, stripe_rows: int, dst_ptr: int,
@@ -333,10 +344,12 @@ class Context:
 
     def set_cost_order(self, on: bool):
         """Start the tiles of a job most-expensive-first by their cost in the previous sample (scheduling only)."""
+        self.settings["set_cost_order"] = (on,)
         self._check(self.lib.rm_ctx_set_cost_order(self.h, 1 if on else 0))
 
     def set_cull_min_pixels(self, pixels: int):
         """Pixel-samples a scene has to be asked for before its culling grid is built (0: with the first render; same bits)."""
+        self.settings["set_cull_min_pixels"] = (pixels,)
         self._check(self.lib.rm_ctx_set_cull_min_pixels(self.h, int(pixels)))
 
     def cull_stats(self) -> dict:
@@ -345,6 +358,7 @@ class Context:
         return dict(built=int(out[0]), bytes=int(out[1]), grids=int(out[2]), budget=int(out[3]))
 
     def set_retire_eps(self, eps: float):
+        self.settings["set_retire_eps"] = (eps,)
         self._check(self.lib.rm_ctx_set_retire_eps(self.h, float(eps)))
 
     def debug_counters(self, reset: bool = True):

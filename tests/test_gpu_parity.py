@@ -67,12 +67,42 @@ def ctx():
 
     c = native.Context(0)
     O.set_tan_mode(O.TAN_PORTABLE)
+    _XCHECK[id(c)] = None
     yield c
+    if _XCHECK.get(id(c)) is not None:
+        _XCHECK[id(c)].close()
+    _XCHECK.pop(id(c), None)
     c.close()
+
+
+# The second implementation of the per-pixel program -- the wavefront pipeline -- is not in the product library since round 5: it is
+# compiled into tests/_xcheck/libhip_raymarch_xcheck.so (build.py build_crosscheck), and a render that asks for it (the WF flag) runs on
+# a context of that library on the same GPU.  What the tests compare is unchanged: the product's pixel kernel against an independent
+# implementation of the marches, bounces and lights, bit for bit.
+_XCHECK = {}
+
+
+def impl_ctx(ctx, flags):
+    """The context a render with these flags runs on: the product's, or -- for RM_RENDER_WAVEFRONT -- the cross-check build's."""
+    if not (flags & WF) or ctx.gl_stack_on:
+        return ctx
+    from raymarching_engine_amd import native
+
+    if _XCHECK.get(id(ctx)) is None:
+        _XCHECK[id(ctx)] = native.Context(ctx.device, library=native.XCHECK_LIB_PATH)
+    x = _XCHECK[id(ctx)]
+    for name, args in ctx.settings.items():  # the retire tolerance, samples in flight, batch, cost order ... a test has set on its context
+        if x.settings.get(name) != args:
+            getattr(x, name)(*args)
+    return x
 
 
 def render_gpu(ctx, sc, schema, noises, flags=STRICT, rows=None, tile=None):
     r = schema["render"]
+    surfaces = bool(getattr(sc, "surfaces", lambda: [])()) or getattr(sc, "_kind_scene", None) is not None  # (and tables with kind rows, RM_PRIM_KIND)
+    if flags & WF and surfaces:
+        flags = (flags & ~WF) | MK  # the pipeline has no per-shape materials and no kind rows: such a scene's "other implementation" is the pixel kernel again (its second check is the oracle)
+    ctx = impl_ctx(ctx, flags)
     h = ctx.create_scene(sc)
     rb, rc = rows if rows else (0, r["height"])
     fb = ctx.create_framebuffer(r["width"], r["height"], rb, rc)
@@ -82,8 +112,7 @@ def render_gpu(ctx, sc, schema, noises, flags=STRICT, rows=None, tile=None):
     # surfaces always takes the pixel kernel (rm_api.hip uses_wavefront), and a test that renders "both implementations" of such a
     # scene compares the pixel kernel with itself; its second check is the oracle
     if flags & (MK | WF) and not ctx.gl_stack_on:
-        surfaces = bool(getattr(sc, "surfaces", lambda: [])()) or getattr(sc, "_kind_scene", None) is not None  # (and tables with kind rows, RM_PRIM_KIND)
-        assert ctx.last_pipeline() == ("wavefront" if flags & WF and not surfaces else "megakernel"), (ctx.last_pipeline(), flags, surfaces)
+        assert ctx.last_pipeline() == ("wavefront" if flags & WF else "megakernel"), (ctx.last_pipeline(), flags, surfaces)
     out = [fb.download(p) for p in (0, 1, 2)]
     fb.destroy()
     h.destroy()
@@ -438,17 +467,22 @@ def test_striped_row_sharding_equals_single_frame(ctx, parts):
     h = ctx.create_scene(sc)
     for mk in (MK, WF):  # each pipeline against its own single-frame render
         whole = render_gpu(ctx, sc, schema, noises, flags | mk)
+        c = impl_ctx(ctx, mk)
+        hc = h if c is ctx else c.create_scene(sc)
         pieces = [[], [], []]
         for part in range(parts):
-            fb = ctx.create_striped_framebuffer(3840, 2160, shard.STRIPE_ROWS, parts, part)
+            fb = c.create_striped_framebuffer(3840, 2160, shard.STRIPE_ROWS, parts, part)
             assert fb.row_count == len(shard.owned_rows(2160, parts, part))
             for n in noises:
-                ctx.render_sample(h, fb, J.uniforms_from_schema(schema, n), None, flags | mk)
+                c.render_sample(hc, fb, J.uniforms_from_schema(schema, n), None, flags | mk)
             for k in range(3):
                 pieces[k].append(fb.download(k))
             fb.destroy()
+        if hc is not h:
+            hc.destroy()
         for k in range(3):
             assert same_bits(shard.assemble(pieces[k], 2160), whole[k]).all()
+    whole = render_gpu(ctx, sc, schema, noises, flags)
     # a tile that cuts through stripes
     fb = ctx.create_striped_framebuffer(3840, 2160, shard.STRIPE_ROWS, parts, parts - 1)
     ctx.render_sample(h, fb, J.uniforms_from_schema(schema, noises[0]), abi.RmRect(100, 1001, 300, 77), flags)
@@ -863,7 +897,11 @@ def test_contexts_give_their_memory_back(ctx):
         for n in noises[:3]:
             c.render_sample(h, fb, J.uniforms_from_schema(schema, tuple(n)), None, FAST)
         c.render_samples(h, sfb, J.uniforms_from_schema(schema, (0.0, 0.0)), [tuple(n) for n in noises], None, FAST)
-        c.render_sample(h, fb, J.uniforms_from_schema(schema, tuple(noises[0])), None, STRICT | WF)
+        x = native.Context(0, library=native.XCHECK_LIB_PATH)  # the pipeline's workspace (240 B per pixel) is the cross-check build's to give back
+        xh, xfb = x.create_scene(sc), x.create_framebuffer(640, 512)
+        x.render_sample(xh, xfb, J.uniforms_from_schema(schema, tuple(noises[0])), None, STRICT | WF)
+        x.sync()
+        xfb.destroy(); xh.destroy(); x.close()
         fb.present(4)
         out = c.buffer(640 * 512 * 4)
         c.present_rows(sfb, 9, out.ptr)
@@ -995,8 +1033,13 @@ def test_random_jobs_strict_build_equals_the_oracle_bit_for_bit(ctx):
             got = render_gpu(ctx, sc, schema, noises, STRICT | pipeline)
             for k in range(3 if mode == "full" else 1):
                 eq = same_bits(want[k], got[k])
+                if not eq.all():
+                    y, x = [int(v[0]) for v in np.nonzero(~eq.all(-1))]
+                    again = render_gpu(ctx, sc, schema, noises, STRICT | pipeline)  # (is it the render or the state it ran in?)
+                    detail = (f"; first at pixel ({x}, {y}): oracle {want[k][y, x]} gpu {got[k][y, x]}; the same render again differs from the first in "
+                              f"{int((~same_bits(again[k], got[k])).sum())} values and from the oracle in {int((~same_bits(again[k], want[k])).sum())}; scene {vars(sc) if not hasattr(sc, '_nodes') else ''}")
                 assert eq.all(), (f"job {it}: {type(sc).__name__} {w}x{h} {mode} counts {counts} camera {cam} lights {len(lights)} pipeline {pipeline}: "
-                                  f"plane {k}, {int((~eq).sum())} values differ")
+                                  f"plane {k}, {int((~eq).sum())} values differ" + detail)
     # the jobs are not empty: their images are far from constant, and both hits and escapes occur
     print(f"\nrandom jobs: share of pixels that end within 1e5 of the camera, min / median / max {min(hits):.2f} / {np.median(hits):.2f} / {max(hits):.2f}; "
           f"distinct colour values per image, median {int(np.median(distinct))}")
@@ -1169,13 +1212,15 @@ def test_random_jobs_partitions_and_implementations_leave_the_same_bits(ctx):
         noises = GC.halton_pairs(int(rng.integers(1, 3)))
         build = FAST if rng.random() < 0.5 else STRICT
         planes = 3 if mode == "full" else 1
-        hnd = ctx.create_scene(sc)
+        ctx_mk = ctx
+        hnd = ctx_mk.create_scene(sc)
 
         def render(fb, tile, pipe):
             for x in noises:
-                ctx.render_sample(hnd, fb, J.uniforms_from_schema(schema, tuple(x)), tile, build | pipe)
+                fb.ctx.render_sample(hnds[id(fb.ctx)], fb, J.uniforms_from_schema(schema, tuple(x)), tile, build | pipe)
 
-        fb = ctx.create_framebuffer(w, h)
+        hnds = {id(ctx_mk): hnd}
+        fb = ctx_mk.create_framebuffer(w, h)
         render(fb, None, MK)
         want = [fb.download(k) for k in range(planes)]
         fb.destroy()
@@ -1184,6 +1229,9 @@ def test_random_jobs_partitions_and_implementations_leave_the_same_bits(ctx):
         if what == 2 and stripes < 2:
             what = 1  # too low for two striped parts (a part without rows is refused)
         pipe = (MK, WF)[rng.integers(0, 2)]
+        ctx = impl_ctx(ctx_mk, WF if what == 0 else pipe)  # the context of the implementation this job's second render runs on
+        if id(ctx) not in hnds:
+            hnds[id(ctx)] = ctx.create_scene(sc)
         if what == 0:  # the other implementation, whole frame
             fb = ctx.create_framebuffer(w, h)
             render(fb, None, WF)
@@ -1215,10 +1263,12 @@ def test_random_jobs_partitions_and_implementations_leave_the_same_bits(ctx):
             for x in noises:  # sample by sample, tile by tile (accumulation per pixel is in sample order either way)
                 for y0, y1 in zip(ys[:-1], ys[1:]):
                     for x0, x1 in zip(xs[:-1], xs[1:]):
-                        ctx.render_sample(hnd, fb, J.uniforms_from_schema(schema, tuple(x)), abi.RmRect(x0, y0, x1 - x0, y1 - y0), build | pipe)
+                        ctx.render_sample(hnds[id(ctx)], fb, J.uniforms_from_schema(schema, tuple(x)), abi.RmRect(x0, y0, x1 - x0, y1 - y0), build | pipe)
             got = [fb.download(k) for k in range(planes)]
             fb.destroy()
-        hnd.destroy()
+        for c in {id(ctx_mk): ctx_mk, id(ctx): ctx}.values():
+            hnds[id(c)].destroy()
+        ctx = ctx_mk
         for k in range(planes):
             assert same_bits(got[k], want[k]).all(), (f"job {it}: {type(sc).__name__} {w}x{h} {mode} counts {counts} cam {cam} lights {len(lights)} "
                                                       f"build {build} partition {what} pipeline {pipe}: plane {k}")

@@ -442,6 +442,22 @@ def test_render_job_host_replays_the_reference_loop_call_by_call():
         compare_host_events(k, schema, events, want)
 
 
+def test_the_wavefront_pipeline_lives_in_the_cross_check_build_only():
+    """Round 5: the second implementation of the per-pixel program (csrc/rm_wavefront.inc) is test infrastructure.  The product
+    library holds none of its kernels; tests/_xcheck/libhip_raymarch_xcheck.so -- the same sources with -DRM_WITH_WAVEFRONT=1
+    (build.py build_crosscheck) -- holds them and exports the same C ABI, so the GPU tests can hold the pixel kernel to it."""
+    from raymarching_engine_amd import native
+
+    product = native.LIB_PATH.read_bytes()
+    assert product.count(b"wf_march") == 0 and product.count(b"wf_shade") == 0 and product.count(b"rm_pixel_kernel") > 0
+    if not native.XCHECK_LIB_PATH.exists():
+        pytest.skip("the cross-check build has not been made (python raymarching-engine_amd/build.py)")
+    xcheck = native.XCHECK_LIB_PATH.read_bytes()
+    assert xcheck.count(b"wf_march") > 0 and xcheck.count(b"rm_pixel_kernel") > 0
+    lib = native.load_library(native.XCHECK_LIB_PATH)
+    assert all(hasattr(lib, name) for name in native.EXPORTS) and lib.rm_abi_version() == abi.RM_ABI_VERSION
+
+
 def test_a_suspended_job_keeps_its_scene_through_the_cache_eviction():
     """The scene cache of a context holds 64 scenes, least recently used out first (job.SCENE_CACHE_ENTRIES) -- but a job yields
     between samples, and the scenes other jobs bring in meanwhile must not destroy the one it still renders (round 4 did: the

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Round 3: table scenes (CSG-64) by library variant: python tools/table_variants.py default tools/_exp_x.so ...
-ms per sample of C4 (4096^2 full frame, both implementations), one 8-way shard of it, one 8-way shard of C5, and C2."""
+"""Table scenes (CSG-64) by library variant: python tools/table_variants.py default tools/_exp_x.so ...
+ms per sample of C4 (4096^2 full frame), one 8-way shard of it, one 8-way shard of C5, C5, and C2 (the pixel kernel: the wavefront pipeline
+is in the tests' cross-check build only since round 5 -- tools/time_all.py times it)."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) >= 2 and sys.argv[1] != "--child":
@@ -15,12 +16,12 @@ from raymarching_engine_amd import abi, job as J, native, scene as S, shard
 ctx = native.Context(0)
 F, MK, WF = abi.RM_RENDER_FAST, abi.RM_RENDER_MEGAKERNEL, abi.RM_RENDER_WAVEFRONT
 soft = [J.point_light((2.0, 3.0, -4.0), size=0.3)]
-cases = [("c4 full", S.csg64(), dict(width=4096, height=4096, counts=(128,), render_mode="full", position=(0, 0, -5.0), lights=GC.LIGHT), None, (MK, WF)),
-         ("c4 shard/8", S.csg64(), dict(width=4096, height=4096, counts=(128,), render_mode="full", position=(0, 0, -5.0), lights=GC.LIGHT), 8, (MK, WF)),
-         ("c5 shard/8", S.csg64(), dict(width=8192, height=8192, counts=(128, 64, 64), render_mode="full", position=(0, 0, -5.0), lights=soft), 8, (MK, WF)),
-         ("c5 full", S.csg64(), dict(width=8192, height=8192, counts=(128, 64, 64), render_mode="full", position=(0, 0, -5.0), lights=soft), None, (MK, WF)),
+cases = [("c4 full", S.csg64(), dict(width=4096, height=4096, counts=(128,), render_mode="full", position=(0, 0, -5.0), lights=GC.LIGHT), None, (MK,)),
+         ("c4 shard/8", S.csg64(), dict(width=4096, height=4096, counts=(128,), render_mode="full", position=(0, 0, -5.0), lights=GC.LIGHT), 8, (MK,)),
+         ("c5 shard/8", S.csg64(), dict(width=8192, height=8192, counts=(128, 64, 64), render_mode="full", position=(0, 0, -5.0), lights=soft), 8, (MK,)),
+         ("c5 full", S.csg64(), dict(width=8192, height=8192, counts=(128, 64, 64), render_mode="full", position=(0, 0, -5.0), lights=soft), None, (MK,)),
          ("c2", S.single_sphere(), dict(width=1920, height=1080, counts=(128,), render_mode="preview", position=(0, 0, -3.0)), None, (MK,)),
-         ("csg_blocks (192 rows, hard operators) 1080p", S.csg_blocks(), dict(width=1920, height=1080, counts=(128, 64), render_mode="full", position=(0.3, 0.2, -6.0), lights=GC.LIGHT), None, (MK, WF)),
+         ("csg_blocks (192 rows, hard operators) 1080p", S.csg_blocks(), dict(width=1920, height=1080, counts=(128, 64), render_mode="full", position=(0.3, 0.2, -6.0), lights=GC.LIGHT), None, (MK,)),
          ("csg_blocks preview 1080p", S.csg_blocks(), dict(width=1920, height=1080, counts=(128,), render_mode="preview", position=(0.3, 0.2, -6.0)), None, (MK,)),
          ("csg_mixed 1080p", GC.build_scene("csg_mixed"), dict(width=1920, height=1080, counts=(128, 64), render_mode="full", position=(0.3, 0.2, -4.0), lights=GC.LIGHT), None, (MK,))]
 def smooth_table(rows, boxes, seed=11):  # mostly smooth unions of several radii (round 4: the general fold culls their far rows too)
