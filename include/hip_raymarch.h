@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RM_ABI_VERSION 7 /* 7: rm_present_sharded_finish / rm_present_sharded take the size of the host buffer (a changed signature), rm_ctx_set_cull_min_pixels, rm_ctx_cull_stats; 6: rm_present_striped_rows, rm_present_sharded_start / _finish, rm_ctx_last_warning, RM_PROBE_CAST_SHADOW, RM_PRIM_KIND (additions only); 3: rm_ctx_set_sample_batch, rm_buffer_*; 4: rm_ctx_set_gl_stack; 5: RmSurface / RmSceneDesc.surfaces (the struct grew), rm_pack_present_rows, rm_present_sharded, rm_ctx_last_pipeline, RM_RENDER_NO_FAR_JUMP, RM_RENDER_NO_CULL (additions only) */
+#define RM_ABI_VERSION 8 /* 8: RM_PRIM_TORUS / _CYLINDER / _PLANE, RM_OP_SMOOTH_SUBTRACT / _INTERSECT (additions only); 7: rm_present_sharded_finish / rm_present_sharded take the size of the host buffer (a changed signature), rm_ctx_set_cull_min_pixels, rm_ctx_cull_stats; 6: rm_present_striped_rows, rm_present_sharded_start / _finish, rm_ctx_last_warning, RM_PROBE_CAST_SHADOW, RM_PRIM_KIND (additions only); 3: rm_ctx_set_sample_batch, rm_buffer_*; 4: rm_ctx_set_gl_stack; 5: RmSurface / RmSceneDesc.surfaces (the struct grew), rm_pack_present_rows, rm_present_sharded, rm_ctx_last_pipeline, RM_RENDER_NO_FAR_JUMP, RM_RENDER_NO_CULL (additions only) */
 
 #define RM_MAX_BOUNCES 10 /* raymarchingStepCountsArray[10], raymarcher.frag:31 */
 #define RM_MAX_LIGHTS 10  /* lightPositions[10],             raymarcher.frag:37-39 */
@@ -115,9 +115,20 @@ enum {
  *                   kind = (int)size[0] one of RM_SCENE_MANDELBULB, RM_SCENE_SPHERE_LATTICE and the kind's parameters in
  *                   RmSceneDesc.params (its own slots: one kind per table, any number of rows of it).  Operator, k and
  *                   surface as for a sphere or a box.  A table with such a row renders with the pixel kernel, without the
- *                   far-field exits and the row culling (both are arguments about spheres and boxes). */
-enum { RM_PRIM_SPHERE = 0, RM_PRIM_BOX = 1, RM_PRIM_REPEAT = 2, RM_PRIM_FOLD = 3, RM_PRIM_KIND = 4 };
-enum { RM_OP_UNION = 0, RM_OP_SMOOTH_UNION = 1, RM_OP_SUBTRACT = 2, RM_OP_INTERSECT = 3 };
+ *                   far-field exits and the row culling (both are arguments about spheres and boxes).
+ *   (ABI 8) three more shapes and the smooth forms of the other two operators -- the vocabulary a scene author composes with next
+ *   to sphere / box / smooth union (the reference's helper set is those three: raymarcher.frag:74,:108, smooth-tree.glsl:20-22; any
+ *   other shape is GLSL of the author's own, which cannot cross this ABI).  About the row's centre c, axis y:
+ *   RM_PRIM_TORUS     length(vec2(length((q - c).xz) - R, (q - c).y)) - r                R = size[0], r = size[1]
+ *   RM_PRIM_CYLINDER  capped: dx = length((q - c).xz) - r, dy = |(q - c).y| - h;          r = size[0], h = size[1]
+ *                     min(max(dx, dy), 0) + length(max(vec2(dx, dy), 0))
+ *   RM_PRIM_PLANE     dot(q - c, n)                                                      n = size[0..2] (the caller's unit normal)
+ *   RM_OP_SMOOTH_SUBTRACT   h = clamp(0.5 - 0.5 (d + di) / k, 0, 1);  mix(d, -di, h) + k h (1 - h)      (k > 0)
+ *   RM_OP_SMOOTH_INTERSECT  h = clamp(0.5 - 0.5 (d - di) / k, 0, 1);  mix(d,  di, h) + k h (1 - h)
+ *   A table with one of these renders with the general fold, step by step: the far-field exits and the row culling are
+ *   arguments about spheres, boxes and the four older operators. */
+enum { RM_PRIM_SPHERE = 0, RM_PRIM_BOX = 1, RM_PRIM_REPEAT = 2, RM_PRIM_FOLD = 3, RM_PRIM_KIND = 4, RM_PRIM_TORUS = 5, RM_PRIM_CYLINDER = 6, RM_PRIM_PLANE = 7 };
+enum { RM_OP_UNION = 0, RM_OP_SMOOTH_UNION = 1, RM_OP_SUBTRACT = 2, RM_OP_INTERSECT = 3, RM_OP_SMOOTH_SUBTRACT = 4, RM_OP_SMOOTH_INTERSECT = 5 };
 
 /* One row of the primitive table, 32 bytes.  The scene distance is the left
  * fold  d = shape[0];  d = op_i(d, shape[i])  over the shape rows, in table order
@@ -126,7 +137,8 @@ typedef struct RmPrim {
   int32_t type; /* RM_PRIM_* in bits 0..7, RM_OP_* in bits 8..15, surface index of a shape row in bits 16..23 (RmSurface) */
   float k;      /* smooth-union radius */
   float center[3];
-  float size[3]; /* sphere: size[0] = radius; box: half extents; repeat: period; fold: angles; kind: size[0] = the RM_SCENE_* kind */
+  float size[3]; /* sphere: size[0] = radius; box: half extents; repeat: period; fold: angles; kind: size[0] = the RM_SCENE_* kind;
+                    torus: R, r; cylinder: r, half height; plane: unit normal */
 } RmPrim;
 
 /* parameter slots of RmSceneDesc.params per kind */

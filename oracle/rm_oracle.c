@@ -308,6 +308,28 @@ static float sd_box(v3 p, v3 b) {
 }
 
 /* examples/smooth-tree.glsl:20-22 */
+/* the shapes and operators of ABI 8 (include/hip_raymarch.h), as the composer emits them (scene.py rmTorus, rmCylinder, rmPlane,
+ * rmSmoothSubtract, rmSmoothIntersect): the text the goldens were rendered from, statement for statement */
+static float length2(float x, float y) { FL(4); return sqrtf(x * x + y * y); }
+static float sd_torus(v3 p, float R, float r) { FL(2); return length2(length2(p.x, p.z) - R, p.y) - r; }
+static float sd_cylinder(v3 p, float r, float h) {
+  FL(2);
+  const float dx = length2(p.x, p.z) - r, dy = fabsf(p.y) - h;
+  FL(1);
+  return gl_min(gl_max(dx, dy), 0.0f) + length2(gl_max(dx, 0.0f), gl_max(dy, 0.0f));
+}
+static float sd_plane(v3 p, v3 n) { return vdot(p, n); }
+static float op_smooth_subtract(float d, float di, float k) {
+  FL(4 + 4);
+  float h = gl_clamp(0.5f - 0.5f * (d + di) / k, 0.0f, 1.0f);
+  return gl_mix(d, -di, h) + k * h * (1.0f - h);
+}
+static float op_smooth_intersect(float d, float di, float k) {
+  FL(4 + 4);
+  float h = gl_clamp(0.5f - 0.5f * (d - di) / k, 0.0f, 1.0f);
+  return gl_mix(d, di, h) + k * h * (1.0f - h);
+}
+static float table_shape(const RmSceneDesc* sc, const RmPrim* pr, int prim, v3 q, v3 c);
 static float op_smooth_union(float d1, float d2, float k) {
   FL(4 + 4);
   float h = gl_clamp(0.5f + 0.5f * (d2 - d1) / k, 0.0f, 1.0f);
@@ -326,6 +348,14 @@ static float sdf_kind_row(const RmSceneDesc* sc, const RmPrim* pr, v3 q) {
   FL(3);
   const v3 at = vsub(q, V(pr->center[0], pr->center[1], pr->center[2]));
   return (int)pr->size[0] == RM_SCENE_SPHERE_LATTICE ? sdf_sphere_lattice(sc, at) : sdf_mandelbulb(sc, at);
+}
+static float table_shape(const RmSceneDesc* sc, const RmPrim* pr, int prim, v3 q, v3 c) {
+  if (prim == RM_PRIM_SPHERE) return sdf_sphere(q, c, pr->size[0]);
+  if (prim == RM_PRIM_KIND) return sdf_kind_row(sc, pr, q);
+  if (prim == RM_PRIM_TORUS) return sd_torus(vsub(q, c), pr->size[0], pr->size[1]);
+  if (prim == RM_PRIM_CYLINDER) return sd_cylinder(vsub(q, c), pr->size[0], pr->size[1]);
+  if (prim == RM_PRIM_PLANE) return sd_plane(vsub(q, c), V(pr->size[0], pr->size[1], pr->size[2]));
+  return sd_box(vsub(q, c), V(pr->size[0], pr->size[1], pr->size[2]));
 }
 static float sdf_table(const RmSceneDesc* sc, v3 p) {
   float d = 0.0f, factor = 1.0f;
@@ -350,16 +380,15 @@ static float sdf_table(const RmSceneDesc* sc, v3 p) {
       factor = factor * pr->k;
       continue;
     }
-    float di;
-    if (prim == RM_PRIM_SPHERE) di = sdf_sphere(q, c, pr->size[0]);
-    else if (prim == RM_PRIM_KIND) di = sdf_kind_row(sc, pr, q);
-    else di = sd_box(vsub(q, c), V(pr->size[0], pr->size[1], pr->size[2]));
+    float di = table_shape(sc, pr, prim, q, c);
     if (domain) { FL(1); di = di * factor; }
     if (first) { d = di; first = 0; continue; }
     switch ((pr->type >> 8) & 0xff) {
       case RM_OP_UNION: d = gl_min(d, di); break;
       case RM_OP_SMOOTH_UNION: d = op_smooth_union(d, di, pr->k); break;
       case RM_OP_SUBTRACT: FL(1); d = gl_max(d, -di); break;
+      case RM_OP_SMOOTH_SUBTRACT: d = op_smooth_subtract(d, di, pr->k); break;
+      case RM_OP_SMOOTH_INTERSECT: d = op_smooth_intersect(d, di, pr->k); break;
       default: d = gl_max(d, di); break;
     }
   }
@@ -569,10 +598,7 @@ static int surface_index(const RmSceneDesc* sc, v3 p) {
       factor = factor * pr->k;
       continue;
     }
-    float di;
-    if (prim == RM_PRIM_SPHERE) di = sdf_sphere(q, c, pr->size[0]);
-    else if (prim == RM_PRIM_KIND) di = sdf_kind_row(sc, pr, q);
-    else di = sd_box(vsub(q, c), V(pr->size[0], pr->size[1], pr->size[2]));
+    float di = table_shape(sc, pr, prim, q, c);
     if (domain) di = di * factor;
     if (first || di < best) { best = di; surface = (pr->type >> 16) & 0xff; }
     first = 0;

@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-RM_ABI_VERSION = 7
+RM_ABI_VERSION = 8
 RM_MAX_BOUNCES = 10
 RM_MAX_LIGHTS = 10
 RM_MAX_PRIMS = 256
@@ -12,8 +12,8 @@ RM_OK, RM_ERR_INVALID, RM_ERR_DEVICE, RM_ERR_NO_DEVICE = 0, 1, 2, 3
 
 (RM_SCENE_TABLE, RM_SCENE_MANDELBULB, RM_SCENE_SPHERE_GRID, RM_SCENE_SPHERE_LATTICE,
  RM_SCENE_MENGER, RM_SCENE_KIFS_TREE, RM_SCENE_KIFS_BOX) = range(7)
-RM_PRIM_SPHERE, RM_PRIM_BOX, RM_PRIM_REPEAT, RM_PRIM_FOLD, RM_PRIM_KIND = 0, 1, 2, 3, 4
-RM_OP_UNION, RM_OP_SMOOTH_UNION, RM_OP_SUBTRACT, RM_OP_INTERSECT = 0, 1, 2, 3
+RM_PRIM_SPHERE, RM_PRIM_BOX, RM_PRIM_REPEAT, RM_PRIM_FOLD, RM_PRIM_KIND, RM_PRIM_TORUS, RM_PRIM_CYLINDER, RM_PRIM_PLANE = 0, 1, 2, 3, 4, 5, 6, 7
+RM_OP_UNION, RM_OP_SMOOTH_UNION, RM_OP_SUBTRACT, RM_OP_INTERSECT, RM_OP_SMOOTH_SUBTRACT, RM_OP_SMOOTH_INTERSECT = 0, 1, 2, 3, 4, 5
 
 RM_RENDER_STRICT, RM_RENDER_FAST, RM_RENDER_COLOR_ONLY, RM_RENDER_MEGAKERNEL, RM_RENDER_NO_COST_CLASSES, RM_RENDER_WAVEFRONT = 0, 1, 2, 4, 8, 16
 RM_RENDER_NO_OVERLAP = 32

@@ -428,6 +428,7 @@ static void table_far_field(const RmSceneDesc* desc, DevScene* dev) {
     const RmPrim& p = desc->prims[i];
     const int type = p.type & 0xff, op = (p.type >> 8) & 0xff;
     if (type == RM_PRIM_REPEAT || type == RM_PRIM_FOLD || type == RM_PRIM_KIND) return;  // a tiled or folded space has no far field; a kind's estimator is not a sphere's or a box's
+    if (type > RM_PRIM_KIND || op > RM_OP_INTERSECT) return;  // ABI 8's shapes and smooth operators: no end state has been derived for them (a plane has no far field at all)
     const double c = std::sqrt((double)p.center[0] * p.center[0] + (double)p.center[1] * p.center[1] + (double)p.center[2] * p.center[2]);
     const double extent = type == RM_PRIM_SPHERE ? std::fabs((double)p.size[0])
                                                  : std::sqrt((double)p.size[0] * p.size[0] + (double)p.size[1] * p.size[1] + (double)p.size[2] * p.size[2]);
@@ -488,7 +489,8 @@ static bool table_cull_params(const RmSceneDesc* desc, CullGrid* g, CullBuild* b
   for (int i = 0; i < n; i++) {
     const RmPrim& p = desc->prims[i];
     const int type = p.type & 0xff;
-    if (type != RM_PRIM_SPHERE && type != RM_PRIM_BOX) return false;  // domain rows: no grid in the table's own space
+    if (type != RM_PRIM_SPHERE && type != RM_PRIM_BOX) return false;  // domain rows: no grid in the table's own space (ABI 8's shapes: no rule)
+    if (((p.type >> 8) & 0xff) > RM_OP_INTERSECT) return false;         // ... nor for its smooth subtraction / intersection
     for (int a = 0; a < 3; a++) {
       const double e = std::fabs((double)(type == RM_PRIM_SPHERE ? p.size[0] : p.size[a]));
       lo[a] = std::fmin(lo[a], p.center[a] - e);
@@ -534,7 +536,7 @@ int rm_debug_cull_cell(const RmSceneDesc* desc, const double* centre, double rad
   if (!desc || !centre || !out_words || desc->kind != RM_SCENE_TABLE || desc->nprims < 1 || desc->nprims > RM_MAX_PRIMS || !desc->prims) return RM_ERR_INVALID;
   for (int i = 0; i < desc->nprims; i++) {
     const int type = desc->prims[i].type & 0xff;
-    if (type != RM_PRIM_SPHERE && type != RM_PRIM_BOX) return RM_ERR_INVALID;
+    if ((type != RM_PRIM_SPHERE && type != RM_PRIM_BOX) || ((desc->prims[i].type >> 8) & 0xff) > RM_OP_INTERSECT) return RM_ERR_INVALID;
   }
   rm_cull_cell(desc->prims, desc->nprims, (desc->nprims + 63) / 64, centre, radius, margin, out_words);
   return RM_OK;
@@ -592,7 +594,7 @@ int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out) {
     for (int i = 0; i < desc->nprims; i++) {
       const RmPrim& p = desc->prims[i];
       const int type = p.type & 0xff, op = (p.type >> 8) & 0xff;
-      if (type > RM_PRIM_KIND || op > RM_OP_INTERSECT || (p.type >> 24) != 0) {
+      if (type > RM_PRIM_PLANE || op > RM_OP_SMOOTH_INTERSECT || (p.type >> 24) != 0) {
         std::snprintf(buf, sizeof buf, "scene: row %d: unknown primitive/operator 0x%x", i, p.type);
         return fail(ctx, RM_ERR_INVALID, buf);
       }
@@ -609,7 +611,8 @@ int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out) {
           return fail(ctx, RM_ERR_INVALID, "scene: mandelbulb iterations must be in 0..64");
         if (kind == RM_SCENE_SPHERE_LATTICE && !(desc->params[RM_P_LATTICE_PERIOD] > 0.0f)) return fail(ctx, RM_ERR_INVALID, "scene: the lattice's period must be > 0");
       }
-      if (surface > desc->nsurfaces || (surface != 0 && type != RM_PRIM_SPHERE && type != RM_PRIM_BOX && type != RM_PRIM_KIND)) {
+      const bool shape = type != RM_PRIM_REPEAT && type != RM_PRIM_FOLD;
+      if (surface > desc->nsurfaces || (surface != 0 && !shape)) {
         std::snprintf(buf, sizeof buf, "scene: row %d: surface %d of %d (only shape rows name a surface)", i, surface, desc->nsurfaces);
         return fail(ctx, RM_ERR_INVALID, buf);
       }
@@ -625,9 +628,16 @@ int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out) {
         std::snprintf(buf, sizeof buf, "scene: row %d: fold needs scale > 0", i);
         return fail(ctx, RM_ERR_INVALID, buf);
       }
-      const bool shape = type == RM_PRIM_SPHERE || type == RM_PRIM_BOX || type == RM_PRIM_KIND;
-      if (shape && op == RM_OP_SMOOTH_UNION && !(p.k > 0.0f) && shapes > 0) {
-        std::snprintf(buf, sizeof buf, "scene: row %d: smooth union needs k > 0", i);
+      if (shape && (op == RM_OP_SMOOTH_UNION || op == RM_OP_SMOOTH_SUBTRACT || op == RM_OP_SMOOTH_INTERSECT) && !(p.k > 0.0f) && shapes > 0) {
+        std::snprintf(buf, sizeof buf, "scene: row %d: smooth %s needs k > 0", i, op == RM_OP_SMOOTH_UNION ? "union" : op == RM_OP_SMOOTH_SUBTRACT ? "subtraction" : "intersection");
+        return fail(ctx, RM_ERR_INVALID, buf);
+      }
+      if ((type == RM_PRIM_TORUS || type == RM_PRIM_CYLINDER) && !(p.size[0] >= 0.0f && p.size[1] >= 0.0f)) {
+        std::snprintf(buf, sizeof buf, "scene: row %d: a torus / cylinder needs radii (and a half height) >= 0", i);
+        return fail(ctx, RM_ERR_INVALID, buf);
+      }
+      if (type == RM_PRIM_PLANE && !(p.size[0] != 0.0f || p.size[1] != 0.0f || p.size[2] != 0.0f)) {
+        std::snprintf(buf, sizeof buf, "scene: row %d: a plane needs a normal", i);
         return fail(ctx, RM_ERR_INVALID, buf);
       }
       shapes += shape ? 1 : 0;
@@ -654,7 +664,7 @@ int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out) {
       if (((desc->prims[i].type >> 16) & 0xff) != 0) surfaces = true;
       if (type != RM_PRIM_SPHERE || (i > 0 && op != RM_OP_SMOOTH_UNION)) spheres_smooth = false;
       if (type == RM_PRIM_REPEAT || type == RM_PRIM_FOLD) domain = true;
-      if (type == RM_PRIM_BOX) boxes = true;
+      if (type == RM_PRIM_BOX || type == RM_PRIM_TORUS || type == RM_PRIM_CYLINDER || type == RM_PRIM_PLANE) boxes = true;  // (RM_TABLE_NO_BOXES is a promise about spheres)
       if (type == RM_PRIM_KIND) kinds = true;
     }
     // (RM_TABLE_NO_BOXES promises a non-finite distance at a non-finite point: not said of a kind's estimator, so a kind row withdraws it)

@@ -336,6 +336,23 @@ template <class M> RM_DEV float sd_box(v3 p, v3 b) {
   return length<M>(vmaxs(q, 0.0f)) + gmin(gmax(q.x, gmax(q.y, q.z)), 0.0f);
 }
 
+// the shapes and operators of ABI 8 (include/hip_raymarch.h; oracle/rm_oracle.c sd_torus ...; the composer's rmTorus ...)
+template <class M> RM_DEV float length2(float x, float y) { return M::sqrt(M::fma(y, y, x * x)); }
+template <class M> RM_DEV float sd_torus(v3 p, float R, float r) { return length2<M>(length2<M>(p.x, p.z) - R, p.y) - r; }
+template <class M> RM_DEV float sd_cylinder(v3 p, float r, float h) {
+  const float dx = length2<M>(p.x, p.z) - r, dy = fabsf(p.y) - h;
+  return gmin(gmax(dx, dy), 0.0f) + length2<M>(gmax(dx, 0.0f), gmax(dy, 0.0f));
+}
+template <class M> RM_DEV float sd_plane(v3 p, v3 n) { return dot<M>(p, n); }
+template <class M> RM_DEV float op_smooth_subtract(float d, float di, float k) {
+  float h = gclamp(0.5f - M::div(0.5f * (d + di), k), 0.0f, 1.0f);
+  return gmix<M>(d, -di, h) + k * h * (1.0f - h);
+}
+template <class M> RM_DEV float op_smooth_intersect(float d, float di, float k) {
+  float h = gclamp(0.5f - M::div(0.5f * (d - di), k), 0.0f, 1.0f);
+  return gmix<M>(d, di, h) + k * h * (1.0f - h);
+}
+
 // examples/smooth-tree.glsl:20-22
 template <class M> RM_DEV float op_smooth_union(float d1, float d2, float k) {
   float h = gclamp(0.5f + M::div(0.5f * (d2 - d1), k), 0.0f, 1.0f);
@@ -716,7 +733,17 @@ struct Sdf<RM_SCENE_TABLE> {
     if (op == RM_OP_UNION) return gmin(d, di);
     if (op == RM_OP_SMOOTH_UNION) return op_smooth_union<M>(d, di, k);
     if (op == RM_OP_SUBTRACT) return gmax(d, -di);
+    if (op == RM_OP_SMOOTH_SUBTRACT) return op_smooth_subtract<M>(d, di, k);
+    if (op == RM_OP_SMOOTH_INTERSECT) return op_smooth_intersect<M>(d, di, k);
     return gmax(d, di);
+  }
+  // the distance term of a shape row other than a sphere or a kind: box, torus, capped cylinder, plane (about the row's centre)
+  template <class M>
+  static RM_DEV float other_shape(int prim, v3 at, float4 b) {
+    if (prim == RM_PRIM_TORUS) return sd_torus<M>(at, b.y, b.z);
+    if (prim == RM_PRIM_CYLINDER) return sd_cylinder<M>(at, b.y, b.z);
+    if (prim == RM_PRIM_PLANE) return sd_plane<M>(at, V(b.y, b.z, b.w));
+    return sd_box<M>(at, V(b.y, b.z, b.w));
   }
   template <class M>
   static RM_DEV float eval_general_culled(const DevScene& sc, const SceneLds& lds, v3 p) {
@@ -840,7 +867,7 @@ struct Sdf<RM_SCENE_TABLE> {
       float di;
       if (prim == RM_PRIM_SPHERE) di = sdf_sphere<M>(q, c, b.y);
       else if (KINDS && prim == RM_PRIM_KIND) di = kind_row<M>(sc, lds, __builtin_amdgcn_readfirstlane((int)b.y), q - c);
-      else di = sd_box<M>(q - c, V(b.y, b.z, b.w));
+      else di = other_shape<M>(prim, q - c, b);
       if (domain) di = di * factor;
       if (first || di < best) { best = di; surface = (type >> 16) & 0xff; }
       first = false;
@@ -881,7 +908,7 @@ struct Sdf<RM_SCENE_TABLE> {
       float di;
       if (prim == RM_PRIM_SPHERE) di = sdf_sphere<M>(q, c, b.y);
       else if (KINDS && prim == RM_PRIM_KIND) di = kind_row<M>(sc, lds, __builtin_amdgcn_readfirstlane((int)b.y), q - c);
-      else di = sd_box<M>(q - c, V(b.y, b.z, b.w));
+      else di = other_shape<M>(prim, q - c, b);
       if (domain) di = di * factor;
       if (first) { d = di; first = false; continue; }
       const int op = (type >> 8) & 0xff;

@@ -14,7 +14,10 @@ export interface Surface { diffuse?: Vec3; specular?: Vec3; roughness?: number; 
 export class Scene { kind: number; params: number[]; material: Material; key(): string; }
 export class CsgScene extends Scene {
   constructor(material?: Partial<Material>);
-  union(): this; smoothUnion(k: number): this; subtract(): this; intersect(): this;
+  union(): this; smoothUnion(k: number): this; subtract(): this; intersect(): this; smoothSubtract(k: number): this; smoothIntersect(k: number): this;
+  /** ABI 8: a ring, a capped cylinder (axis y) and a half space (unit normal) about `center` / through `point` */
+  torus(center: Vec3, majorRadius: number, minorRadius: number, surface?: Surface): this; cylinder(center: Vec3, radius: number, halfHeight: number, surface?: Surface): this;
+  plane(point: Vec3, normal: Vec3, surface?: Surface): this;
   /** `surface`: the material functions then depend on the position -- at a point, the values of the nearest shape */
   sphere(center: Vec3, radius: number, surface?: Surface): this; box(center: Vec3, halfExtents: Vec3, surface?: Surface): this;
   /** domain operators: transform the point the FOLLOWING primitives are evaluated at (sphere-grid.glsl's repeat; one level of tree.glsl's fold) */

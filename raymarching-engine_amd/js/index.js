@@ -21,7 +21,8 @@ const addon = require("./rm_napi.node");
 const RM = {
   MAX_BOUNCES: 10, MAX_LIGHTS: 10,
   SCENE_TABLE: 0, SCENE_MANDELBULB: 1, SCENE_SPHERE_GRID: 2, SCENE_SPHERE_LATTICE: 3, SCENE_MENGER: 4, SCENE_KIFS_TREE: 5, SCENE_KIFS_BOX: 6,
-  PRIM_SPHERE: 0, PRIM_BOX: 1, PRIM_REPEAT: 2, PRIM_FOLD: 3, PRIM_KIND: 4, OP_UNION: 0, OP_SMOOTH_UNION: 1, OP_SUBTRACT: 2, OP_INTERSECT: 3,
+  PRIM_SPHERE: 0, PRIM_BOX: 1, PRIM_REPEAT: 2, PRIM_FOLD: 3, PRIM_KIND: 4, PRIM_TORUS: 5, PRIM_CYLINDER: 6, PRIM_PLANE: 7,
+  OP_UNION: 0, OP_SMOOTH_UNION: 1, OP_SUBTRACT: 2, OP_INTERSECT: 3, OP_SMOOTH_SUBTRACT: 4, OP_SMOOTH_INTERSECT: 5,
   RENDER_STRICT: 0, RENDER_FAST: 1, RENDER_COLOR_ONLY: 2, RENDER_MEGAKERNEL: 4, RENDER_WAVEFRONT: 16, RENDER_NO_OVERLAP: 32, RENDER_NO_FAR_JUMP: 64, RENDER_NO_CULL: 128,
 };
 
@@ -94,6 +95,9 @@ class CsgScene extends Scene {
   smoothUnion(k) { this._op = RM.OP_SMOOTH_UNION; this._k = k; return this; }
   subtract() { this._op = RM.OP_SUBTRACT; this._k = 0; return this; }
   intersect() { this._op = RM.OP_INTERSECT; this._k = 0; return this; }
+  // ABI 8: the smooth forms of the other two operators (h = clamp(0.5 - 0.5 (d +- di) / k, 0, 1); mix(d, -+di, h) + k h (1 - h)) ...
+  smoothSubtract(k) { this._op = RM.OP_SMOOTH_SUBTRACT; this._k = k; return this; }
+  smoothIntersect(k) { this._op = RM.OP_SMOOTH_INTERSECT; this._k = k; return this; }
   // `surface` (optional): material values of this shape's own -- {diffuse, specular, roughness, subsurface, subsurface_color, ior}, missing
   // ones from the reference defaults (Validate.tsx:18-51); the material functions then depend on the position (materialGlsl)
   _surface(surface) {
@@ -106,6 +110,11 @@ class CsgScene extends Scene {
   }
   sphere(center, radius, surface) { this.prims.push({ prim: RM.PRIM_SPHERE, op: this._op, k: this._k, center, size: [radius, 0, 0], surface: this._surface(surface) }); return this; }
   box(center, half, surface) { this.prims.push({ prim: RM.PRIM_BOX, op: this._op, k: this._k, center, size: half, surface: this._surface(surface) }); return this; }
+  // ... and three more shapes about `center`, axis y: a ring, a capped cylinder, a half space (unit normal); their GLSL text is the
+  // Python composer's (scene.py CsgScene: rmTorus, rmCylinder, rmPlane): glsl() here throws
+  torus(center, majorRadius, minorRadius, surface) { this.prims.push({ prim: RM.PRIM_TORUS, op: this._op, k: this._k, center, size: [majorRadius, minorRadius, 0], surface: this._surface(surface) }); return this; }
+  cylinder(center, radius, halfHeight, surface) { this.prims.push({ prim: RM.PRIM_CYLINDER, op: this._op, k: this._k, center, size: [radius, halfHeight, 0], surface: this._surface(surface) }); return this; }
+  plane(point, normal, surface) { this.prims.push({ prim: RM.PRIM_PLANE, op: this._op, k: this._k, center: point, size: normal, surface: this._surface(surface) }); return this; }
   // a shape whose distance term is another scene kind's own estimator at p - center (RM_PRIM_KIND, include/hip_raymarch.h): a Mandelbulb
   // (or a kind 3 lattice), folded like a sphere or a box -- new CsgScene().shape(new Mandelbulb()).intersect().box(...) is a Mandelbulb cut
   // by a box.  One kind with one parameter set per table (they travel in the scene's parameter block).  The GLSL text of such a table
@@ -123,6 +132,7 @@ class CsgScene extends Scene {
   glsl() {  // the reference's scene contract: float sdf(vec3); helpers sdfSphere/sdBox come from raymarcher.frag:74,108
     const lines = [];
     if (this.prims.some((n) => n.prim === RM.PRIM_KIND)) throw new Error("glsl(): a table with kind rows gets its text from the Python composer (scene.py CsgScene.shape)");
+    if (this.prims.some((n) => n.prim > RM.PRIM_KIND || n.op > RM.OP_INTERSECT)) throw new Error("glsl(): a table with ABI 8's shapes or smooth operators gets its text from the Python composer (scene.py CsgScene)");
     const isShape = (n) => n.prim === RM.PRIM_SPHERE || n.prim === RM.PRIM_BOX;
     const shapes = this.prims.filter(isShape), domain = shapes.length !== this.prims.length;
     if (shapes.slice(1).some((p) => p.op === RM.OP_SMOOTH_UNION))

@@ -193,7 +193,7 @@ class _Node:
     surface: int = 0  # 0 = the scene's material; k = the k-th Surface given to the scene's shapes
 
 
-SHAPE_PRIMS = (abi.RM_PRIM_SPHERE, abi.RM_PRIM_BOX, abi.RM_PRIM_KIND)  # rows that contribute a distance term
+SHAPE_PRIMS = (abi.RM_PRIM_SPHERE, abi.RM_PRIM_BOX, abi.RM_PRIM_KIND, abi.RM_PRIM_TORUS, abi.RM_PRIM_CYLINDER, abi.RM_PRIM_PLANE)  # rows that contribute a distance term
 KIND_SHAPES = (abi.RM_SCENE_MANDELBULB, abi.RM_SCENE_SPHERE_LATTICE)      # kinds a RM_PRIM_KIND row can evaluate
 
 
@@ -257,6 +257,17 @@ class CsgScene(Scene):
         self._op, self._k = abi.RM_OP_INTERSECT, 0.0
         return self
 
+    def smooth_subtract(self, k: float):
+        """The shapes that follow are carved out of the running value with a rounded edge of radius ~k (the polynomial smooth
+        maximum: h = clamp(0.5 - 0.5 (d + di) / k, 0, 1); mix(d, -di, h) + k h (1 - h))."""
+        self._op, self._k = abi.RM_OP_SMOOTH_SUBTRACT, float(k)
+        return self
+
+    def smooth_intersect(self, k: float):
+        """... intersected with it, likewise (h = clamp(0.5 - 0.5 (d - di) / k, 0, 1); mix(d, di, h) + k h (1 - h))."""
+        self._op, self._k = abi.RM_OP_SMOOTH_INTERSECT, float(k)
+        return self
+
     def sphere(self, center: Sequence[float], radius: float, surface: Optional[Surface] = None):
         """`surface`: material values of this shape's own (Surface); the material functions then depend on the position."""
         self._nodes.append(_Node(abi.RM_PRIM_SPHERE, self._op, self._k, tuple(center), (radius, 0.0, 0.0), self._surface(surface)))
@@ -264,6 +275,21 @@ class CsgScene(Scene):
 
     def box(self, center: Sequence[float], half_extents: Sequence[float], surface: Optional[Surface] = None):
         self._nodes.append(_Node(abi.RM_PRIM_BOX, self._op, self._k, tuple(center), tuple(half_extents), self._surface(surface)))
+        return self
+
+    def torus(self, center: Sequence[float], major_radius: float, minor_radius: float, surface: Optional[Surface] = None):
+        """A ring about `center` in its xz plane (axis y)."""
+        self._nodes.append(_Node(abi.RM_PRIM_TORUS, self._op, self._k, tuple(center), (float(major_radius), float(minor_radius), 0.0), self._surface(surface)))
+        return self
+
+    def cylinder(self, center: Sequence[float], radius: float, half_height: float, surface: Optional[Surface] = None):
+        """A capped cylinder about `center`, axis y."""
+        self._nodes.append(_Node(abi.RM_PRIM_CYLINDER, self._op, self._k, tuple(center), (float(radius), float(half_height), 0.0), self._surface(surface)))
+        return self
+
+    def plane(self, point: Sequence[float], normal: Sequence[float], surface: Optional[Surface] = None):
+        """The half space behind the plane through `point` with the UNIT normal `normal` (distance = dot(p - point, normal))."""
+        self._nodes.append(_Node(abi.RM_PRIM_PLANE, self._op, self._k, tuple(point), tuple(float(v) for v in normal), self._surface(surface)))
         return self
 
     def shape(self, scene: "Scene", center: Sequence[float] = (0.0, 0.0, 0.0), surface: Optional[Surface] = None):
@@ -305,7 +331,7 @@ class CsgScene(Scene):
     def sdf_glsl(self) -> str:
         shapes = [n for n in self._nodes if n.prim in SHAPE_PRIMS]
         if not shapes:
-            raise ValueError("a CSG scene needs at least one sphere, box or kind shape")
+            raise ValueError("a CSG scene needs at least one shape (sphere, box, torus, cylinder, plane or a kind)")
         domain = len(shapes) != len(self._nodes)
         lines = []
         if self._kind_scene is not None:  # the kind's own text, as a function of its own name
@@ -318,6 +344,15 @@ class CsgScene(Scene):
                 " float h = clamp(0.5 + 0.5 * (d2 - d1) / k, 0.0, 1.0);"
                 " return mix(d2, d1, h) - k * h * (1.0 - h); }"
             )
+        if any(n.op == abi.RM_OP_SMOOTH_SUBTRACT for n in shapes[1:]):
+            lines.append("float rmSmoothSubtract(float d, float di, float k) {"
+                         " float h = clamp(0.5 - 0.5 * (d + di) / k, 0.0, 1.0);"
+                         " return mix(d, -di, h) + k * h * (1.0 - h); }")
+        if any(n.op == abi.RM_OP_SMOOTH_INTERSECT for n in shapes[1:]):
+            lines.append("float rmSmoothIntersect(float d, float di, float k) {"
+                         " float h = clamp(0.5 - 0.5 * (d - di) / k, 0.0, 1.0);"
+                         " return mix(d, di, h) + k * h * (1.0 - h); }")
+        lines += self._shape_helpers()
         if any(n.prim == abi.RM_PRIM_FOLD for n in self._nodes):
             lines.append(  # scalar by scalar, in the order of the oracle / the kernel (tree.glsl:24-32 writes it with mat2)
                 "vec3 rmFold(vec3 q, float scale, vec3 off, vec3 ang) {"
@@ -341,11 +376,31 @@ class CsgScene(Scene):
                 lines.append(f"  d = rmSmoothUnion(d, {e}, {_f(n.k)});")
             elif n.op == abi.RM_OP_SUBTRACT:
                 lines.append(f"  d = max(d, -{e});")
+            elif n.op == abi.RM_OP_SMOOTH_SUBTRACT:
+                lines.append(f"  d = rmSmoothSubtract(d, {e}, {_f(n.k)});")
+            elif n.op == abi.RM_OP_SMOOTH_INTERSECT:
+                lines.append(f"  d = rmSmoothIntersect(d, {e}, {_f(n.k)});")
             else:
                 lines.append(f"  d = max(d, {e});")
         lines.append("  return d;")
         lines.append("}")
         return "\n".join(lines)
+
+    def _shape_helpers(self) -> List[str]:
+        """The GLSL of the shapes the reference's shader has no helper for (raymarcher.frag has sdfSphere :74 and sdBox :108), scalar
+        by scalar in the order of the oracle and the kernels."""
+        out = []
+        used = {n.prim for n in self._nodes}
+        if used & {abi.RM_PRIM_TORUS, abi.RM_PRIM_CYLINDER}:
+            out.append("float rmLength2(float x, float y) { return sqrt(x * x + y * y); }")
+        if abi.RM_PRIM_TORUS in used:
+            out.append("float rmTorus(vec3 p, float R, float r) { return rmLength2(rmLength2(p.x, p.z) - R, p.y) - r; }")
+        if abi.RM_PRIM_CYLINDER in used:
+            out.append("float rmCylinder(vec3 p, float r, float h) { float dx = rmLength2(p.x, p.z) - r; float dy = abs(p.y) - h;"
+                       " return min(max(dx, dy), 0.0) + rmLength2(max(dx, 0.0), max(dy, 0.0)); }")
+        if abi.RM_PRIM_PLANE in used:
+            out.append("float rmPlane(vec3 p, vec3 n) { return p.x * n.x + p.y * n.y + p.z * n.z; }")
+        return out
 
     def _terms(self, lines: List[str], domain: bool):
         """The shape rows in table order with the GLSL expression of each one's distance term; the statements of the domain
@@ -362,6 +417,12 @@ class CsgScene(Scene):
                 e = f"sdfSphere({q}, {_v3(n.center)}, {_f(n.size[0])})"
             elif n.prim == abi.RM_PRIM_KIND:
                 e = f"rmKindSdf({q} - {_v3(n.center)})"
+            elif n.prim == abi.RM_PRIM_TORUS:
+                e = f"rmTorus({q} - {_v3(n.center)}, {_f(n.size[0])}, {_f(n.size[1])})"
+            elif n.prim == abi.RM_PRIM_CYLINDER:
+                e = f"rmCylinder({q} - {_v3(n.center)}, {_f(n.size[0])}, {_f(n.size[1])})"
+            elif n.prim == abi.RM_PRIM_PLANE:
+                e = f"rmPlane({q} - {_v3(n.center)}, {_v3(n.size)})"
             else:
                 e = f"sdBox({q} - {_v3(n.center)}, {_v3(n.size)})"
             if domain:

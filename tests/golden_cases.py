@@ -78,6 +78,23 @@ SCENES = {
         .union().box((0.0, -1.75, 0.0), (2.0, 0.125, 2.0)),
         None,
     ),
+    # round 5: the shapes and smooth operators of ABI 8 (+ - * / sqrt abs min max only, so bit-exact): a slab with a torus-shaped groove
+    # (smooth subtraction), a capped cylinder standing on it, a torus that names a surface, the whole smooth-intersected with the half space
+    # below y = 1 and drilled by a thin cylinder; and
+    # the same vocabulary under a domain row (a lattice of short cylinders with a ring each, their tops shaved by a smooth-subtracted half space)
+    "csg_shapes": (
+        lambda: S.CsgScene().box((0.0, 0.0, 0.0), (1.25, 0.375, 1.0)).smooth_subtract(0.125).torus((0.0, 0.375, 0.0), 0.625, 0.1875)
+        .union().cylinder((0.875, 0.75, -0.25), 0.25, 0.5)
+        .smooth_union(0.1875).torus((-0.75, 0.75, 0.25), 0.375, 0.125, surface=S.Surface(diffuse=(0.875, 0.5, 0.125), specular=(0.5, 0.5, 0.5), roughness=0.375))
+        .smooth_intersect(0.25).plane((0.0, 1.0, 0.0), (0.0, 1.0, 0.0))
+        .subtract().cylinder((-0.25, 0.0, 0.625), 0.1875, 1.0),
+        None,
+    ),
+    "csg_shapes_repeat": (
+        lambda: S.CsgScene().repeat((2.0, 2.0, 2.0)).cylinder((0.0, 0.0, 0.0), 0.375, 0.5).smooth_union(0.125).torus((0.0, 0.5, 0.0), 0.375, 0.125)
+        .smooth_subtract(0.0625).plane((0.0, 0.5625, 0.0), (0.0, -1.0, 0.0)),
+        None,
+    ),
     "mandelbulb": (lambda: S.Mandelbulb(), None),
     "lattice": (lambda: S.sphere_lattice_example(), None),
     "fractal1": (lambda: S.SphereGridFractal(), "fractal1.glsl"),
@@ -90,9 +107,9 @@ SCENES = {
 # scenes whose SDF the oracle reproduces bit for bit (only + - * / sqrt floor
 # abs min max); the others go through sin/cos/acos/atan/pow/log where
 # SwiftShader and the oracle (either of its math modes) differ in the last bits (or much more: see test tolerances)
-SDF_BIT_EXACT = ("sphere", "sphere_sss", "csg64", "csg_mixed", "csg_repeat_fold", "csg_surfaces", "csg_lattice_ball", "lattice", "fractal1")
+SDF_BIT_EXACT = ("sphere", "sphere_sss", "csg64", "csg_mixed", "csg_repeat_fold", "csg_surfaces", "csg_lattice_ball", "csg_shapes", "csg_shapes_repeat", "lattice", "fractal1")
 # scenes with a material-function golden (tests/golden/misc_material_<name>.npz)
-MATERIAL_SCENES = ("sphere", "lattice", "csg_surfaces", "csg_bulb_cut")
+MATERIAL_SCENES = ("sphere", "lattice", "csg_surfaces", "csg_bulb_cut", "csg_shapes")
 
 IMG_W, IMG_H = 64, 32
 
@@ -132,6 +149,9 @@ IMAGES = {
     # roughness at the moved point (:366), the subsurface branch of one shape only; and the preview's diffuse + specular (:218-219)
     "csg_surfaces_full_2b": ("csg_surfaces", 2, dict(render_mode="full", position=(0.25, 0.5, -3.5), counts=(64, 32), lights=THREE_LIGHTS)),
     "csg_surfaces_preview": ("csg_surfaces", 1, dict(render_mode="preview", position=(0.25, 0.5, -3.5), counts=(64,))),
+    "csg_shapes_full_2b": ("csg_shapes", 2, dict(render_mode="full", position=(0.25, 0.875, -3.25), counts=(64, 32), lights=LIGHT)),
+    "csg_shapes_preview": ("csg_shapes", 1, dict(render_mode="preview", position=(0.25, 0.875, -3.25), counts=(64,))),
+    "csg_shapes_repeat_full_2b": ("csg_shapes_repeat", 1, dict(render_mode="full", position=(0.5, 0.375, -1.25), counts=(48, 24), lights=LIGHT)),
     # round 4: kind rows through the whole main()
     "csg_bulb_cut_full_2b": ("csg_bulb_cut", 2, dict(render_mode="full", position=(0.25, 0.125, -1.625), counts=(48, 24), lights=LIGHT)),
     "csg_lattice_ball_full_2b": ("csg_lattice_ball", 1, dict(render_mode="full", position=(0.25, 0.5, -3.5), counts=(48, 24), lights=LIGHT)),
@@ -148,6 +168,7 @@ CAST = {
     "menger": ((0.5, 0.5, -2.0), 48.0),
     "csg_repeat_fold": ((0.2, 0.1, -1.4), 48.0),
     "csg_lattice_ball": ((0.25, 0.5, -3.5), 64.0),
+    "csg_shapes": ((0.25, 0.875, -3.25), 64.0),
 }
 
 
