@@ -91,7 +91,7 @@ struct rm_ctx {
     bool have_cost = false;
     // Off the critical path (the context's own slot): two cost / order buffers used in turn.  The costs of launch n
     // are sorted on a side stream WHILE launch n + 1 runs, and launch n + 2 starts in that order -- tile costs hardly
-    // change from one sample to the next, so an order that is one sample old is as good, and the 15 us of the sort
+    // change from one sample to the next, so an order that is one sample old is as good, and the sort's two small launches
     // (one workgroup) no longer stand between two launches.
     unsigned int* cost2 = nullptr;
     unsigned int* order2 = nullptr;
@@ -142,9 +142,10 @@ struct rm_scene {
   RmPrim* d_prims = nullptr;
   RmSurface* d_surfaces = nullptr;
   unsigned long long* d_cull = nullptr;
-  // the culling grid of a long CSG table is built by the first call that can use it (scene_cull_grid): a host that
-  // creates many scenes it never renders does not pay (32^3 x levels + 1) x words x 8 B -- 4.7 MB at 12
-  // rows, 14 MB at 192; 134 MB for a table of spheres under one smooth-union radius, whose rule wants 128^3 cells -- and a build kernel per scene
+  // the culling grid of a long CSG table is built once the scene has earned it (scene_cull_grid: rm_ctx_set_cull_min_pixels): a host that
+  // creates many scenes it never renders, or shows a new one in every small frame, does not pay ((n^3 + (levels - 1) n_outer^3 + 1) x words
+  // x 8 B -- 4.7 MB at 12 rows, 14 MB at 192 of hard operators; 31.5 MB per 64 rows of smooth unions, whose rule wants 128^3 cells near the
+  // shapes -- and a build kernel per scene)
   bool cull_wanted = false;
   CullGrid cull_grid{};
   CullBuild cull_build{};
@@ -658,7 +659,7 @@ int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out) {
   s->dev.kind = desc->kind;
   s->dev.nprims = desc->kind == RM_SCENE_TABLE ? desc->nprims : 0;
   if (desc->kind == RM_SCENE_TABLE) {
-    bool spheres_smooth = true, domain = false, boxes = false, surfaces = false, kinds = false;
+    bool spheres_smooth = true, domain = false, boxes = false, surfaces = false, kinds = false, more = false;
     for (int i = 0; i < desc->nprims; i++) {
       const int type = desc->prims[i].type & 0xff, op = (desc->prims[i].type >> 8) & 0xff;
       if (((desc->prims[i].type >> 16) & 0xff) != 0) surfaces = true;
@@ -666,10 +667,11 @@ int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out) {
       if (type == RM_PRIM_REPEAT || type == RM_PRIM_FOLD) domain = true;
       if (type == RM_PRIM_BOX || type == RM_PRIM_TORUS || type == RM_PRIM_CYLINDER || type == RM_PRIM_PLANE) boxes = true;  // (RM_TABLE_NO_BOXES is a promise about spheres)
       if (type == RM_PRIM_KIND) kinds = true;
+      if (type > RM_PRIM_KIND || op > RM_OP_INTERSECT) more = true;
     }
     // (RM_TABLE_NO_BOXES promises a non-finite distance at a non-finite point: not said of a kind's estimator, so a kind row withdraws it)
     s->dev.table_flags = (spheres_smooth ? RM_TABLE_SPHERES_SMOOTH : 0) | (domain ? RM_TABLE_HAS_DOMAIN : 0) | (boxes || kinds ? 0 : RM_TABLE_NO_BOXES) |
-                         (surfaces ? RM_TABLE_HAS_SURFACES : 0) | (kinds ? RM_TABLE_HAS_KIND : 0);
+                         (surfaces ? RM_TABLE_HAS_SURFACES : 0) | (kinds ? RM_TABLE_HAS_KIND : 0) | (more ? RM_TABLE_MORE : 0);
     if (spheres_smooth && desc->nprims >= 2 && desc->nprims * 3 <= RM_MAX_PRIMS * 2) {  // one smooth-union radius for the whole table (the usual case): it travels as a kernel argument, and a compact image of the rows fits behind them in LDS
       bool one_k = true;
       for (int i = 2; i < desc->nprims; i++) one_k = one_k && desc->prims[i].k == desc->prims[1].k;

@@ -728,13 +728,16 @@ struct Sdf<RM_SCENE_TABLE> {
     const v3 c = V(a.z, a.w, b.x);
     return (type & 0xff) == RM_PRIM_SPHERE ? sdf_sphere<M>(q, c, b.y) : sd_box<M>(q - c, V(b.y, b.z, b.w));
   }
-  template <class M>
+  // MORE: the table uses ABI 8's shapes or smooth operators (RM_TABLE_MORE, kernel-uniform) -- compiled as a second copy of the fold, so that
+  // the tables of the older vocabulary keep the code they had (with the two operators and three shapes in ONE fold, a table of 192 rows of
+  // hard operators lost 12 %: 15.6 -> 17.6 ms at 1080p)
+  template <class M, bool MORE = false>
   static RM_DEV float apply_op(float d, float di, int op, float k) {
     if (op == RM_OP_UNION) return gmin(d, di);
     if (op == RM_OP_SMOOTH_UNION) return op_smooth_union<M>(d, di, k);
     if (op == RM_OP_SUBTRACT) return gmax(d, -di);
-    if (op == RM_OP_SMOOTH_SUBTRACT) return op_smooth_subtract<M>(d, di, k);
-    if (op == RM_OP_SMOOTH_INTERSECT) return op_smooth_intersect<M>(d, di, k);
+    if (MORE && op == RM_OP_SMOOTH_SUBTRACT) return op_smooth_subtract<M>(d, di, k);
+    if (MORE && op == RM_OP_SMOOTH_INTERSECT) return op_smooth_intersect<M>(d, di, k);
     return gmax(d, di);
   }
   // the distance term of a shape row other than a sphere or a kind: box, torus, capped cylinder, plane (about the row's centre)
@@ -843,6 +846,11 @@ struct Sdf<RM_SCENE_TABLE> {
   static RM_DEV float kind_row(const DevScene& sc, const SceneLds& lds, int kind, v3 at);
   template <class M, bool KINDS = false>
   static RM_DEV int surface_index(const DevScene& sc, const SceneLds& lds, v3 p) {
+    if (sc.table_flags & RM_TABLE_MORE) return surface_index_of<M, KINDS, true>(sc, lds, p);  // kernel-uniform
+    return surface_index_of<M, KINDS, false>(sc, lds, p);
+  }
+  template <class M, bool KINDS, bool MORE>
+  static RM_DEV int surface_index_of(const DevScene& sc, const SceneLds& lds, v3 p) {
     const bool domain = (sc.table_flags & RM_TABLE_HAS_DOMAIN) != 0;  // kernel-uniform
     float best = 0.0f, factor = 1.0f;
     int surface = 0;
@@ -867,7 +875,7 @@ struct Sdf<RM_SCENE_TABLE> {
       float di;
       if (prim == RM_PRIM_SPHERE) di = sdf_sphere<M>(q, c, b.y);
       else if (KINDS && prim == RM_PRIM_KIND) di = kind_row<M>(sc, lds, __builtin_amdgcn_readfirstlane((int)b.y), q - c);
-      else di = other_shape<M>(prim, q - c, b);
+      else di = MORE ? other_shape<M>(prim, q - c, b) : sd_box<M>(q - c, V(b.y, b.z, b.w));
       if (domain) di = di * factor;
       if (first || di < best) { best = di; surface = (type >> 16) & 0xff; }
       first = false;
@@ -885,6 +893,11 @@ struct Sdf<RM_SCENE_TABLE> {
   }
   template <class M, bool KINDS = false>
   static RM_DEV float eval_general(const DevScene& sc, const SceneLds& lds, v3 p) {
+    if (sc.table_flags & RM_TABLE_MORE) return eval_general_of<M, KINDS, true>(sc, lds, p);  // kernel-uniform
+    return eval_general_of<M, KINDS, false>(sc, lds, p);
+  }
+  template <class M, bool KINDS, bool MORE>
+  static RM_DEV float eval_general_of(const DevScene& sc, const SceneLds& lds, v3 p) {
     const bool domain = (sc.table_flags & RM_TABLE_HAS_DOMAIN) != 0;  // kernel-uniform
     float d = 0.0f, factor = 1.0f;
     bool first = true;
@@ -908,11 +921,11 @@ struct Sdf<RM_SCENE_TABLE> {
       float di;
       if (prim == RM_PRIM_SPHERE) di = sdf_sphere<M>(q, c, b.y);
       else if (KINDS && prim == RM_PRIM_KIND) di = kind_row<M>(sc, lds, __builtin_amdgcn_readfirstlane((int)b.y), q - c);
-      else di = other_shape<M>(prim, q - c, b);
+      else di = MORE ? other_shape<M>(prim, q - c, b) : sd_box<M>(q - c, V(b.y, b.z, b.w));
       if (domain) di = di * factor;
       if (first) { d = di; first = false; continue; }
       const int op = (type >> 8) & 0xff;
-      d = apply_op<M>(d, di, op, a.y);
+      d = apply_op<M, MORE>(d, di, op, a.y);
     }
     return d;
   }

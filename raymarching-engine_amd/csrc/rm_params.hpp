@@ -11,6 +11,7 @@
 #define RM_TABLE_NO_BOXES 8         /* no RM_PRIM_BOX row: the sdf of a point with a non-finite coordinate is itself non-finite */
 #define RM_TABLE_UNIFORM_K 4       /* RM_TABLE_SPHERES_SMOOTH with one k for every fold: k in p[0], 0.5 / k in p[1] */
 #define RM_TABLE_HAS_KIND 32      /* some shape row evaluates a scene kind's estimator (RM_PRIM_KIND): its own pixel kernel, no far-field exits, no row culling */
+#define RM_TABLE_MORE 64          /* some row uses ABI 8's vocabulary (torus / cylinder / plane, smooth subtraction / intersection): the second copy of the general fold */
 #define RM_TABLE_HAS_SURFACES 16   /* some shape row names a surface (RmPrim.type bits 16..23): the material functions depend on the position */
 
 #define RM_BATCH_MAX 8  /* samples one pixel-kernel launch can render (KParams::batch) */
