@@ -26,6 +26,18 @@ const rm = require("./index.js");
     process.stdout.write(JSON.stringify({ prims: Buffer.from(d.prims).toString("hex"), glsl: sc.glsl() }));
     return;
   }
+  if (mode === "shapes") {  // no GPU needed: ABI 8's shapes and smooth operators (tests/golden_cases.py csg_shapes), as the table and the surface rows
+    const sc = new rm.CsgScene().box([0.0, 0.0, 0.0], [1.25, 0.375, 1.0]).smoothSubtract(0.125).torus([0.0, 0.375, 0.0], 0.625, 0.1875)
+      .union().cylinder([0.875, 0.75, -0.25], 0.25, 0.5)
+      .smoothUnion(0.1875).torus([-0.75, 0.75, 0.25], 0.375, 0.125, { diffuse: [0.875, 0.5, 0.125], specular: [0.5, 0.5, 0.5], roughness: 0.375 })
+      .smoothIntersect(0.25).plane([0.0, 1.0, 0.0], [0.0, 1.0, 0.0])
+      .subtract().cylinder([-0.25, 0.0, 0.625], 0.1875, 1.0);
+    const d = sc.desc();
+    let refused = "";
+    try { sc.glsl(); } catch (e) { refused = e.message; }
+    process.stdout.write(JSON.stringify({ prims: Buffer.from(d.prims).toString("hex"), surfaces: Buffer.from(d.surfaces).toString("hex"), refused }));
+    return;
+  }
   if (mode === "kinds") {  // no GPU needed: a table whose rows evaluate a scene kind (RM_PRIM_KIND), as the description and the table
     const sc = new rm.CsgScene().shape(new rm.Mandelbulb(8, 5, 2)).intersect().box([0.0, 0.0, 0.25], [1.25, 1.25, 0.75])
       .subtract().sphere([0.5, 0.375, -0.5], 0.375, { diffuse: [0.875, 0.25, 0.125], specular: [0.5, 0.5, 0.5], roughness: 0.25 });

@@ -442,6 +442,37 @@ def test_render_job_host_replays_the_reference_loop_call_by_call():
         compare_host_events(k, schema, events, want)
 
 
+def test_pruned_flop_count_is_a_lower_count_of_the_same_image():
+    """bench.py's frac_useful prices the arithmetic the marches NEED: the counting oracle with or_set_count_pruned stops counting a march
+    at its bitwise fixed point or its certain escape (rm_oracle.c).  The image does not change, the count can only fall; and
+    profiles/flops_per_pixel.json holds a pruned entry next to every workload's full one, row for row."""
+    import json
+
+    import numpy as np
+
+    from raymarching_engine_amd import job as J, scene as S
+
+    sc = S.Mandelbulb()
+    schema = J.make_schema(sc, 48, 24, counts=(64,), render_mode="full", position=(0, 0, -2.5), lights=[J.point_light((2.0, 3.0, -4.0))])
+    u = J.uniforms_from_schema(schema, (0.5, 1.0 / 3.0))
+    rows = list(range(24))
+    try:
+        O.set_count_pruned(False)
+        full, img_full = O.render_rows(sc, u, 48, 24, rows, threads=2, count_flops=True)
+        O.set_count_pruned(True)
+        pruned, img_pruned = O.render_rows(sc, u, 48, 24, rows, threads=2, count_flops=True)
+    finally:
+        O.set_count_pruned(False)
+    assert 0 < pruned < full
+    a, b = np.asarray(img_full), np.asarray(img_pruned)
+    assert ((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all()
+    d = json.loads((Path(__file__).resolve().parents[1] / "profiles" / "flops_per_pixel.json").read_text())
+    for w in ("c2", "c3a", "c3b", "c4", "c5"):
+        f, p = d[w], d[w + "_pruned"]
+        assert (f["row_stride"], f["rows"], f["width"]) == (p["row_stride"], p["rows"], p["width"])
+        assert all(pr <= fr for pr, fr in zip(p["flops_per_row"], f["flops_per_row"])) and p["flops_per_pixel_sample"] < f["flops_per_pixel_sample"]
+
+
 def test_the_wavefront_pipeline_lives_in_the_cross_check_build_only():
     """Round 5: the second implementation of the per-pixel program (csrc/rm_wavefront.inc) is test infrastructure.  The product
     library holds none of its kernels; tests/_xcheck/libhip_raymarch_xcheck.so -- the same sources with -DRM_WITH_WAVEFRONT=1

@@ -62,6 +62,19 @@ def test_js_kind_rows_match_the_python_composer():
     assert "Python composer" in out["refused"] and out["mixed"] == "TypeError"
 
 
+def test_js_abi8_shapes_match_the_python_composer():
+    """Torus, capped cylinder, plane, smooth subtraction and intersection (ABI 8): the JS composer lays out the same table rows and
+    surface rows as the Python one for the scene of the `csg_shapes` goldens (its GLSL is the Python composer's to emit)."""
+    import ctypes as C
+
+    out = json.loads(subprocess.run(["node", str(JS / "render_cli.js"), "-", "shapes"], capture_output=True, text=True, check=True).stdout)
+    d = GC.build_scene("csg_shapes").desc()
+    assert d.nprims == 6 and d.nsurfaces == 1
+    assert out["prims"] == bytes(C.string_at(d.prims, 32 * d.nprims)).hex()
+    assert out["surfaces"] == bytes(C.string_at(d.surfaces, 48 * d.nsurfaces)).hex()
+    assert "Python composer" in out["refused"]
+
+
 def test_js_domain_operators_match_the_python_composer():
     """repeat / fold (the composition API's domain operators): the JS composer lays out the same table rows and the
     same GLSL statements as the Python one."""

@@ -23,13 +23,18 @@ schema = J.make_schema(sc, W, H, counts=(256,), render_mode="full", position=(0,
 h = ctx.create_scene(sc)
 noises = GC.halton_pairs(2)
 planes = {}
+xctx = native.Context(0, library=native.XCHECK_LIB_PATH) if not os.environ.get("RM_LIB") else None  # the wavefront pipeline: the tests' cross-check build
+xh = xctx.create_scene(sc) if xctx else None
 for name, flags in (("jump", F | NO), ("nojump", F | NO | NJ), ("wavefront", F | NO | abi.RM_RENDER_WAVEFRONT)):
-    fb = ctx.create_framebuffer(W, H)
+    c, hc = (xctx, xh) if name == "wavefront" else (ctx, h)
+    if c is None:
+        continue
+    fb = c.create_framebuffer(W, H)
     for nz in noises:
-        ctx.render_sample(h, fb, J.uniforms_from_schema(schema, nz), None, flags)
+        c.render_sample(hc, fb, J.uniforms_from_schema(schema, nz), None, flags)
     planes[name] = [fb.download(k) for k in range(3)]
     fb.destroy()
-for other in ("nojump", "wavefront"):
+for other in [o for o in ("nojump", "wavefront") if o in planes]:
     for k in range(3):
         a, b = planes["jump"][k], planes[other][k]
         same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))

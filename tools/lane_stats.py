@@ -11,7 +11,7 @@ sc = S.Mandelbulb(); kw = dict(width=3840, height=2160, counts=(256,), render_mo
 schema = J.make_schema(sc, **kw); h = ctx.create_scene(sc); fb = ctx.create_framebuffer(kw["width"], kw["height"])
 u = J.uniforms_from_schema(schema, (0.5, 1 / 3))
 out = (ctypes.c_ulonglong * 4)()
-for name, flags in (("megakernel", 1 | 4), ("wavefront", 1 | 16)):
+for name, flags in (("megakernel", 1 | 4),):  # (the wavefront pipeline is in the tests' cross-check build only since round 5)
     lib.rm_fast_lane_stats(out, 1)
     ctx.render_timed(h, fb, u, 1, None, flags)
     lib.rm_fast_lane_stats(out, 1)

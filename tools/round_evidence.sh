@@ -29,6 +29,8 @@ else
   python3 tools/emulate_ranks.py > $O/shard_emulation.txt 2>&1
   EMU_YIELD=1 python3 tools/emulate_ranks.py >> $O/shard_emulation.txt 2>&1
   python3 tools/time_present.py > $O/present_by_parts.txt 2>&1
+  SPP=32 python3 tools/normal_study.py default > $O/normal_study.txt 2>&1
+  python3 tools/small_kernels_probe.py > $O/small_kernels.txt 2>&1
   RM_BENCH_SHARE_GPU=1 RM_BENCH_BACKEND=gloo python3 bench.py --gpus 4 --steps 16 --warmup 8 --no-cpu-baseline --check-frame --dof > $O/bench_ranks_sharing_dof.txt 2>&1
   RM_BENCH_SHARE_GPU=1 RM_BENCH_BACKEND=gloo python3 bench.py --gpus 4 --steps 16 --warmup 8 --no-cpu-baseline --check-frame > $O/bench_ranks_sharing.txt 2>&1
   bash tools/fuzz.sh $R > $O/fuzz_stdout.txt 2>&1
