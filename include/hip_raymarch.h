@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RM_ABI_VERSION 8 /* 8: RM_PRIM_TORUS / _CYLINDER / _PLANE, RM_OP_SMOOTH_SUBTRACT / _INTERSECT (additions only); 7: rm_present_sharded_finish / rm_present_sharded take the size of the host buffer (a changed signature), rm_ctx_set_cull_min_pixels, rm_ctx_cull_stats; 6: rm_present_striped_rows, rm_present_sharded_start / _finish, rm_ctx_last_warning, RM_PROBE_CAST_SHADOW, RM_PRIM_KIND (additions only); 3: rm_ctx_set_sample_batch, rm_buffer_*; 4: rm_ctx_set_gl_stack; 5: RmSurface / RmSceneDesc.surfaces (the struct grew), rm_pack_present_rows, rm_present_sharded, rm_ctx_last_pipeline, RM_RENDER_NO_FAR_JUMP, RM_RENDER_NO_CULL (additions only) */
+#define RM_ABI_VERSION 8 /* 8: RM_PRIM_TORUS / _CYLINDER / _PLANE, RM_OP_SMOOTH_SUBTRACT / _INTERSECT (additions only); 7: rm_present_sharded_finish / rm_present_sharded take the size of the host buffer (a changed signature), rm_ctx_set_cull_min_pixels, rm_ctx_set_cull_budget, rm_ctx_cull_stats; 6: rm_present_striped_rows, rm_present_sharded_start / _finish, rm_ctx_last_warning, RM_PROBE_CAST_SHADOW, RM_PRIM_KIND (additions only); 3: rm_ctx_set_sample_batch, rm_buffer_*; 4: rm_ctx_set_gl_stack; 5: RmSurface / RmSceneDesc.surfaces (the struct grew), rm_pack_present_rows, rm_present_sharded, rm_ctx_last_pipeline, RM_RENDER_NO_FAR_JUMP, RM_RENDER_NO_CULL (additions only) */
 
 #define RM_MAX_BOUNCES 10 /* raymarchingStepCountsArray[10], raymarcher.frag:31 */
 #define RM_MAX_LIGHTS 10  /* lightPositions[10],             raymarcher.frag:37-39 */
@@ -326,6 +326,7 @@ int rm_ctx_set_gl_stack(rm_ctx* ctx, int on);
  * budget in bytes (a sixteenth of the device's memory, at most 1 GiB: beyond it the least recently rendered scene gives its
  * grid up and renders on without one)}. */
 int rm_ctx_set_cull_min_pixels(rm_ctx* ctx, long long pixels);
+int rm_ctx_set_cull_budget(rm_ctx* ctx, size_t bytes); /* the bytes a context's grids may hold (a host that knows its memory better; the tests: small, to see grids go) */
 int rm_ctx_cull_stats(const rm_ctx* ctx, unsigned long long* out4);
 /* Diagnostics of the wavefront march, filled only by builds compiled with
  * -DRM_WF_STATS (zeros otherwise): out16[8*shadow + 4*pass2 + {0,1,2}] =

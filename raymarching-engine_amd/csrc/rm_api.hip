@@ -1030,6 +1030,12 @@ int rm_ctx_set_cull_min_pixels(rm_ctx* ctx, long long pixels) {
   return RM_OK;
 }
 
+int rm_ctx_set_cull_budget(rm_ctx* ctx, size_t bytes) {
+  if (!ctx) return RM_ERR_INVALID;
+  ctx->cull_budget = bytes;  // (grids held beyond it go as new ones come: scene_cull_grid)
+  return RM_OK;
+}
+
 int rm_ctx_cull_stats(const rm_ctx* ctx, unsigned long long* out4) {
   if (!ctx || !out4) return RM_ERR_INVALID;
   out4[0] = ctx->cull_built;

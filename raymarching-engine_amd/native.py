@@ -32,7 +32,7 @@ LIB_PATH = Path(os.environ.get("RM_LIB") or Path(__file__).resolve().parent / "l
 # every symbol include/hip_raymarch.h declares
 EXPORTS = [
     "rm_abi_version", "rm_material_default", "rm_ctx_create", "rm_ctx_destroy", "rm_last_error", "rm_ctx_set_stream",
-    "rm_ctx_set_retire_eps", "rm_ctx_set_samples_in_flight", "rm_ctx_last_warning", "rm_ctx_set_cost_order", "rm_ctx_set_cull_min_pixels", "rm_ctx_cull_stats", "rm_debug_counters", "rm_device_memory", "rm_sync", "rm_scene_create", "rm_scene_destroy", "rm_fb_create", "rm_fb_create_striped", "rm_fb_rows", "rm_fb_width", "rm_fb_height", "rm_fb_wrap", "rm_fb_clear", "rm_fb_destroy",
+    "rm_ctx_set_retire_eps", "rm_ctx_set_samples_in_flight", "rm_ctx_last_warning", "rm_ctx_set_cost_order", "rm_ctx_set_cull_min_pixels", "rm_ctx_set_cull_budget", "rm_ctx_cull_stats", "rm_debug_counters", "rm_device_memory", "rm_sync", "rm_scene_create", "rm_scene_destroy", "rm_fb_create", "rm_fb_create_striped", "rm_fb_rows", "rm_fb_width", "rm_fb_height", "rm_fb_wrap", "rm_fb_clear", "rm_fb_destroy",
     "rm_fb_download", "rm_fb_upload", "rm_fb_device_ptr", "rm_buffer_create", "rm_buffer_destroy", "rm_buffer_download", "rm_buffer_upload", "rm_render_sample", "rm_render_samples", "rm_ctx_set_sample_batch", "rm_ctx_set_gl_stack", "rm_render_timed",
     "rm_probe", "rm_probe_camera", "rm_probe_rng", "rm_assemble_striped", "rm_assemble_striped_bytes", "rm_present", "rm_present_planes", "rm_present_device", "rm_present_rows", "rm_pack_present_rows", "rm_ctx_last_pipeline", "rm_present_sharded", "rm_present_sharded_start", "rm_present_sharded_finish", "rm_present_striped_rows", "rm_debug_cull_cell",
 ]
@@ -124,6 +124,7 @@ def load_library(path=None):
         "rm_buffer_upload": (ip, [vp, vp, vp, C.c_size_t]),
         "rm_ctx_set_cost_order": (ip, [vp, C.c_int]),
         "rm_ctx_set_cull_min_pixels": (ip, [vp, C.c_longlong]),
+        "rm_ctx_set_cull_budget": (ip, [vp, C.c_size_t]),
         "rm_ctx_cull_stats": (ip, [vp, C.POINTER(C.c_ulonglong)]),
         "rm_debug_counters": (ip, [vp, C.POINTER(C.c_ulonglong), ip]),
         "rm_debug_cull_cell": (ip, [C.POINTER(abi.RmSceneDesc), C.POINTER(C.c_double), C.c_double, C.c_double, C.POINTER(C.c_ulonglong)]),
@@ -351,6 +352,11 @@ class Context:
         """Pixel-samples a scene has to be asked for before its culling grid is built (0: with the first render; same bits)."""
         self.settings["set_cull_min_pixels"] = (pixels,)
         self._check(self.lib.rm_ctx_set_cull_min_pixels(self.h, int(pixels)))
+
+    def set_cull_budget(self, nbytes: int):
+        """The bytes this context's culling grids may hold together (default: a sixteenth of the device's memory, at most 1 GiB)."""
+        self.settings["set_cull_budget"] = (nbytes,)
+        self._check(self.lib.rm_ctx_set_cull_budget(self.h, int(nbytes)))
 
     def cull_stats(self) -> dict:
         out = (C.c_ulonglong * 4)()

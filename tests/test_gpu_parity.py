@@ -1911,6 +1911,44 @@ def test_a_scene_earns_its_culling_grid_and_a_new_scene_every_frame_stays_exact(
         ctx.set_cull_min_pixels(0)
 
 
+def test_culling_grids_stay_within_their_budget_and_give_way_exactly(ctx):
+    """A context's culling grids are held within a byte budget: with room for two of CSG-64's (31.5 MB each), four scenes rendered in
+    turn, several rounds, keep pushing one another's grids out -- the least recently rendered first, its buffer handed to the next build
+    while samples that read it may still be in flight (the build is ordered behind them) -- and a scene that lost its grid renders on
+    without one and earns it back.  Every frame has the bits of the fold of every row (RM_RENDER_NO_CULL)."""
+    NC = abi.RM_RENDER_NO_CULL
+    rng = np.random.default_rng(8128 + SEED_OFFSET)
+    scenes = [S.csg64()] + [_smooth_sphere_table(rng, 64, one_k=True) for _ in range(3)]
+    schemas = [J.make_schema(t, 320, 224, counts=(96,), render_mode="full", position=(0.0, 0.0, -5.0) if i == 0 else (0.3, 0.2, -6.0), lights=GC.LIGHT) for i, t in enumerate(scenes)]
+    noises = GC.halton_pairs(2)
+    want = [render_gpu(ctx, t, sch, noises, FAST | MK | NC) for t, sch in zip(scenes, schemas)]
+    st0 = ctx.cull_stats()
+    try:
+        ctx.set_cull_budget(70 << 20)
+        ctx.set_cull_min_pixels(0)
+        handles = [ctx.create_scene(t) for t in scenes]
+        held = []
+        for rnd in range(4):
+            for i in ([0, 1, 2, 3] if rnd % 2 == 0 else [2, 0, 3, 1]):
+                fb = ctx.create_framebuffer(320, 224)
+                for n in noises:
+                    ctx.render_sample(handles[i], fb, J.uniforms_from_schema(schemas[i], tuple(n)), None, FAST | MK)
+                got = [fb.download(k) for k in range(3)]
+                fb.destroy()
+                for k in range(3):
+                    assert same_bits(got[k], want[i][k]).all(), f"round {rnd}, scene {i}, plane {k}"
+                st = ctx.cull_stats()
+                assert st["bytes"] <= st["budget"] and st["grids"] <= 2
+                held.append(st["grids"])
+        assert max(held) == 2 and ctx.cull_stats()["built"] - st0["built"] >= 8  # grids went and were rebuilt
+        for h in handles:
+            h.destroy()
+        assert ctx.cull_stats()["grids"] == 0 and ctx.cull_stats()["bytes"] == 0
+    finally:
+        ctx.set_cull_budget(st0["budget"])
+        ctx.set_cull_min_pixels(0)
+
+
 def test_fast_build_tolerance_is_anchored_to_the_spread_between_glsl_legal_arithmetics(ctx):
     """Headline frame (3840x2160, full, [256], the light), 4 samples per pixel, same random stream in all three renders:
     fast against strict, and GL-stack strict against default strict.  For the whole frame, for the pixels that show the
