@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RM_ABI_VERSION 8 /* 8: RM_PRIM_TORUS / _CYLINDER / _PLANE, RM_OP_SMOOTH_SUBTRACT / _INTERSECT (additions only); 7: rm_present_sharded_finish / rm_present_sharded take the size of the host buffer (a changed signature), rm_ctx_set_cull_min_pixels, rm_ctx_set_cull_budget, rm_ctx_cull_stats; 6: rm_present_striped_rows, rm_present_sharded_start / _finish, rm_ctx_last_warning, RM_PROBE_CAST_SHADOW, RM_PRIM_KIND (additions only); 3: rm_ctx_set_sample_batch, rm_buffer_*; 4: rm_ctx_set_gl_stack; 5: RmSurface / RmSceneDesc.surfaces (the struct grew), rm_pack_present_rows, rm_present_sharded, rm_ctx_last_pipeline, RM_RENDER_NO_FAR_JUMP, RM_RENDER_NO_CULL (additions only) */
+#define RM_ABI_VERSION 8 /* 8: RM_PRIM_TORUS / _CYLINDER / _PLANE, RM_OP_SMOOTH_SUBTRACT / _INTERSECT, rm_probe_math (additions only); 7: rm_present_sharded_finish / rm_present_sharded take the size of the host buffer (a changed signature), rm_ctx_set_cull_min_pixels, rm_ctx_set_cull_budget, rm_ctx_cull_stats; 6: rm_present_striped_rows, rm_present_sharded_start / _finish, rm_ctx_last_warning, RM_PROBE_CAST_SHADOW, RM_PRIM_KIND (additions only); 3: rm_ctx_set_sample_batch, rm_buffer_*; 4: rm_ctx_set_gl_stack; 5: RmSurface / RmSceneDesc.surfaces (the struct grew), rm_pack_present_rows, rm_present_sharded, rm_ctx_last_pipeline, RM_RENDER_NO_FAR_JUMP, RM_RENDER_NO_CULL (additions only) */
 
 #define RM_MAX_BOUNCES 10 /* raymarchingStepCountsArray[10], raymarcher.frag:31 */
 #define RM_MAX_LIGHTS 10  /* lightPositions[10],             raymarcher.frag:37-39 */
@@ -467,6 +467,18 @@ int rm_probe_camera(rm_ctx* ctx, const RmUniforms* uniforms, int width, int heig
  * of a width x height image the first `count` values of uniformSample().
  * out = height*width*count floats, HOST pointer. */
 int rm_probe_rng(rm_ctx* ctx, const RmUniforms* uniforms, int width, int height, int count, float* out);
+
+/* The transcendental functions of the parity arithmetic on arrays, as the kernels call them: the fp32 sequences of
+ * csrc/rm_pm_math.hpp (the text of oracle/pm_math.h), or the GL stack's (rm_ss_math.hpp = oracle/ss_math.h) on a context
+ * with rm_ctx_set_gl_stack -- so that "the same bits as the oracle" is tested function by function on millions of
+ * arguments, not only through rendered frames.  POW is pow(|a|, b) (the oracle's gl_pow), ATAN2 atan(a, b) with a = y,
+ * TAN the portable tangent of the random stream and camera (oracle/rm_oracle.c or_tan); POW_PAIR_NM1 / _N are
+ * pow(a, b - 1) / pow(a, b) from one logarithm and SINCOS_S / _C sin / cos from one reduction, the shared forms the
+ * Mandelbulb uses (they must have the bits of the separate calls).  a, b, out: HOST pointers to n floats; b may be NULL
+ * for the functions of one argument.  Test infrastructure like rm_probe: no part of a render job calls it. */
+enum { RM_MATH_SIN = 0, RM_MATH_COS = 1, RM_MATH_LOG = 2, RM_MATH_EXP = 3, RM_MATH_POW = 4, RM_MATH_ACOS = 5, RM_MATH_ATAN2 = 6, RM_MATH_TAN = 7,
+       RM_MATH_POW_PAIR_NM1 = 8, RM_MATH_POW_PAIR_N = 9, RM_MATH_SINCOS_S = 10, RM_MATH_SINCOS_C = 11, RM_MATH_SQRT = 12, RM_MATH_DIV = 13, RM_MATH_COUNT = 14 };
+int rm_probe_math(rm_ctx* ctx, int fn, const float* a, const float* b, int n, float* out);
 
 /* ---- assembling a sharded frame ------------------------------------------ */
 

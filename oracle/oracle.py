@@ -56,6 +56,7 @@ def _lib(count: bool = False):
         lib.or_set_math_mode.argtypes = [C.c_int]
         lib.or_set_math_round_bits.argtypes = [C.c_int]
         lib.or_ss_math.argtypes = [C.c_int, fp, fp, C.c_int, fp]
+        lib.or_math.argtypes = [C.c_int, fp, fp, C.c_int, fp]
         _libs[key] = lib
     return _libs[key]
 
@@ -91,6 +92,18 @@ def ss_math(name: str, a: np.ndarray, b: np.ndarray = None) -> np.ndarray:
     b = np.ascontiguousarray(b, np.float32) if b is not None else None
     out = np.empty_like(a)
     _lib().or_ss_math(SS_FUNCTIONS.index(name), _fp(a), _fp(b) if b is not None else None, a.size, _fp(out))
+    return out
+
+
+MATH_FUNCTIONS = ("sin", "cos", "log", "exp", "pow", "acos", "atan2", "tan", "pow_pair_nm1", "pow_pair_n", "sincos_s", "sincos_c", "sqrt", "div")
+
+
+def math(name: str, a: np.ndarray, b: np.ndarray = None) -> np.ndarray:
+    """One function of the current arithmetic (set_math) on an array, numbered like hip_raymarch.h RM_MATH_* (rm_oracle.c or_math)."""
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32) if b is not None else None
+    out = np.empty_like(a)
+    _lib().or_math(MATH_FUNCTIONS.index(name), _fp(a), _fp(b) if b is not None else None, a.size, _fp(out))
     return out
 
 

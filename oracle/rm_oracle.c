@@ -170,6 +170,31 @@ static float or_tan(float x) {
   return (odd > 0.5f) ? (-c / s) : (s / c);
 }
 
+/* The transcendentals of the parity arithmetic on arrays, numbered like include/hip_raymarch.h RM_MATH_* (rm_probe_math is the
+ * HIP side): in the current or_set_math mode -- the fp32 sequences of pm_math.h, or the GL stack's ss_math.h.  The shared
+ * forms (8-11) are written here as the two separate calls whose bits they must have. */
+void or_math(int which, const float* a, const float* b, int n, float* out) {
+  for (int i = 0; i < n; i++) {
+    const float x = a[i], y = b ? b[i] : 0.0f;
+    float r = 0.0f;
+    switch (which) {
+      case 0: case 10: r = o_sin(x); break;
+      case 1: case 11: r = o_cos(x); break;
+      case 2: r = o_log(x); break;
+      case 3: r = o_exp(x); break;
+      case 4: case 9: r = o_pow(or_math_mode == OR_MATH_SWIFTSHADER ? x : fabsf(x), y); break; /* gl_pow */
+      case 5: r = o_acos(x); break;
+      case 6: r = o_atan2(x, y); break;
+      case 7: r = or_tan(x); break;
+      case 8: r = o_pow(or_math_mode == OR_MATH_SWIFTSHADER ? x : fabsf(x), y - 1.0f); break;
+      case 12: r = sqrtf(x); break;
+      case 13: r = x / y; break;
+      default: break;
+    }
+    out[i] = r;
+  }
+}
+
 /* ---- GLSL built-ins (GLSL ES 3.00 section 8) ---------------------------- */
 
 typedef struct { float x, y, z; } v3;
@@ -214,7 +239,9 @@ static inline float gl_sign(float x) { FL(1); return (float)((x > 0.0f) - (x < 0
  * below (SwiftShader: bit-exact on 16k smooth-union folds, oracle/gl/gen_golden.py) */
 static inline float gl_mix(float x, float y, float a) { FL(3); return x + a * (y - x); }
 /* pow(x,y) for x < 0 is undefined in GLSL; SwiftShader evaluates it on |x| (probed) */
-static inline float gl_pow(float x, float y) { FL(2); return o_pow(fabsf(x), y); }
+/* pow on |x| (GLSL leaves a negative base undefined); the GL stack's own pow takes x as it comes -- its logarithm drops the
+ * sign bit itself, so only pow(-Inf, y) differs (rm_probe_math asks) -- and the kernels' GL-stack build does the same */
+static inline float gl_pow(float x, float y) { FL(2); return o_pow(or_math_mode == OR_MATH_SWIFTSHADER ? x : fabsf(x), y); }
 
 static inline v3 V(float x, float y, float z) { v3 r = {x, y, z}; return r; }
 static inline v3 vadd(v3 a, v3 b) { FL(3); return V(a.x + b.x, a.y + b.y, a.z + b.z); }

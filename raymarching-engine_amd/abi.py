@@ -22,6 +22,7 @@ RM_RENDER_NO_CULL = 128
 RM_PIPELINE_NONE, RM_PIPELINE_PIXEL_KERNEL, RM_PIPELINE_WAVEFRONT = 0, 1, 2
 RM_PLANE_COLOR, RM_PLANE_NORMAL_DOF, RM_PLANE_ALBEDO_DEPTH = 0, 1, 2
 RM_PROBE_SDF, RM_PROBE_CAST_RAY, RM_PROBE_NORMAL, RM_PROBE_MATERIAL, RM_PROBE_CAST_STEPS, RM_PROBE_CAST_SHADOW = 0, 1, 2, 3, 4, 5
+RM_MATH_FUNCTIONS = ("sin", "cos", "log", "exp", "pow", "acos", "atan2", "tan", "pow_pair_nm1", "pow_pair_n", "sincos_s", "sincos_c", "sqrt", "div")  # RM_MATH_*
 
 
 class RmUniforms(C.Structure):

@@ -29,6 +29,7 @@
 extern "C" {
 hipError_t rm_gl_launch_pixels(const void* kparams, hipStream_t stream);
 hipError_t rm_gl_launch_probe(const void* probe_params, hipStream_t stream);
+hipError_t rm_gl_launch_math_probe(int fn, const float* a, const float* b, int n, float* out, hipStream_t stream);
 hipError_t rm_gl_launch_camera_rng(const RmUniforms* u, int W, int H, int what, int count, float* out, hipStream_t stream);
 hipError_t rm_gl_launch_present(const float4* color, const float4* normal_dof, int W, int H, float brightness, uchar4* out, hipStream_t stream);
 hipError_t rm_gl_launch_present_striped(const float4* color, const float4* normal_dof, int W, int H, float brightness, uchar4* out, int stripe_rows, int parts,
@@ -1853,6 +1854,26 @@ static int camera_rng(rm_ctx* ctx, const RmUniforms* u, int width, int height, i
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   (void)hipFree(d_out);
   if (e != hipSuccess) return fail(ctx, RM_ERR_DEVICE, std::string("probe: ") + hipGetErrorString(e));
+  return RM_OK;
+}
+
+int rm_probe_math(rm_ctx* ctx, int fn, const float* a, const float* b, int n, float* out) {
+  if (!ctx || !a || !out || n < 1 || fn < 0 || fn >= RM_MATH_COUNT) return fail(ctx, RM_ERR_INVALID, "rm_probe_math: bad argument");
+  const bool two = fn == RM_MATH_POW || fn == RM_MATH_ATAN2 || fn == RM_MATH_POW_PAIR_NM1 || fn == RM_MATH_POW_PAIR_N || fn == RM_MATH_DIV;
+  if (two && !b) return fail(ctx, RM_ERR_INVALID, "rm_probe_math: this function takes two arguments");
+  RM_HIP(ctx, hipSetDevice(ctx->device));
+  float* d = nullptr;  // a | b | out
+  const size_t bytes = sizeof(float) * (size_t)n;
+  RM_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&d), 3 * bytes));
+  hipError_t e = hipMemcpyAsync(d, a, bytes, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && two) e = hipMemcpyAsync(d + n, b, bytes, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess)
+    e = ctx->gl_stack ? rm_gl_launch_math_probe(fn, d, two ? d + n : nullptr, n, d + 2 * (size_t)n, ctx->stream)
+                      : rm::launch_math_probe(fn, d, two ? d + n : nullptr, n, d + 2 * (size_t)n, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d + 2 * (size_t)n, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(ctx, RM_ERR_DEVICE, std::string("rm_probe_math: ") + hipGetErrorString(e));
   return RM_OK;
 }
 

@@ -26,6 +26,9 @@ hipError_t rm_gl_launch_present_striped(const float4* color, const float4* norma
                                         int part, int local_rows, hipStream_t stream) {
   return rm_gl::launch_present_striped(color, normal_dof, W, H, brightness, out, stripe_rows, parts, part, local_rows, stream);
 }
+hipError_t rm_gl_launch_math_probe(int fn, const float* a, const float* b, int n, float* out, hipStream_t stream) {
+  return rm_gl::launch_math_probe(fn, a, b, n, out, stream);
+}
 hipError_t rm_gl_set_native_tan(int on, hipStream_t) {  // synchronous: the source is the caller's stack
   return hipMemcpyToSymbol(HIP_SYMBOL(rm_gl::g_native_tan), &on, sizeof on, 0, hipMemcpyHostToDevice);
 }

@@ -333,4 +333,5 @@ hipError_t launch_pixels_fast(const KParams& P, hipStream_t stream);
 hipError_t launch_probe_strict(const ProbeParams& P, hipStream_t stream);
 hipError_t launch_probe_fast(const ProbeParams& P, hipStream_t stream);
 hipError_t launch_camera_rng(const RmUniforms& u, int W, int H, int what, int count, float* out, hipStream_t stream);
+hipError_t launch_math_probe(int fn, const float* a, const float* b, int n, float* out, hipStream_t stream);
 }  // namespace rm

@@ -34,7 +34,7 @@ EXPORTS = [
     "rm_abi_version", "rm_material_default", "rm_ctx_create", "rm_ctx_destroy", "rm_last_error", "rm_ctx_set_stream",
     "rm_ctx_set_retire_eps", "rm_ctx_set_samples_in_flight", "rm_ctx_last_warning", "rm_ctx_set_cost_order", "rm_ctx_set_cull_min_pixels", "rm_ctx_set_cull_budget", "rm_ctx_cull_stats", "rm_debug_counters", "rm_device_memory", "rm_sync", "rm_scene_create", "rm_scene_destroy", "rm_fb_create", "rm_fb_create_striped", "rm_fb_rows", "rm_fb_width", "rm_fb_height", "rm_fb_wrap", "rm_fb_clear", "rm_fb_destroy",
     "rm_fb_download", "rm_fb_upload", "rm_fb_device_ptr", "rm_buffer_create", "rm_buffer_destroy", "rm_buffer_download", "rm_buffer_upload", "rm_render_sample", "rm_render_samples", "rm_ctx_set_sample_batch", "rm_ctx_set_gl_stack", "rm_render_timed",
-    "rm_probe", "rm_probe_camera", "rm_probe_rng", "rm_assemble_striped", "rm_assemble_striped_bytes", "rm_present", "rm_present_planes", "rm_present_device", "rm_present_rows", "rm_pack_present_rows", "rm_ctx_last_pipeline", "rm_present_sharded", "rm_present_sharded_start", "rm_present_sharded_finish", "rm_present_striped_rows", "rm_debug_cull_cell",
+    "rm_probe", "rm_probe_camera", "rm_probe_rng", "rm_probe_math", "rm_assemble_striped", "rm_assemble_striped_bytes", "rm_present", "rm_present_planes", "rm_present_device", "rm_present_rows", "rm_pack_present_rows", "rm_ctx_last_pipeline", "rm_present_sharded", "rm_present_sharded_start", "rm_present_sharded_finish", "rm_present_striped_rows", "rm_debug_cull_cell",
 ]
 
 
@@ -148,6 +148,7 @@ def load_library(path=None):
         "rm_probe": (ip, [vp, vp, ip, fp, ip, C.c_float, ip, fp]),
         "rm_probe_camera": (ip, [vp, C.POINTER(abi.RmUniforms), ip, ip, fp]),
         "rm_probe_rng": (ip, [vp, C.POINTER(abi.RmUniforms), ip, ip, ip, fp]),
+        "rm_probe_math": (ip, [vp, ip, fp, fp, ip, fp]),
         "rm_assemble_striped": (ip, [vp, vp, ip, ip, ip, ip, ip, vp, vp]),
         "rm_assemble_striped_bytes": (ip, [vp, vp, ip, ip, C.c_longlong, ip, ip, vp, vp]),
         "rm_present_device": (ip, [vp, vp, vp, ip, ip, ip, vp, vp]),
@@ -419,6 +420,14 @@ class Context:
     def probe_rng(self, uniforms: abi.RmUniforms, width: int, height: int, count: int) -> np.ndarray:
         out = np.empty((height, width, count), np.float32)
         self._check(self.lib.rm_probe_rng(self.h, C.byref(uniforms), width, height, count, _fp(out)))
+        return out
+
+    def probe_math(self, name: str, a: np.ndarray, b: np.ndarray = None) -> np.ndarray:
+        """One transcendental of this context's parity arithmetic on an array (rm_probe_math; name: abi.RM_MATH_FUNCTIONS)."""
+        a = np.ascontiguousarray(a, np.float32).ravel()
+        b = np.ascontiguousarray(b, np.float32).ravel() if b is not None else None
+        out = np.empty_like(a)
+        self._check(self.lib.rm_probe_math(self.h, abi.RM_MATH_FUNCTIONS.index(name), _fp(a), _fp(b) if b is not None else None, a.size, _fp(out)))
         return out
 
 

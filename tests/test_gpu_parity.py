@@ -155,6 +155,72 @@ def test_rng_stream_bits_4k(ctx):
     assert same_bits(got, O.rng(u, 3840, 16, 3)).all()
 
 
+def math_arguments(name, n, seed):
+    """Arguments for one function of the parity arithmetic: every kind of bit pattern (NaN, infinities, denormals, both zeros),
+    the function's own interesting ranges densely, the neighbourhoods of its breakpoints, and what the path feeds it."""
+    rng = np.random.default_rng(seed)
+    specials = np.array([0.0, -0.0, 1.0, -1.0, 2.0, 0.5, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1.1754942e-38, 1.17549435e-38, 3.4028235e38, -3.4028235e38,
+                         np.pi, -np.pi, np.pi / 2, np.pi / 4, 88.72284, -87.33655, -103.97, 0.99999994, 1.0000001, 0.70710677, 8.0, 7.0], np.float32)
+    bits = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+
+    def near(values, ulps=64):
+        v = np.repeat(np.asarray(values, np.float32), 2 * ulps + 1).view(np.int32) + np.tile(np.arange(-ulps, ulps + 1, dtype=np.int32), len(values))
+        return v.view(np.float32)
+
+    def pick(*parts):
+        v = np.concatenate([np.asarray(q, np.float32).ravel() for q in parts])
+        return v[rng.permutation(v.size)]
+
+    u = lambda lo, hi, k=n: rng.uniform(lo, hi, k).astype(np.float32)
+    logu = lambda lo, hi, k=n: np.exp(rng.uniform(np.log(lo), np.log(hi), k)).astype(np.float32) * rng.choice(np.float32([-1, 1]), k)
+    if name in ("sin", "cos", "tan", "sincos_s", "sincos_c"):
+        a = pick(specials, bits, u(-8, 8), u(-1e3, 1e3), logu(1e-30, 1e12), near(np.arange(-40, 41) * np.float32(np.pi / 4)))
+        return a, None
+    if name == "log":
+        return pick(specials, bits, np.abs(logu(1e-44, 3e38)), u(0.5, 2.0), near([1.0, 0.5, 2.0, 0.70710677, 1.4142135])), None
+    if name == "exp":
+        return pick(specials, bits, u(-110, 95), u(-1, 1), near([0.0, 88.72284, -87.33655, -103.2789, 0.34657359, -0.34657359])), None
+    if name == "acos":
+        return pick(specials, bits, u(-1.01, 1.01), near([1.0, -1.0, 0.5, -0.5, 0.0])), None
+    if name == "sqrt":
+        return pick(specials, bits, np.abs(logu(1e-44, 3e38))), None
+    if name == "atan2":
+        a = pick(specials, bits, u(-4, 4), logu(1e-30, 1e30))
+        b = pick(specials[::-1], bits[::-1], u(-4, 4), logu(1e-30, 1e30))
+        k = min(a.size, b.size)
+        a, b = a[:k].copy(), b[:k].copy()
+        a[: specials.size ** 2] = np.repeat(specials, specials.size)  # every pair of the special values
+        b[: specials.size ** 2] = np.tile(specials, specials.size)
+        return a, b
+    if name == "div":
+        a, b = pick(specials, bits, logu(1e-40, 1e38)), pick(bits[::-1], specials, logu(1e-40, 1e38))
+        return a, b
+    # pow and the pair: any bits; bases and exponents of a shader's size; the Mandelbulb's radii with its exponents; the specular term
+    base = pick(specials, bits, np.abs(logu(1e-30, 1e30)), u(0, 4), u(0, 2, 2 * n), u(0, 1))
+    expo = pick(bits[::-1], specials, u(-12, 12), u(-60, 60), rng.choice(np.float32([8, 7, 2, 3, 1, 0, -1, 0.5, 5, 2.4, 1 / 2.2]), 2 * n), u(0, 64))
+    k = min(base.size, expo.size)
+    base, expo = base[:k].copy(), expo[:k].copy()
+    base[: specials.size ** 2] = np.repeat(specials, specials.size)
+    expo[: specials.size ** 2] = np.tile(specials, specials.size)
+    return base, expo
+
+
+@pytest.mark.parametrize("name", abi.RM_MATH_FUNCTIONS)
+def test_transcendentals_of_the_parity_arithmetic_have_the_oracles_bits(ctx, name):
+    """Strict build == oracle rests on csrc/rm_pm_math.hpp and oracle/pm_math.h being one text AND on hipcc and gcc both compiling
+    that text into the operations it names.  Frames test that through the few thousand arguments a scene produces; this
+    asks each function directly, on several million arguments of every kind (rm_probe_math), the shared forms included:
+    pow_pair (two powers from one logarithm) and sincos (one reduction) must have the bits of the separate calls."""
+    a, b = math_arguments(name, 400_000, 20260 + abi.RM_MATH_FUNCTIONS.index(name))
+    got = ctx.probe_math(name, a, b)
+    want = O.math(name, a, b)
+    eq = same_bits(got, want)
+    bad = np.flatnonzero(~eq)
+    assert eq.all(), f"{name}: {bad.size} of {a.size} differ, e.g. " + "; ".join(
+        f"f({a[i]!r}{'' if b is None else ', ' + repr(b[i])}) = {got[i]!r} (0x{got[i:i+1].view(np.uint32)[0]:08x}) vs oracle {want[i]!r} (0x{want[i:i+1].view(np.uint32)[0]:08x})"
+        for i in bad[:6])
+
+
 @pytest.mark.parametrize("mode", ["perspective", "orthographic", "panoramic"])
 def test_camera_block(ctx, mode):
     schema = J.make_schema(GC.build_scene("sphere"), 240, 135, camera=mode, rotation=GC.ROT, position=(0.3, -0.2, -3.0), dof_distance=2.5)

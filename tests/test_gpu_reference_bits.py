@@ -54,6 +54,24 @@ def test_cast_ray_and_normal_are_the_reference_bit_for_bit(glctx, name):
     h.destroy()
 
 
+@pytest.mark.parametrize("name", abi.RM_MATH_FUNCTIONS)
+def test_gl_stack_transcendentals_have_the_oracles_bits_on_the_gpu(glctx, name):
+    """The GL stack's functions as the kernels compile them (csrc/rm_ss_math.hpp) against the oracle's (oracle/ss_math.h, itself
+    pinned by tests/golden/swiftshader_math.npz), argument by argument (rm_probe_math on a GL-stack context)."""
+    from test_gpu_parity import math_arguments
+
+    a, b = math_arguments(name, 200_000, 515 + abi.RM_MATH_FUNCTIONS.index(name))
+    O.set_math_mode(O.MATH_SWIFTSHADER)
+    try:
+        want = O.math(name, a, b)
+    finally:
+        O.set_math_mode(O.MATH_PORTABLE)
+    got = glctx.probe_math(name, a, b)
+    eq = same_bits(got, want)
+    bad = np.flatnonzero(~eq)
+    assert eq.all(), f"{name}: {bad.size} of {a.size} differ, e.g. " + "; ".join(f"f({a[i]!r}, {None if b is None else b[i]!r}) = {got[i]!r} vs {want[i]!r}" for i in bad[:6])
+
+
 def test_random_stream_is_the_reference_bit_for_bit(glctx):
     r = load("rng_32x32")
     u = J.uniforms_from_schema(J.make_schema(GC.build_scene("sphere"), 32, 32), tuple(r["rand_noise"]))
