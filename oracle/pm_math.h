@@ -11,7 +11,7 @@
  * fp64 instructions in the shading of every kernel and a strict Mandelbulb 26x slower than the fast one.  The reference's shader is
  * `precision highp float` on every GPU it runs on: what a GL stack computes for sin() is an fp32 sequence of this kind.  Accuracy
  * (tests/test_host_cpu.py measures it against double precision): log, exp, sin, cos (|x| <= 1e5), acos within 2 ulp, atan2 within 3, pow
- * within 2 ulp for |y log x| <= 40 -- its logarithm is carried as a pair (hi, lo).  Denormal-free by definition: an argument or a
+ * within 2 ulp for exponents up to 16 (3 at 32, 5 at 64, 16 at 250) -- its logarithm is carried as a normalised pair (hi, lo).  Denormal-free by definition: an argument or a
  * result below 2^-126 counts as zero, so the sequences give the same bits whether or not fp32 denormals are flushed (the fast
  * kernels of the power-8 Mandelbulb flush them).  Polynomial coefficients: the classic single-precision minimax sets of
  * Cephes (sinf, cosf, expf, asinf, atanf; Moshier) and FreeBSD msun (e_logf.c).
@@ -54,7 +54,7 @@ PM_FN float pm_cos(float x) { float s, c; pm_sincos(x, &s, &c); return c; }
 /* ---- log -----------------------------------------------------------------------------------------------------------------
  * log x = hi + lo for a positive, finite, normal x: x = 2^k m, m in [sqrt 1/2, sqrt 2), f = m - 1, s = f / (2 + f),
  * log m = f - f^2/2 + s (f^2/2 + R(s^2)) (msun e_logf.c), kept as the rounded head f - f^2/2 and everything it leaves behind;
- * k ln 2 = k LN2_HI (exact: 17 bits x 8 bits) + k LN2_LO.  hi + lo carries about 29 bits. */
+ * k ln 2 = k LN2_HI (exact: 17 bits x 8 bits) + k LN2_LO.  hi + lo carries about 27 bits, |lo| <= ulp(hi) / 2. */
 PM_FN void pm_log_hl(float x, float* hi, float* lo) {
   unsigned int ix = PM_F2U(x) + (0x3f800000u - 0x3f3504f3u);
   const float k = (float)((int)(ix >> 23) - 127);
@@ -71,8 +71,10 @@ PM_FN void pm_log_hl(float x, float* hi, float* lo) {
   const float ml = ((f - mh) - hfsq) - herr + s * (hfsq + R);
   const float ah = k * 6.9313812256e-01f;         /* exact */
   const float h = ah + mh;                        /* |ah| > |mh| unless k = 0, and then h = mh exactly */
-  *lo = ((ah - h) + mh) + PM_FMAF(k, 9.0580006145e-06f, ml);
-  *hi = h;
+  const float l = ((ah - h) + mh) + PM_FMAF(k, 9.0580006145e-06f, ml);
+  const float sum = h + l;                        /* the pair normalised (|h| > |l|: exact), so that |lo| <= ulp(hi) / 2 and a */
+  *lo = l - (sum - h);                            /* large exponent multiplies a small tail: pow(1.4, 60) was 1 400 ulp off without */
+  *hi = sum;
 }
 /* log(x): NaN for x < 0 or NaN, -Inf for zero (and for a denormal: see the header), +Inf for +Inf */
 PM_FN float pm_log(float x) {
@@ -89,8 +91,7 @@ PM_FN float pm_log(float x) {
  * e^(t + tl), |tl| << 1: n = rint(t / ln 2), r = t - n ln 2 in two fused steps (n * 0.693359375 is exact), Cephes' polynomial on
  * |r| <= ln 2 / 2, e^tl = 1 + tl, the scale 2^n in two factors (n = 128 has no float of its own).  +Inf above the overflow
  * threshold, 0 where the result would be below 2^-126, NaN for NaN. */
-PM_FN float pm_exp_hl(float t, float tl) {
-  const float tc = t > 89.0f ? 89.0f : (t < -104.0f ? -104.0f : t); /* (keeps n in range; NaN passes through) */
+PM_FN float pm_exp_core(float tc, float tl) { /* -104 <= tc <= 89: the evaluation itself, no special case */
   const float n = rintf(tc * 1.44269504f);
   float r = PM_FMAF(-n, 0.693359375f, tc);
   r = PM_FMAF(-n, -2.12194440e-4f, r) + tl;
@@ -98,8 +99,12 @@ PM_FN float pm_exp_hl(float t, float tl) {
   float p = PM_FMAF(PM_FMAF(PM_FMAF(PM_FMAF(PM_FMAF(1.9875691500e-4f, r, 1.3981999507e-3f), r, 8.3334519073e-3f), r, 4.1665795894e-2f), r,
                             1.6666665459e-1f), r, 5.0000001201e-1f);
   p = PM_FMAF(p, z, r) + 1.0f;
-  const int ni = (int)(n == n ? n : 0.0f), n1 = ni / 2, n2 = ni - n1;  /* (a NaN's result is replaced below) */
-  float v = (p * PM_U2F((unsigned int)(n1 + 127) << 23)) * PM_U2F((unsigned int)(n2 + 127) << 23);
+  const int ni = (int)n, n1 = ni / 2, n2 = ni - n1;
+  return (p * PM_U2F((unsigned int)(n1 + 127) << 23)) * PM_U2F((unsigned int)(n2 + 127) << 23);
+}
+PM_FN float pm_exp_hl(float t, float tl) {
+  const float tc = t > 89.0f ? 89.0f : (t < -104.0f ? -104.0f : (t == t ? t : 0.0f)); /* (keeps n in range; a NaN's result is replaced below) */
+  float v = pm_exp_core(tc, tl);
   if (v < PM_TINY) v = 0.0f;
   if (t > 88.7228394f) v = PM_INF;
   if (t != t) v = t;
@@ -157,6 +162,14 @@ PM_FN float pm_acos(float x) {
  * atan2(y, x) with C's conventions for zeros and infinities.  The angle of (|x|, |y|) by Cephes' atanf reduction with ONE
  * division: beyond tan 3pi/8 it is pi/2 + atan(-|x| / |y|), beyond tan pi/8 it is pi/4 + atan((|y| - |x|) / (|y| + |x|)), and the
  * polynomial serves |t| <= tan pi/8.  (|x| + |y| has to stay finite: magnitudes up to 1e38.) */
+PM_FN float pm_atan_quadrant(float ax, float ay) { /* the angle of (ax, ay), both positive and finite, in (0, pi/2) */
+  float num = ay, den = ax, base = 0.0f;
+  if (ay > 2.41421356f * ax) { num = -ax; den = ay; base = 1.57079637f; }
+  else if (ay > 0.414213562f * ax) { num = ay - ax; den = ay + ax; base = 0.785398185f; }
+  const float t = num / den, z = t * t;
+  const float p = PM_FMAF(PM_FMAF(PM_FMAF(8.05374449538e-2f, z, -1.38776856032e-1f), z, 1.99777106478e-1f), z, -3.33329491539e-1f);
+  return base + PM_FMAF(t * z, p, t);
+}
 PM_FN float pm_atan2(float y, float x) {
   if (x != x || y != y) return x + y;
   const int xneg = (int)(PM_F2U(x) >> 31), yneg = (int)(PM_F2U(y) >> 31);
@@ -166,14 +179,7 @@ PM_FN float pm_atan2(float y, float x) {
   else if (ax == 0.0f) a = 1.57079637f;
   else if (ay == PM_INF) a = ax == PM_INF ? 0.785398185f : 1.57079637f;
   else if (ax == PM_INF) a = 0.0f;
-  else {
-    float num = ay, den = ax, base = 0.0f;
-    if (ay > 2.41421356f * ax) { num = -ax; den = ay; base = 1.57079637f; }
-    else if (ay > 0.414213562f * ax) { num = ay - ax; den = ay + ax; base = 0.785398185f; }
-    const float t = num / den, z = t * t;
-    const float p = PM_FMAF(PM_FMAF(PM_FMAF(8.05374449538e-2f, z, -1.38776856032e-1f), z, 1.99777106478e-1f), z, -3.33329491539e-1f);
-    a = base + PM_FMAF(t * z, p, t);
-  }
+  else a = pm_atan_quadrant(ax, ay);
   if (xneg) a = 3.14159274f - a;
   return yneg ? -a : a;
 }

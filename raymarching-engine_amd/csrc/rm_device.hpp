@@ -89,20 +89,42 @@ struct PM {
   // Transcendentals: rm_pm_math.hpp, the same text as the oracle's.  pow: on |x| (oracle/rm_oracle.c gl_pow; GLSL leaves
   // a negative base undefined, SwiftShader takes |x|); pm_pow returns x * x for the exponent 2 -- every use of the path
   // with that exponent has it as a literal (the GGX term :371, schlick's r0 :173), so the test folds away.
-  static RM_DEV float pow(float x, float y) { return pm_pow(fabsf(x), y); }
+  static RM_DEV float pow(float x, float y) {
+    float hi, lo;
+    pm_log_hl(fabsf(x), &hi, &lo);
+    return pow_from_log(fabsf(x), y, hi, lo);
+  }
   static RM_DEV float log(float x) { return pm_log(x); }
   static RM_DEV float exp(float x) { return pm_exp(x); }
   static RM_DEV float sin(float x) { return pm_sin(x); }
   static RM_DEV float cos(float x) { return pm_cos(x); }
   static RM_DEV float acos(float x) { return pm_acos(x); }
-  static RM_DEV float atan2(float y, float x) { return pm_atan2(y, x); }
   static RM_DEV void sincos(float x, float& s, float& c) { pm_sincos(x, &s, &c); }  // one reduction, the bits of sin and cos
   // pow(r, n - 1) and pow(r, n) from ONE logarithm of r: the bits of the two calls (pm_pow is pm_log_hl + pm_pow_from_log)
   static RM_DEV void pow_pair(float r, float n, float& r_nm1, float& r_n) {
     float hi, lo;
     pm_log_hl(fabsf(r), &hi, &lo);
-    r_nm1 = pm_pow_from_log(fabsf(r), n - 1.0f, hi, lo);
-    r_n = pm_pow_from_log(fabsf(r), n, hi, lo);
+    r_nm1 = pow_from_log(fabsf(r), n - 1.0f, hi, lo);
+    r_n = pow_from_log(fabsf(r), n, hi, lo);
+  }
+  // The special cases of pm_pow_from_log / pm_exp_hl / pm_atan2 are a dozen comparisons each, every one a VALU instruction, on
+  // arguments that are ordinary numbers nearly always.  One test for "ordinary" first (v_cmp_class: a positive normal base, a
+  // finite non-zero exponent, neither 1 / 2, |y log x| < 87 so that the result is a normal number) and then the evaluation
+  // alone -- pm_exp_core, what the shared text reaches for such arguments through all of its tests; the text itself for the
+  // wave that holds anything else.  Same bits: rm_probe_math asks both ways on millions of arguments (tests/test_gpu_parity.py).
+  static RM_DEV float pow_from_log(float x, float y, float hi, float lo) {
+    const float th = y * hi, tl = PM_FMAF(y, hi, -th) + y * lo;  // (the product as pm_pow_from_log carries it)
+    const bool plain = __builtin_amdgcn_classf(x, 0x100) & __builtin_amdgcn_classf(y, 0x198) & (x != 1.0f) & (y != 2.0f) & (fabsf(th) < 87.0f);
+    if (__builtin_expect(plain, 1)) return pm_exp_core(th, tl);
+    return pm_pow_from_log(x, y, hi, lo);
+  }
+  static RM_DEV float atan2(float y, float x) {
+    if (__builtin_expect(__builtin_amdgcn_classf(x, 0x198) & __builtin_amdgcn_classf(y, 0x198), 1)) {  // both finite and not zero
+      const float a = pm_atan_quadrant(fabsf(x), fabsf(y));
+      const float b = x < 0.0f ? 3.14159274f - a : a;
+      return y < 0.0f ? -b : b;
+    }
+    return pm_atan2(y, x);
   }
 };
 #endif

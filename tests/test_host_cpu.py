@@ -325,6 +325,13 @@ void t_pow_pair(const float* x, const float* y, float* o, int c) {  /* two power
         a, b = np.exp(rng.uniform(-20, 20, n)).astype(np.float32), rng.uniform(-4, 4, n).astype(np.float32)
         check("pow wide", call("t_pow", a, b), np.power(a.astype(np.float64), b.astype(np.float64)), 2.0, 0.85)
         assert (call("t_pow_pair", a, b) .view(np.uint32) == call("t_pow", a, b).view(np.uint32)).all()
+        # large exponents multiply the logarithm's error: the pair (hi, lo) has to be normalised for this (before it was, y lo entered
+        # the exponential's polynomial as part of its argument and pow(1.4, 60) was 1 400 ulp off, pow(1.37, -240) came out 0)
+        for lo_e, hi_e, bar in ((15, 17, 2.0), (30, 34, 3.5), (60, 64, 6.0), (-64, -60, 6.0), (200, 250, 24.0), (-250, -200, 24.0)):
+            a, b = rng.uniform(0.5, 2.0, n).astype(np.float32), rng.uniform(lo_e, hi_e, n).astype(np.float32)
+            want = np.power(a.astype(np.float64), b.astype(np.float64))
+            keep = (want > 1e-36) & (want < 1e36)
+            check(f"pow exponents {lo_e}..{hi_e}", call("t_pow", a[keep], b[keep]), want[keep], bar, 0.2)
         # whole powers of small integers come out exact (the iterated kinds' per-level scale factors)
         assert (call("t_pow", [2, 2, 2, 3, 10, 0.5, 4, 3], [5, 10, -3, 4, 3, 7, 0.5, 0]) == np.array([32, 1024, 0.125, 81, 1000, 0.0078125, 2, 1], np.float32)).all()
         y, x = rng.normal(size=n).astype(np.float32), rng.normal(size=n).astype(np.float32)
