@@ -16,8 +16,8 @@
  * kernels of the power-8 Mandelbulb flush them).  Polynomial coefficients: the classic single-precision minimax sets of
  * Cephes (sinf, cosf, expf, asinf, atanf; Moshier) and FreeBSD msun (e_logf.c).
  *
- * The including file defines PM_FN (function qualifiers), PM_FMAF (IEEE fusedMultiplyAdd of floats), PM_F2U / PM_U2F (bit casts
- * float <-> 32-bit unsigned). */
+ * The including file defines PM_FN (function qualifiers), PM_FMAF (IEEE fusedMultiplyAdd of floats), PM_SQRTF (IEEE squareRoot), PM_F2U /
+ * PM_U2F (bit casts float <-> 32-bit unsigned). */
 
 #define PM_INF __builtin_inff()
 #define PM_NAN __builtin_nanf("")
@@ -150,7 +150,7 @@ PM_FN float pm_acos(float x) {
   if (ax <= 0.5f) {
     r = 1.57079637f - (pm_asin_poly(x, x * x) + 4.37113883e-8f);
   } else {
-    const float z = 0.5f * (1.0f - ax), t = sqrtf(z);
+    const float z = 0.5f * (1.0f - ax), t = PM_SQRTF(z);
     const float a = 2.0f * pm_asin_poly(t, z);
     r = x < 0.0f ? (3.14159274f - (a + 8.74227766e-8f)) : a;
   }

@@ -69,6 +69,7 @@ struct PM {
   static RM_DEV float rcp(float x) { return 1.0f / x; }
   static RM_DEV float div(float a, float b) { return a / b; }
   static RM_DEV float sqrt(float x) { return sqrtf(x); }
+  static RM_DEV float sqrt_of_ordinary(float x) { return sqrtf(x); }
   static RM_DEV float pow(float x, float y) { return ss_pow(x, y); }  // exp2(y log2 |x|), also for y = 2
   static RM_DEV float log(float x) { return ss_log(x); }
   static RM_DEV float exp(float x) { return ss_exp(x); }
@@ -86,6 +87,9 @@ struct PM {
   static RM_DEV float rcp(float x) { return 1.0f / x; }
   static RM_DEV float div(float a, float b) { return a / b; }
   static RM_DEV float sqrt(float x) { return sqrtf(x); }
+  // the same value by rm_pm_math.hpp's shorter way for an argument of ordinary size: for the Mandelbulb's rounds, whose other
+  // functions are branches already (in a table's row loop the test costs more than it saves: strict C5 stripes 43.7 -> 45.9 ms)
+  static RM_DEV float sqrt_of_ordinary(float x) { return rm_sqrt_rn(x); }
   // Transcendentals: rm_pm_math.hpp, the same text as the oracle's.  pow: on |x| (oracle/rm_oracle.c gl_pow; GLSL leaves
   // a negative base undefined, SwiftShader takes |x|); pm_pow returns x * x for the exponent 2 -- every use of the path
   // with that exponent has it as a literal (the GGX term :371, schlick's r0 :173), so the test folds away.
@@ -135,6 +139,7 @@ struct FM {
   static RM_DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
   static RM_DEV float div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
   static RM_DEV float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+  static RM_DEV float sqrt_of_ordinary(float x) { return __builtin_amdgcn_sqrtf(x); }
   static RM_DEV float pow(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(fabsf(x))); }
   static RM_DEV float log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718056f; }
   static RM_DEV float sin(float x) { return __builtin_amdgcn_sinf(x * 0.15915494309189535f); }
@@ -981,7 +986,7 @@ struct Sdf<RM_SCENE_MANDELBULB> {
     v3 z = pos;
     float dr = 1.0f, r = 0.0f;
     for (int i = 0; i < iterations; i++) {
-      r = length<M>(z);
+      r = M::sqrt_of_ordinary(dot<M>(z, z));  // length(z)
       if (r > bailout) break;
       generic_round<M>(z, dr, pos, r, power);
     }
@@ -1218,7 +1223,7 @@ struct Sdf<RM_SCENE_MANDELBULB> {
     v3 z = p;
     float dr = 1.0f, r = 0.0f;
     for (int i = 0; i <= cheap_cap; i++) {
-      r = length<M>(z);
+      r = M::sqrt_of_ordinary(dot<M>(z, z));  // length(z)
       if (r > bailout) { bailed = true; break; }
       if (i == cheap_cap) break;
       generic_round<M>(z, dr, p, r, power);

@@ -11,6 +11,21 @@
 #define PM_FMAF(a, b, c) __builtin_fmaf((a), (b), (c))
 #define PM_F2U(x) __float_as_uint(x)
 #define PM_U2F(u) __uint_as_float(u)
+// IEEE squareRoot.  hipcc's sqrtf is the correctly rounded one: v_sqrt_f32 (1 ulp), then the neighbour that the exact residuals
+// x - s * next_down(s), x - s * next_up(s) call for -- between a scaling for arguments below 2^-96 and a class test for 0 / Inf / NaN,
+// 16 instructions.  An argument in [2^-96, 2^127] needs neither: one range test on its bits, then the same correction, 11.
+static __device__ __forceinline__ float rm_sqrt_rn(float x) {
+  if (__builtin_expect((__float_as_uint(x) - 0x0f800000u) < 0x70000000u, 1)) {
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float down = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_down = __builtin_fmaf(-down, s, x), r_up = __builtin_fmaf(-up, s, x);
+    if (r_down <= 0.0f) s = down;
+    if (r_up > 0.0f) s = up;
+    return s;
+  }
+  return sqrtf(x);
+}
+#define PM_SQRTF(x) rm_sqrt_rn(x)
 // ---- shared text (oracle/pm_math.h) ----
 #define PM_INF __builtin_inff()
 #define PM_NAN __builtin_nanf("")
@@ -143,7 +158,7 @@ PM_FN float pm_acos(float x) {
   if (ax <= 0.5f) {
     r = 1.57079637f - (pm_asin_poly(x, x * x) + 4.37113883e-8f);
   } else {
-    const float z = 0.5f * (1.0f - ax), t = sqrtf(z);
+    const float z = 0.5f * (1.0f - ax), t = PM_SQRTF(z);
     const float a = 2.0f * pm_asin_poly(t, z);
     r = x < 0.0f ? (3.14159274f - (a + 8.74227766e-8f)) : a;
   }
