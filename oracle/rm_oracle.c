@@ -111,6 +111,7 @@ static inline float o_rounded(float v) {
 
 #define PM_FN static inline
 #define PM_SQRTF(x) sqrtf(x)
+#define PM_DIV_ORDINARY(a, b) ((a) / (b))
 #define PM_FMAF(a, b, c) fmaf((a), (b), (c)) /* IEEE fusedMultiplyAdd: one rounding, in hardware (-mfma) or in libm, the same bits */
 static inline unsigned int PM_F2U(float x) { unsigned int u; memcpy(&u, &x, 4); return u; }
 static inline float PM_U2F(unsigned int u) { float x; memcpy(&x, &u, 4); return x; }

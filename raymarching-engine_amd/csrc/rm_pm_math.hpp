@@ -26,6 +26,17 @@ static __device__ __forceinline__ float rm_sqrt_rn(float x) {
   return sqrtf(x);
 }
 #define PM_SQRTF(x) rm_sqrt_rn(x)
+// IEEE division where the text knows the operands (pm_log_hl: |a| < 0.42 or 0, b in [1.7, 2.42]): hipcc's division is this sequence between
+// two v_div_scale (which change nothing for such operands), with v_div_fmas (a plain fma then) as its last step and a v_div_fixup (the identity
+// here) behind it -- 11 instructions, 8 without them.  The same bits: rm_probe_math's log / pow tests, tools/exhaustive_math.py on every float.
+static __device__ __forceinline__ float rm_div_ordinary(float a, float b) {
+  float r = __builtin_amdgcn_rcpf(b);
+  r = __builtin_fmaf(__builtin_fmaf(-b, r, 1.0f), r, r);
+  float q = a * r;
+  q = __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+  return __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+}
+#define PM_DIV_ORDINARY(a, b) rm_div_ordinary((a), (b))
 // ---- shared text (oracle/pm_math.h) ----
 #define PM_INF __builtin_inff()
 #define PM_NAN __builtin_nanf("")
@@ -49,7 +60,7 @@ PM_FN void pm_sincos(float x, float* s, float* c) {
   const float cp = PM_FMAF(PM_FMAF(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
   const float hz = 0.5f * z, w = 1.0f - hz;   /* cos r = 1 - z/2 + z^2 cp with the head's rounding error put back: (1 - w) - hz is exact, */
   float cr = w + (((1.0f - w) - hz) + PM_FMAF(z * z, cp, -0.5f * PM_FMAF(r, r, -z)));  /* and so is r^2 - z */
-  if (!(r >= -1.25f && r <= 1.25f)) sr = cr = PM_NAN; /* |x| beyond ~1e7 (k is no longer the nearest multiple), Inf, NaN */
+  if (!((r < 0.0f ? -r : r) <= 1.25f)) sr = cr = PM_NAN; /* |x| beyond ~1e7 (k is no longer the nearest multiple), Inf, NaN */
   const float q = k - 4.0f * floorf(k * 0.25f); /* quadrant 0..3 (NaN for a non-finite argument: the last branch, of NaNs) */
   if (q == 1.0f) { *s = cr; *c = -sr; }
   else if (q == 2.0f) { *s = -sr; *c = -cr; }
@@ -68,7 +79,7 @@ PM_FN void pm_log_hl(float x, float* hi, float* lo) {
   const float k = (float)((int)(ix >> 23) - 127);
   ix = (ix & 0x007fffffu) + 0x3f3504f3u;
   const float f = PM_U2F(ix) - 1.0f;
-  const float s = f / (2.0f + f);
+  const float s = PM_DIV_ORDINARY(f, 2.0f + f);  /* |f| < 0.42 or 0, the divisor in [1.7, 2.42] */
   const float z = s * s, w = z * z;
   const float t1 = w * PM_FMAF(w, 0.24279078841f, 0.40000972152f);
   const float t2 = z * PM_FMAF(w, 0.28498786688f, 0.66666662693f);
@@ -154,14 +165,11 @@ PM_FN float pm_asin_poly(float t, float z) {
 }
 PM_FN float pm_acos(float x) {
   const float ax = x < 0.0f ? -x : x;
-  float r;
-  if (ax <= 0.5f) {
-    r = 1.57079637f - (pm_asin_poly(x, x * x) + 4.37113883e-8f);
-  } else {
-    const float z = 0.5f * (1.0f - ax), t = PM_SQRTF(z);
-    const float a = 2.0f * pm_asin_poly(t, z);
-    r = x < 0.0f ? (3.14159274f - (a + 8.74227766e-8f)) : a;
-  }
+  const int inner = ax <= 0.5f;
+  float t = x, z = x * x;                       /* the polynomial's arguments: (x, x^2) inside, (sqrt z, z = (1 - |x|) / 2) outside */
+  if (!inner) { z = 0.5f * (1.0f - ax); t = PM_SQRTF(z); }
+  const float a = pm_asin_poly(t, z);
+  float r = inner ? 1.57079637f - (a + 4.37113883e-8f) : (x < 0.0f ? 3.14159274f - (2.0f * a + 8.74227766e-8f) : 2.0f * a);
   if (!(ax <= 1.0f)) r = x != x ? x : PM_NAN;
   return r;
 }

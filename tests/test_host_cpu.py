@@ -265,6 +265,7 @@ def test_portable_math_accuracy_and_conventions():
 #define PM_FN static inline
 #define PM_FMAF(a, b, c) fmaf((a), (b), (c))
 #define PM_SQRTF(x) sqrtf(x)
+#define PM_DIV_ORDINARY(a, b) ((a) / (b))
 static inline unsigned int PM_F2U(float x) { unsigned int u; memcpy(&u, &x, 4); return u; }
 static inline float PM_U2F(unsigned int u) { float x; memcpy(&x, &u, 4); return x; }
 #include "pm_math.h"
