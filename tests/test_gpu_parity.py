@@ -221,6 +221,27 @@ def test_transcendentals_of_the_parity_arithmetic_have_the_oracles_bits(ctx, nam
         for i in bad[:6])
 
 
+@pytest.mark.parametrize("name", ["sin", "cos", "log", "exp", "acos", "tan", "sqrt"])
+def test_one_argument_transcendentals_across_every_exponent(ctx, name):
+    """Every 61st bit pattern of a float -- all exponents, both signs, NaNs and denormals, 70 million arguments -- through one function of
+    the parity arithmetic: kernels == oracle.  (tools/exhaustive_math.py does all 2^32 per function: profiles/r05_exhaustive_math.txt.)"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    a = np.arange(17, 1 << 32, 61, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    got = ctx.probe_math(name, a)
+    want = np.empty_like(a)
+    parts = np.array_split(np.arange(a.size), 16)
+
+    def fill(idx):
+        want[idx] = O.math(name, a[idx])  # (ctypes releases the GIL)
+
+    with ThreadPoolExecutor(16) as pool:
+        list(pool.map(fill, parts))
+    eq = same_bits(got, want)
+    bad = np.flatnonzero(~eq)
+    assert eq.all(), f"{name}: {bad.size} of {a.size} differ, e.g. " + "; ".join(f"f({a[i]!r}) = {got[i]!r} vs oracle {want[i]!r}" for i in bad[:6])
+
+
 @pytest.mark.parametrize("mode", ["perspective", "orthographic", "panoramic"])
 def test_camera_block(ctx, mode):
     schema = J.make_schema(GC.build_scene("sphere"), 240, 135, camera=mode, rotation=GC.ROT, position=(0.3, -0.2, -3.0), dof_distance=2.5)
