@@ -23,6 +23,7 @@ C = np.array([n.center if not isinstance(n, tuple) else n[3] for n in sc._nodes]
 R = np.array([(n.size if not isinstance(n, tuple) else n[4])[0] for n in sc._nodes], np.float64)
 K = 0.2
 HALF, NCELL = 2.2, 128
+REPACK = int(os.environ.get("REPACK", "8"))
 CELL = 2 * HALF / NCELL
 _lists = {}
 
@@ -82,8 +83,9 @@ def tile(tx, ty, W=8192, fov=1.5, seed=0):
     v = (v / (np.linalg.norm(v, axis=1, keepdims=True) + 1e-30)).astype(f32)
     q = (p + n.astype(f32) * f32(1e-3)).astype(f32)
     alive = np.ones(len(q), bool)
-    tot = np.zeros(4)
+    tot = np.zeros(5)
     steps = 0
+    group = None  # wave of every ray, fixed at the last repack
     for s in range(64):
         dist = fold(q)
         moving = alive & (np.abs(q).max(-1) < 8.0) & (dist > 1e-6)
@@ -93,13 +95,20 @@ def tile(tx, ty, W=8192, fov=1.5, seed=0):
         c, inside = cell_of(q[idx].astype(np.float64))
         lists = np.array([list_of(ci) if ok else np.ones(64, bool) for ci, ok in zip(c, inside)])
         own = lists.sum(1).mean()
+
         def waves(order):
             u = [lists[order[i:i + 64]].any(0).sum() * len(order[i:i + 64]) for i in range(0, len(order), 64)]
             return sum(u) / len(order)
         a = waves(np.arange(len(idx)))
         key = np.where(inside, morton(np.clip(c, 0, NCELL - 1)), (1 << 40))
-        b = waves(np.argsort(key, kind="stable")) if s % 8 == 0 or True else a
-        tot += np.array([64.0, own, a, b]) * len(idx)
+        order = np.argsort(key, kind="stable")
+        b = waves(order)
+        if s % REPACK == 0:  # the kernel's cadence: the waves formed now stay until the next repack (rays that stop leave their lanes idle)
+            group = np.full(len(q), -1)
+            group[idx[order]] = np.arange(len(idx)) // 64
+        g = group[idx]
+        e = sum(lists[g == w].any(0).sum() * (g == w).sum() for w in np.unique(g)) / len(idx)
+        tot += np.array([64.0, own, a, b, e]) * len(idx)
         steps += len(idx)
         q = (q + v * dist[:, None]).astype(f32)
         alive = moving
@@ -108,15 +117,15 @@ def tile(tx, ty, W=8192, fov=1.5, seed=0):
 
 if __name__ == "__main__":
     tiles = [(4096, 4096), (3600, 4300), (4600, 3700), (3200, 3300), (5000, 5000), (4096, 3000)]
-    print("tile            rays  ray-steps   every row   own list   waves in pixel order   waves sorted by cell")
-    acc, n = np.zeros(4), 0
+    print(f"tile            rays  ray-steps   every row   own list   waves in pixel order   waves sorted by cell   sorted every {REPACK} steps only")
+    acc, n = np.zeros(5), 0
     for t in tiles:
         r = tile(*t)
         if r is None:
             print(t, "misses the scene")
             continue
         m, steps, rays = r
-        print(f"{str(t):14s} {rays:5d} {steps:9d} {m[0]:10.1f} {m[1]:10.1f} {m[2]:18.1f} {m[3]:22.1f}")
+        print(f"{str(t):14s} {rays:5d} {steps:9d} {m[0]:10.1f} {m[1]:10.1f} {m[2]:18.1f} {m[3]:22.1f} {m[4]:22.1f}")
         acc += m * steps
         n += steps
     print("all", (acc / n).round(1))
