@@ -107,8 +107,11 @@ def instrumented_flops(key, rows_held):
     return e["flops_per_pixel_sample"] * len(rows_held) * W, e["flops_per_pixel_sample"], e
 
 
-def cpu_baseline(sc, schema, target_seconds=12.0):
-    """The oracle on the host cores over rows spaced evenly over the WHOLE frame (every k-th row: an unbiased sample)."""
+def cpu_baseline(sc, schema, target_seconds=16.0):
+    """The oracle on the host cores over rows spaced evenly over the WHOLE frame (every k-th row: an unbiased sample).
+    The box's host is shared and an OpenMP team of every hardware thread oversubscribes it, so the same 1/8-of-the-budget
+    row sample is timed with teams of 32, 64, 128 and all hardware threads first; the timed sample then runs with the team
+    that was fastest, and `cores` is THAT count (`threads_tried` keeps every rate)."""
     from oracle import oracle as O
     from raymarching_engine_amd import job as J
 
@@ -125,19 +128,28 @@ def cpu_baseline(sc, schema, target_seconds=12.0):
         k = max(1, H // n)
         return list(range(k // 2, H, k))
 
-    # probe: about one row per core, spread over the frame, to size the timed sample
+    def rate(rows, threads):
+        t0 = time.perf_counter()
+        O.render_rows(sc, u, W, H, rows, threads=threads)
+        t = time.perf_counter() - t0
+        return len(rows) * W / t / 1e6, t
+
+    # probe: about one row per core, spread over the frame, to size the samples
     probe = rows_for(max(8, min(H, cores)))
-    t0 = time.perf_counter()
-    O.render_rows(sc, u, W, H, probe, threads=cores)
-    per_row = max((time.perf_counter() - t0) / len(probe), 1e-6)
-    n = int(max(len(probe), min(H, target_seconds / per_row)))
+    r0, t = rate(probe, cores)
+    per_row = max(t / len(probe), 1e-6)
+    teams = sorted({min(cores, c) for c in (32, 64, 128, cores)})
+    sweep_rows = rows_for(int(max(len(probe), min(H, target_seconds / 8.0 / per_row))))
+    tried = {c: rate(sweep_rows, c)[0] for c in teams}
+    best = max(tried, key=tried.get)
+    n = int(max(len(probe), min(H, 0.5 * target_seconds * tried[best] * 1e6 / W)))
     rows = rows_for(n)
-    t0 = time.perf_counter()
-    O.render_rows(sc, u, W, H, rows, threads=cores)
-    t = time.perf_counter() - t0
+    value, t = rate(rows, best)
     px = len(rows) * W
-    return {"value": px / t / 1e6, "unit": "Mpixels/s", "cores": cores, "kind": "port",
-            "sample": f"every {max(1, H // n)}th row of the {W}x{H} frame ({len(rows)} rows, {px} pixel-samples, {t:.1f} s), "
+    return {"value": value, "unit": "Mpixels/s", "cores": best, "hardware_threads": cores, "kind": "port",
+            "threads_tried": {str(c): round(v, 4) for c, v in tried.items()},
+            "threads_sample": f"every {max(1, H // len(sweep_rows))}th row ({len(sweep_rows)} rows) per team size",
+            "sample": f"every {max(1, H // n)}th row of the {W}x{H} frame ({len(rows)} rows, {px} pixel-samples, {t:.1f} s) on the fastest team ({best} threads), "
                       "oracle/rm_oracle.c with OpenMP over the rows, libm transcendentals"}
 
 
@@ -158,7 +170,7 @@ def reference_gl(key):
             "sample": r["case"], "source": "profiles/r01_b1_swiftshader_reference.json"}
 
 
-def counters_entry(key, strict, pipeline, windowed):
+def counters_entry(key, strict, pipeline, windowed, gl_stack=0):
     """This workload's entry of profiles/<round>_counters.json (separate rocprofv3 --pmc passes of this command, tools/profile_gpu.sh
     + tools/update_counters.py): HBM bytes and executed lane-flops per frame.  The counters belong to the kernel sources they
     were measured on (their hash is recorded): after a source change they are withheld until re-measured."""
@@ -169,9 +181,9 @@ def counters_entry(key, strict, pipeline, windowed):
         spec.loader.exec_module(uc)
         name = uc.COUNTERS_ROUND + "_counters.json"
         cj = json.load(open(os.path.join(ROOT, "profiles", name)))
-        base = key + ("_shard" if windowed else "") + ("_strict" if strict else "_fast")
+        base = key + ("_shard" if windowed else "") + ("_glstack" if gl_stack else "_strict" if strict else "_fast")
         ent = cj.get(base + "_" + pipeline) or cj.get(base)  # (workloads profiled with both implementations carry the implementation in the key)
-        if not ent or ent.get("kernel_source_sha256") != uc.kernel_source_hash() or ent.get("pipeline") != pipeline:
+        if not ent or ent.get("kernel_source_sha256") != uc.kernel_source_hash() or (ent.get("pipeline") != pipeline and pipeline is not None):
             return None
         return dict(ent, counters_file="profiles/" + name)
     except Exception:
@@ -235,6 +247,8 @@ def main():
                                                        "gathers the packed (colour, DoF radius) rows and rank 0 runs the blur")
     ap.add_argument("--no-far-jump", action="store_true", help="RM_RENDER_NO_FAR_JUMP: march escaping rays step by step (measurement switch, same bits)")
     ap.add_argument("--no-cull", action="store_true", help="RM_RENDER_NO_CULL: fold every row of a primitive table at every point (measurement switch, same bits)")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the `workloads` legs (the other BASELINE configurations and the two parity builds of the headline, a few steps each)")
+    ap.add_argument("--no-check-frame", action="store_true", help="sharded runs check the assembled frame by default (see --check-frame); this skips it")
     ap.add_argument("--check-frame", action="store_true",
                     help="sharded runs: after the timed legs rank 0 renders the same samples on ONE framebuffer, presents it and compares "
                          "the bytes with the frame it assembled from the gathered rows (reported as `frame_check`)")
@@ -414,7 +428,7 @@ def main():
     # --check-frame: the canvas rank 0 was last presented against the same samples rendered and presented on ONE framebuffer
     # here (the accumulation per pixel is in sample order either way: the bytes must be identical)
     frame_check = None
-    if args.check_frame and sharded:
+    if sharded and not args.no_check_frame:  # (on by default since round 6: the first run on a real node proves its own frame)
         fb.start_present(samples[0])
         canvas = fb.finish_present()
         torch.cuda.synchronize()
@@ -432,7 +446,7 @@ def main():
             got = canvas.cpu().numpy()
             frame_check = bool(np.array_equal(got, expect))
             if not frame_check:
-                sys.exit(f"bench.py --check-frame: the assembled frame differs from the single-framebuffer render in {int((got != expect).sum())} bytes")
+                sys.exit(f"bench.py: frame check failed: the assembled frame differs from the single-framebuffer render in {int((got != expect).sum())} bytes")
 
     overlap = None
     if world == 1 and not force_dist and in_flight == 1 and args.overlap_leg:
@@ -456,6 +470,64 @@ def main():
         t[rank] = kernel_ms
         dist.all_reduce(t)
         kernel_ms_per_rank = [float(v) for v in t.tolist()]
+
+    # The other claims of DESIGN.md section 6 on the same line (default invocation only; a few steps each): the other BASELINE
+    # configurations in the fast build, and the headline in the two parity builds -- strict (the oracle's bits) and the GL
+    # stack's arithmetic with its own tan (rm_ctx_set_gl_stack(ctx, 2): the reference's bits as SwiftShader renders them).
+    workloads = None
+    if (world == 1 and not force_dist and rows_window is None and stripes is None and args.workload == "c3b" and not args.strict
+            and not args.no_workloads and not args.wavefront and not args.dof):
+        workloads = {}
+        legs = (("c2", "fast", 0, 8), ("c3a", "fast", 0, 5), ("c4", "fast", 0, 5), ("c5", "fast", 0, 3), ("c3b", "strict", 0, 5), ("c3b", "glstack", 2, 3))
+        for n_leg, (key, build, gl_stack, k_steps) in enumerate(legs):
+            wl2, sc2, schema2 = make_workload(key)
+            W2, H2 = wl2["width"], wl2["height"]
+            leg_flags = (abi.RM_RENDER_FAST if build == "fast" else abi.RM_RENDER_STRICT | (abi.RM_RENDER_MEGAKERNEL if gl_stack else 0))
+            for sw, bit in ((args.no_far_jump, abi.RM_RENDER_NO_FAR_JUMP), (args.no_cull, abi.RM_RENDER_NO_CULL)):
+                if sw:
+                    leg_flags |= bit
+            jctx.flags = leg_flags
+            ctx.set_gl_stack(gl_stack)
+            schema2["render"]["frameid"] = 100 + n_leg
+            fb2 = jctx.fbo_create(W2, H2, 100 + n_leg)
+            scene2 = jctx.get_scene(sc2)
+            base2 = schema2["render"]["exposure"] / schema2["render"]["samplesPerPixel"]
+
+            def run2(n):
+                r = schema2["render"]
+                r["samplesPerPixel"], r["sampleYieldInterval"], r["exposure"] = n, 1, base2 * n
+                res = J.drain(J.do_render_job(schema2, jctx)(lambda *a: None))
+                if not res.get("success"):
+                    sys.exit(f"bench.py: workload {key} ({build}) failed: {res}")
+
+            run2(2)  # (a long table earns its culling grid here; the tile cost order settles)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run2(k_steps)
+            torch.cuda.synchronize()
+            e2 = time.perf_counter() - t0
+            u2 = J.uniforms_from_schema(schema2, (0.5, 1.0 / 3.0))
+            k_ms = ctx.render_timed(scene2, fb2, u2, 3, None, leg_flags | abi.RM_RENDER_NO_OVERLAP)
+            pipe2 = ctx.last_pipeline()
+            ent = counters_entry(key, build == "strict", pipe2, False, gl_stack)
+            leg = {"workload": wl2["name"], "build": build + (" (rm_ctx_set_gl_stack 2: the GL stack's arithmetic, its own tan)" if gl_stack else ""),
+                   "steps": k_steps, "ms_per_step": e2 / k_steps * 1e3, "kernel_ms": k_ms, "mpix_s": W2 * H2 * k_steps / e2 / 1e6,
+                   "frac_executed": ent["executed_lane_flops_per_frame"] / (k_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS if ent else None,
+                   "hbm_bytes_per_px": ent["hbm_bytes_per_pixel"] if ent else None, "lanes_active": ent["lanes_active"] if ent else None,
+                   "counters_from": ent["counters_file"] + " -> " + ent["profile"] if ent else None}
+            workloads[key + "_" + build] = leg
+            jctx.fbo_delete(W2, H2, 100 + n_leg)
+            while jctx._purgatory:  # (C5's planes are 3.2 GB: give them back before the next leg)
+                jctx._purgatory.pop(0)[1].destroy()
+        ctx.set_gl_stack(0)
+        jctx.flags = flags
+
+    # what the collective library actually saw (sharded runs): proof on the line that N ranks took part
+    collective = None
+    if sharded:
+        collective = {"backend": backend, "world_size_seen": dist.get_world_size(), "ranks_sharing_one_gpu": bool(share_gpu),
+                      "payload": payload, "gathered_bytes_per_present": int(fb.gathered_bytes_per_present()) if hasattr(fb, "gathered_bytes_per_present") else None,
+                      "frame_check": frame_check, "frame_check_samples": samples[0] if frame_check is not None else None}
 
     out = None
     if rank == 0:
@@ -529,6 +601,7 @@ def main():
                        "planes": "color+normal_dof+albedo_depth fp32, accumulated in place", "samples_in_flight": in_flight,
                        "sample_yield_interval": yield_interval},
             "roofline": roof, "cpu_baseline": cpu, "overlap": overlap, "present_every_sample": every_sample, "frame_check": frame_check,
+            "collective": collective, "workloads": workloads,
         }
     jctx.fbo_delete(W, H, 7)
     fb.destroy()

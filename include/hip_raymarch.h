@@ -24,6 +24,12 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* The library is built -fvisibility=hidden: exactly the entry points below are exported (tests/test_host_cpu.py compares
+ * this header with `nm -D`). */
+#ifndef RM_API
+#define RM_API __attribute__((visibility("default")))
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -205,7 +211,7 @@ typedef struct RmSceneDesc {
 } RmSceneDesc;
 
 /* Fills *m with the reference defaults of Validate.tsx:18-51. */
-void rm_material_default(RmMaterial* m);
+RM_API void rm_material_default(RmMaterial* m);
 
 /* ---- handles ----------------------------------------------------------- */
 
@@ -258,18 +264,18 @@ enum { RM_PLANE_COLOR = 0, RM_PLANE_NORMAL_DOF = 1, RM_PLANE_ALBEDO_DEPTH = 2 };
 /* Replaces loadRenderJobContext(gl) (LoadRenderJobContext.tsx:268-287): binds
  * a device, creates the stream the launches go to.  Fails with
  * RM_ERR_NO_DEVICE when there is no GPU -- there is no CPU path. */
-int rm_ctx_create(int device, rm_ctx** out);
-void rm_ctx_destroy(rm_ctx* ctx);
+RM_API int rm_ctx_create(int device, rm_ctx** out);
+RM_API void rm_ctx_destroy(rm_ctx* ctx);
 /* Text of the last error on this context ("" if none); ctx may be NULL for
  * errors of rm_ctx_create itself.  Replaces ShaderError.infoLog. */
-const char* rm_last_error(const rm_ctx* ctx);
+RM_API const char* rm_last_error(const rm_ctx* ctx);
 /* Use an externally owned hipStream_t (e.g. torch's current stream) for all
  * later launches; NULL restores the context's own stream.  The switch is
  * ordered on the device (an event, no host wait): work this library queued on
  * the old stream -- the zeroing of rm_fb_create / rm_fb_clear, uploads,
  * renders -- completes before anything enqueued on the new stream after the
  * call.  The old stream must still exist when this is called. */
-int rm_ctx_set_stream(rm_ctx* ctx, void* hip_stream);
+RM_API int rm_ctx_set_stream(rm_ctx* ctx, void* hip_stream);
 /* Samples in flight (default 3, 1 = off; environment RM_SAMPLES_IN_FLIGHT).  The reference submits its draw calls
  * back to back (RenderJobExecutor.tsx:240-260) and the GPU overlaps them; here a full-mode sample of the pixel
  * kernel renders on an internal side stream into a staging buffer (it reads no plane) and a small kernel on the
@@ -277,11 +283,11 @@ int rm_ctx_set_stream(rm_ctx* ctx, void* hip_stream);
  * overlap.  Every call is still ordered on the context's stream as far as the planes are concerned: work enqueued
  * there afterwards sees the sample blended.  The planes receive the same bits as without overlap.  Costs 3 planes
  * of staging per sample in flight. */
-int rm_ctx_set_samples_in_flight(rm_ctx* ctx, int n);
+RM_API int rm_ctx_set_samples_in_flight(rm_ctx* ctx, int n);
 /* Advice that came with the last rm_ctx_set_samples_in_flight that SUCCEEDED ("" = none): the process environment
  * (GPU_MAX_HW_QUEUES < 8, read by the HIP runtime when it starts) will keep the samples from overlapping.  Not an
  * error: rm_last_error is for failures only.  The pointer stays valid until the next such call on the context. */
-const char* rm_ctx_last_warning(const rm_ctx* ctx);
+RM_API const char* rm_ctx_last_warning(const rm_ctx* ctx);
 /* Samples per launch of rm_render_samples (default 0 = automatic, 1 = one launch per sample, 2..8 = fixed).  A small
  * window -- one GPU's rows of a sharded frame -- has too few workgroups to keep the chip busy to the end of a launch
  * (a ray is a serial chain of ~1 ms); rm_render_samples therefore renders up to 8 consecutive samples of the job in
@@ -290,12 +296,12 @@ const char* rm_ctx_last_warning(const rm_ctx* ctx);
  * about 16 384 workgroups (a whole 3840x2160 frame has 16 320, so whole frames are not batched), within a staging
  * budget of a quarter of the device's free memory.  Staging costs 48 bytes per pixel of the TILE a launch renders, per
  * sample of a batch and per launch in flight; a launch whose staging cannot be allocated renders unstaged (same bits). */
-int rm_ctx_set_sample_batch(rm_ctx* ctx, int n);
+RM_API int rm_ctx_set_sample_batch(rm_ctx* ctx, int n);
 /* Cost-ordered dispatch (default on; environment RM_COST_ORDER=0 turns it off).  From the second sample of a job on
  * (same framebuffer window, tile and scene kind, >= 512 workgroups), the pixel kernel starts its tiles in the order of
  * their cost in the previous sample, most expensive first, so that a launch does not end on a few late, long
  * workgroups.  Scheduling only: the planes receive the same bits. */
-int rm_ctx_set_cost_order(rm_ctx* ctx, int on);
+RM_API int rm_ctx_set_cost_order(rm_ctx* ctx, int on);
 /* RM_RENDER_FAST only, opt-in: a marching lane counts as settled once its step
  * |d| <= eps * max(1, |p|_inf).  The default is 0: only the exact test
  * (position bitwise unchanged), which is what RM_RENDER_STRICT always uses.
@@ -305,7 +311,7 @@ int rm_ctx_set_cost_order(rm_ctx* ctx, int on);
  * Mandelbulb, 32 spp, mean of the lit pixels against the parity build:
  * eps 2^-25 +0.7 %, 2^-24 +2.9 %, 2^-23 +4.7 %, 2^-21 +6.8 %, 1e-5 +14 %, for
  * 1 %, 3 %, 8 %, 12 % and 28 % less time (tools/eps_study.py). */
-int rm_ctx_set_retire_eps(rm_ctx* ctx, float eps);
+RM_API int rm_ctx_set_retire_eps(rm_ctx* ctx, float eps);
 /* Parity mode of the strict build: on != 0 makes everything this context does WITHOUT RM_RENDER_FAST -- rm_render_sample(s),
  * rm_probe*, rm_present* -- compute in the arithmetic of the GL stack the reference's golden images were rendered under
  * (SwiftShader as shipped in HeadlessChrome 88): its sin / cos / log / exp / pow / acos / atan as IEEE operation sequences,
@@ -317,7 +323,7 @@ int rm_ctx_set_retire_eps(rm_ctx* ctx, float eps);
  * other arithmetic of this library uses for tan(), see RmUniforms / DESIGN.md) by that stack's own tan = sin / cos: what the
  * reference's UNMODIFIED shader text computes under it, random stream and camera included (that switch is one per DEVICE:
  * the GL-stack contexts of a device share it, and changing it waits for the device). */
-int rm_ctx_set_gl_stack(rm_ctx* ctx, int on);
+RM_API int rm_ctx_set_gl_stack(rm_ctx* ctx, int on);
 /* Culling grids (long primitive tables without domain rows; RM_RENDER_NO_CULL): a scene's grid is built -- on the context's
  * stream, in front of the render that asks for it -- once the scene has been asked for `pixels` pixel-samples since it was
  * created (default 4 Mi: a 4K frame's first sample builds it, a host that shows a NEW scene in every 1080p frame, like the
@@ -325,33 +331,33 @@ int rm_ctx_set_gl_stack(rm_ctx* ctx, int on);
  * same bits with and without a grid.  rm_ctx_cull_stats: out4 = {grids built so far, bytes held now, grids held now, the
  * budget in bytes (a sixteenth of the device's memory, at most 1 GiB: beyond it the least recently rendered scene gives its
  * grid up and renders on without one)}. */
-int rm_ctx_set_cull_min_pixels(rm_ctx* ctx, long long pixels);
-int rm_ctx_set_cull_budget(rm_ctx* ctx, size_t bytes); /* the bytes a context's grids may hold (a host that knows its memory better; the tests: small, to see grids go) */
-int rm_ctx_cull_stats(const rm_ctx* ctx, unsigned long long* out4);
+RM_API int rm_ctx_set_cull_min_pixels(rm_ctx* ctx, long long pixels);
+RM_API int rm_ctx_set_cull_budget(rm_ctx* ctx, size_t bytes); /* the bytes a context's grids may hold (a host that knows its memory better; the tests: small, to see grids go) */
+RM_API int rm_ctx_cull_stats(const rm_ctx* ctx, unsigned long long* out4);
 /* Diagnostics of the wavefront march, filled only by builds compiled with
  * -DRM_WF_STATS (zeros otherwise): out16[8*shadow + 4*pass2 + {0,1,2}] =
  * rays marched, lane-steps, wave-steps since the last reset. */
-int rm_debug_counters(rm_ctx* ctx, unsigned long long* out16, int reset);
+RM_API int rm_debug_counters(rm_ctx* ctx, unsigned long long* out16, int reset);
 
 /* Debug (tests): the rows of a primitive table (no domain rows) that an evaluation anywhere in the ball (centre, radius) has
  * to fold -- what the culling grid stores per cell (RM_RENDER_NO_CULL) -- as (nprims + 63) / 64 64-bit words,
  * bit i = row i stays (row 0 always does); `margin` = the allowance for fp32 rounding (0 tests the rule in
  * exact arithmetic).  Host arithmetic:
  * needs no GPU and no context.  Returns RM_ERR_INVALID for a table with domain rows. */
-int rm_debug_cull_cell(const RmSceneDesc* desc, const double* centre, double radius, double margin, unsigned long long* out_words);
+RM_API int rm_debug_cull_cell(const RmSceneDesc* desc, const double* centre, double radius, double margin, unsigned long long* out_words);
 /* Which implementation of the per-pixel program the LAST rm_render_sample(s) / rm_render_timed call on this context
  * dispatched (the library picks per job unless a flag forces one; same results either way): what a host reports next to a
  * timing instead of re-deriving the library's rule. */
 enum { RM_PIPELINE_NONE = 0, RM_PIPELINE_PIXEL_KERNEL = 1, RM_PIPELINE_WAVEFRONT = 2 };
-int rm_ctx_last_pipeline(const rm_ctx* ctx);
+RM_API int rm_ctx_last_pipeline(const rm_ctx* ctx);
 /* Free and total memory of the context's GPU (hipMemGetInfo): what a host sizes its frames against -- the planes of
  * a W x H frame take 48 W H bytes, staging 48 W H per sample in flight or in a batch, the wavefront pipeline 240 bytes
  * per pixel of a launch (the reference asks MAX_TEXTURE_SIZE instead). */
-int rm_device_memory(rm_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
+RM_API int rm_device_memory(rm_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 /* Completion point: the reference's generator yield / present cadence
  * (RenderJobExecutor.tsx:163-166) maps to "enqueue samples, rm_sync, present". */
-int rm_sync(rm_ctx* ctx);
-int rm_abi_version(void);
+RM_API int rm_sync(rm_ctx* ctx);
+RM_API int rm_abi_version(void);
 
 /* ---- scene ------------------------------------------------------------- */
 
@@ -360,8 +366,8 @@ int rm_abi_version(void);
  * description (the analogue of a GLSL compile) and uploads the primitive
  * table.  On failure returns RM_ERR_INVALID and rm_last_error() is the
  * "info log". */
-int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out);
-void rm_scene_destroy(rm_scene* scene);
+RM_API int rm_scene_create(rm_ctx* ctx, const RmSceneDesc* desc, rm_scene** out);
+RM_API void rm_scene_destroy(rm_scene* scene);
 
 /* ---- framebuffers ------------------------------------------------------ */
 
@@ -374,7 +380,7 @@ void rm_scene_destroy(rm_scene* scene);
  * [row_begin, row_begin+row_count) of a width x height image (row sharding
  * across GPUs): pixel coordinates, texcoord and aspect stay global.
  * Planes are zero-initialised.  Row 0 is the BOTTOM row (GL convention). */
-int rm_fb_create(rm_ctx* ctx, int width, int height, int row_begin, int row_count, rm_fb** out);
+RM_API int rm_fb_create(rm_ctx* ctx, int width, int height, int row_begin, int row_count, rm_fb** out);
 /* Row-striped window for sharding one image over several GPUs with balanced
  * cost: the frame is cut into stripes of `stripe_rows` rows and this
  * framebuffer holds, packed in ascending order, the stripes k with
@@ -382,35 +388,35 @@ int rm_fb_create(rm_ctx* ctx, int width, int height, int row_begin, int row_coun
  * rm_fb_rows() tells how many rows that is.  Planes may be caller-owned
  * (non-NULL color; normal_dof/albedo_depth both or neither) or NULL to let the
  * library allocate them.  Pixel coordinates stay global as in rm_fb_create. */
-int rm_fb_create_striped(rm_ctx* ctx, int width, int height, int stripe_rows, int parts, int part,
+RM_API int rm_fb_create_striped(rm_ctx* ctx, int width, int height, int stripe_rows, int parts, int part,
                          void* color, void* normal_dof, void* albedo_depth, rm_fb** out);
 /* Number of image rows a framebuffer holds; width / height of the image it is a window of. */
-int rm_fb_rows(const rm_fb* fb);
-int rm_fb_width(const rm_fb* fb);
-int rm_fb_height(const rm_fb* fb);
+RM_API int rm_fb_rows(const rm_fb* fb);
+RM_API int rm_fb_width(const rm_fb* fb);
+RM_API int rm_fb_height(const rm_fb* fb);
 /* Same, but over caller-owned device memory (e.g. torch tensors): each plane
  * pointer addresses row_count*width float4; normal_dof/albedo_depth may be
  * NULL (then only RM_RENDER_COLOR_ONLY renders are accepted). */
-int rm_fb_wrap(rm_ctx* ctx, int width, int height, int row_begin, int row_count,
+RM_API int rm_fb_wrap(rm_ctx* ctx, int width, int height, int row_begin, int row_count,
                void* color, void* normal_dof, void* albedo_depth, rm_fb** out);
 /* The clear-on-new-frameid of LoadRenderJobContext.tsx:196-208. */
-int rm_fb_clear(rm_fb* fb);
-void rm_fb_destroy(rm_fb* fb);
+RM_API int rm_fb_clear(rm_fb* fb);
+RM_API void rm_fb_destroy(rm_fb* fb);
 /* Copies one plane (row_count*width*4 floats) to / from host memory; synchronous. */
-int rm_fb_download(rm_fb* fb, int plane, float* host);
-int rm_fb_upload(rm_fb* fb, int plane, const float* host);
+RM_API int rm_fb_download(rm_fb* fb, int plane, float* host);
+RM_API int rm_fb_upload(rm_fb* fb, int plane, const float* host);
 /* Device address of a plane (for collectives / zero-copy wrapping). */
-void* rm_fb_device_ptr(rm_fb* fb, int plane);
+RM_API void* rm_fb_device_ptr(rm_fb* fb, int plane);
 
 /* Raw device memory for hosts that have no allocator of their own: rm_present_rows, rm_present_device and
  * rm_assemble_striped_bytes take DEVICE pointers (in the reference these are textures the GL context owns,
  * LoadRenderJobContext.tsx:43-124; a torch host passes tensor addresses instead).  Created zero-filled; the copies
  * take the buffer's base address and at most its size, are synchronous and ordered after the work on the context's
  * stream; rm_ctx_destroy frees what is left. */
-int rm_buffer_create(rm_ctx* ctx, size_t bytes, void** device_ptr);
-int rm_buffer_destroy(rm_ctx* ctx, void* device_ptr);
-int rm_buffer_download(rm_ctx* ctx, const void* device_ptr, void* host, size_t bytes);
-int rm_buffer_upload(rm_ctx* ctx, void* device_ptr, const void* host, size_t bytes);
+RM_API int rm_buffer_create(rm_ctx* ctx, size_t bytes, void** device_ptr);
+RM_API int rm_buffer_destroy(rm_ctx* ctx, void* device_ptr);
+RM_API int rm_buffer_download(rm_ctx* ctx, const void* device_ptr, void* host, size_t bytes);
+RM_API int rm_buffer_upload(rm_ctx* ctx, void* device_ptr, const void* host, size_t bytes);
 
 /* ---- the hot path ------------------------------------------------------ */
 
@@ -419,7 +425,7 @@ int rm_buffer_upload(rm_ctx* ctx, void* device_ptr, const void* host, size_t byt
  * (RenderJobExecutor.tsx:195-326) = one run of raymarcher.frag main()
  * (raymarcher.frag:178-388) per pixel.  tile == NULL means the whole window.
  * Asynchronous on the context's stream. */
-int rm_render_sample(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* uniforms,
+RM_API int rm_render_sample(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* uniforms,
                      const RmRect* tile, int flags);
 
 /* `count` samples back to back, sample i using randNoise[i] (pairs); every
@@ -428,13 +434,13 @@ int rm_render_sample(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* 
  * sample).  Same planes, bit for bit, as `count` calls of rm_render_sample;
  * full-mode samples of the pixel kernel go out several to a launch (see
  * rm_ctx_set_sample_batch). */
-int rm_render_samples(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* uniforms,
+RM_API int rm_render_samples(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* uniforms,
                       const float* rand_noise_pairs, int count, const RmRect* tile, int flags);
 
 /* Like rm_render_samples with one fixed randNoise, but brackets the `count`
  * launches with HIP events on the context's stream and returns the average
  * kernel time per launch in *ms_per_launch (synchronous). */
-int rm_render_timed(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* uniforms,
+RM_API int rm_render_timed(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* uniforms,
                     int count, const RmRect* tile, int flags, float* ms_per_launch);
 
 /* ---- probes (RNG-free building blocks of the path) --------------------- */
@@ -455,18 +461,18 @@ int rm_render_timed(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms* u
  * A table of 16 rows or more is marched as its pixel kernels march it (the long tables' far-field exits included).
  */
 enum { RM_PROBE_SDF = 0, RM_PROBE_CAST_RAY = 1, RM_PROBE_NORMAL = 2, RM_PROBE_MATERIAL = 3, RM_PROBE_CAST_STEPS = 4, RM_PROBE_CAST_SHADOW = 5 };
-int rm_probe(rm_ctx* ctx, rm_scene* scene, int what, const float* in, int n, float param,
+RM_API int rm_probe(rm_ctx* ctx, rm_scene* scene, int what, const float* in, int n, float param,
              int flags, float* out);
 
 /* Camera block of main() without jitter or depth of field
  * (raymarcher.frag:186-205 with randomDirectionOffset = dofOffset = 0):
  * out = height*width x 8 floats (origin.xyz, deltaZ, dir.xyz, 0), HOST pointer. */
-int rm_probe_camera(rm_ctx* ctx, const RmUniforms* uniforms, int width, int height, float* out);
+RM_API int rm_probe_camera(rm_ctx* ctx, const RmUniforms* uniforms, int width, int height, float* out);
 
 /* The per-pixel random stream (raymarcher.frag:46-49,78-101): for each pixel
  * of a width x height image the first `count` values of uniformSample().
  * out = height*width*count floats, HOST pointer. */
-int rm_probe_rng(rm_ctx* ctx, const RmUniforms* uniforms, int width, int height, int count, float* out);
+RM_API int rm_probe_rng(rm_ctx* ctx, const RmUniforms* uniforms, int width, int height, int count, float* out);
 
 /* The transcendental functions of the parity arithmetic on arrays, as the kernels call them: the fp32 sequences of
  * csrc/rm_pm_math.hpp (the text of oracle/pm_math.h), or the GL stack's (rm_ss_math.hpp = oracle/ss_math.h) on a context
@@ -478,7 +484,7 @@ int rm_probe_rng(rm_ctx* ctx, const RmUniforms* uniforms, int width, int height,
  * for the functions of one argument.  Test infrastructure like rm_probe: no part of a render job calls it. */
 enum { RM_MATH_SIN = 0, RM_MATH_COS = 1, RM_MATH_LOG = 2, RM_MATH_EXP = 3, RM_MATH_POW = 4, RM_MATH_ACOS = 5, RM_MATH_ATAN2 = 6, RM_MATH_TAN = 7,
        RM_MATH_POW_PAIR_NM1 = 8, RM_MATH_POW_PAIR_N = 9, RM_MATH_SINCOS_S = 10, RM_MATH_SINCOS_C = 11, RM_MATH_SQRT = 12, RM_MATH_DIV = 13, RM_MATH_COUNT = 14 };
-int rm_probe_math(rm_ctx* ctx, int fn, const float* a, const float* b, int n, float* out);
+RM_API int rm_probe_math(rm_ctx* ctx, int fn, const float* a, const float* b, int n, float* out);
 
 /* ---- assembling a sharded frame ------------------------------------------ */
 
@@ -489,11 +495,11 @@ int rm_probe_math(rm_ctx* ctx, int fn, const float* a, const float* b, int n, fl
  * multi-GPU host runs on the rank that shows the frame, after the gather (raymarching_engine_amd/dist.py).
  * hip_stream: the hipStream_t to launch on, NULL = the context's stream (a host that keeps rendering while the
  * frame is put together gives it a stream of its own, ordered after the gather). */
-int rm_assemble_striped(rm_ctx* ctx, const void* src, int parts, int max_rows, int width, int height, int stripe_rows, void* dst,
+RM_API int rm_assemble_striped(rm_ctx* ctx, const void* src, int parts, int max_rows, int width, int height, int stripe_rows, void* dst,
                         void* hip_stream);
 /* The same for rows of `row_bytes` opaque bytes (a multiple of 4; buffers 16-byte aligned): RGBA8 rows after the
  * per-rank present (rm_present_rows, row_bytes = 4 * width), or any other per-pixel payload. */
-int rm_assemble_striped_bytes(rm_ctx* ctx, const void* src, int parts, int max_rows, long long row_bytes, int height, int stripe_rows,
+RM_API int rm_assemble_striped_bytes(rm_ctx* ctx, const void* src, int parts, int max_rows, long long row_bytes, int height, int stripe_rows,
                               void* dst, void* hip_stream);
 
 /* ---- present ----------------------------------------------------------- */
@@ -506,19 +512,19 @@ int rm_assemble_striped_bytes(rm_ctx* ctx, const void* src, int parts, int max_r
  * so rm_present needs a framebuffer holding the whole frame; for a sharded
  * frame gather the planes first and use rm_present_planes (device pointers;
  * normal_dof may be NULL = no blur). */
-int rm_present(rm_ctx* ctx, rm_fb* fb, int samples, uint8_t* out_rgba8);
-int rm_present_planes(rm_ctx* ctx, const void* color, const void* normal_dof, int width, int height, int samples, uint8_t* out_rgba8);
+RM_API int rm_present(rm_ctx* ctx, rm_fb* fb, int samples, uint8_t* out_rgba8);
+RM_API int rm_present_planes(rm_ctx* ctx, const void* color, const void* normal_dof, int width, int height, int samples, uint8_t* out_rgba8);
 /* The same pass left on the device and asynchronous: out_rgba8_device = height*width*4 bytes of DEVICE memory,
  * launched on hip_stream (NULL = the context's stream); no allocation, no host wait.  For a host that shows the
  * frame from device memory or reads it back itself (index.tsx:25-59 draws straight to the canvas). */
-int rm_present_device(rm_ctx* ctx, const void* color, const void* normal_dof, int width, int height, int samples,
+RM_API int rm_present_device(rm_ctx* ctx, const void* color, const void* normal_dof, int width, int height, int samples,
                       void* out_rgba8_device, void* hip_stream);
 /* The present pass of the rows ONE framebuffer window holds, for jobs without depth of field (dof.amount = 0: the
  * blur radius of display.frag:24-27 is 0 and its only tap is the pixel itself, so no neighbour row is needed and
  * the bytes equal rm_present's).  out_rgba8_device = rm_fb_rows(fb)*width*4 bytes of DEVICE memory, in the
  * window's own row order.  This is what a sharded run gathers instead of the fp32 colour plane: a quarter of the
  * bytes (raymarching_engine_amd/dist.py); rm_assemble_striped_bytes puts the stripes in image order. */
-int rm_present_rows(rm_ctx* ctx, rm_fb* fb, int samples, void* out_rgba8_device, void* hip_stream);
+RM_API int rm_present_rows(rm_ctx* ctx, rm_fb* fb, int samples, void* out_rgba8_device, void* hip_stream);
 /* What a sharded job WITH depth of field gathers instead: the blur of display.frag:44-55 reads up to 16 rows either
  * side of a pixel, rows that other GPUs hold, so the present pass has to run where the whole frame is.  It reads two
  * things per pixel -- the accumulated colour (display.frag:19,53) and the accumulated DoF radius, normalAndDofRadius.w
@@ -528,7 +534,7 @@ int rm_present_rows(rm_ctx* ctx, rm_fb* fb, int samples, void* out_rgba8_device,
  * passed to rm_present_device / rm_present_planes as BOTH `color` and `normal_dof` (they read .rgb of the one and .w of
  * the other): the bytes are those rm_present gives for the unsharded frame (raymarching_engine_amd/dist.py,
  * index.tsx:25-59 is the caller this serves). */
-int rm_pack_present_rows(rm_ctx* ctx, rm_fb* fb, void* out_float4_device, void* hip_stream);
+RM_API int rm_pack_present_rows(rm_ctx* ctx, rm_fb* fb, void* out_float4_device, void* hip_stream);
 /* The present pass (display.frag:16-64) of ONE PART of a striped frame: `color` / `normal_dof` are DEVICE pointers to the WHOLE
  * frame in image order (height x width float4 each; with depth of field the gathered and assembled rows of
  * rm_pack_present_rows serve as both), out_rgba8_device receives the rows part `part` of `parts` holds (stripes of
@@ -537,7 +543,7 @@ int rm_pack_present_rows(rm_ctx* ctx, rm_fb* fb, void* out_float4_device, void* 
  * rm_present's.  This is how a sharded frame WITH depth of field is shown without one GPU blurring all of it: every
  * GPU gets the packed frame (an all-gather), blurs the stripes it holds -- 1 / parts of the pass -- and only RGBA8
  * travels to the GPU that shows the frame.  Asynchronous on hip_stream (NULL = the context's stream). */
-int rm_present_striped_rows(rm_ctx* ctx, const void* color, const void* normal_dof, int width, int height, int samples, int stripe_rows, int parts, int part,
+RM_API int rm_present_striped_rows(rm_ctx* ctx, const void* color, const void* normal_dof, int width, int height, int samples, int stripe_rows, int parts, int part,
                             void* out_rgba8_device, void* hip_stream);
 
 /* The present of a frame that ONE process renders on several GPUs -- the shape of the reference's own host: one
@@ -560,9 +566,9 @@ int rm_present_striped_rows(rm_ctx* ctx, const void* color, const void* normal_d
  *   rm_present_sharded: both, one after the other (synchronous).
  * (Hosts with a process per GPU -- bench.py, job.RenderJobContext(group=...) -- move the same rows over RCCL instead:
  * raymarching_engine_amd/dist.py.) */
-int rm_present_sharded_start(rm_ctx* const* ctxs, rm_fb* const* fbs, int parts, int samples, int dof);
-int rm_present_sharded_finish(rm_ctx* const* ctxs, int parts, uint8_t* out_rgba8, size_t out_bytes);
-int rm_present_sharded(rm_ctx* const* ctxs, rm_fb* const* fbs, int parts, int samples, int dof, uint8_t* out_rgba8, size_t out_bytes);
+RM_API int rm_present_sharded_start(rm_ctx* const* ctxs, rm_fb* const* fbs, int parts, int samples, int dof);
+RM_API int rm_present_sharded_finish(rm_ctx* const* ctxs, int parts, uint8_t* out_rgba8, size_t out_bytes);
+RM_API int rm_present_sharded(rm_ctx* const* ctxs, rm_fb* const* fbs, int parts, int samples, int dof, uint8_t* out_rgba8, size_t out_bytes);
 
 #ifdef __cplusplus
 }

@@ -151,8 +151,9 @@ def gen_rng():
     save("portable_tan", x=g[..., 0].reshape(-1), tan=g[..., 1].reshape(-1))
 
 
-def gen_image(only=None):
-    """Unmodified main() of the reference (tan routed to the portable tangent):
+def gen_image(only=None, native=False):
+    """Unmodified main() of the reference (tan routed to the portable tangent; `native`, round 6: the text exactly
+    as it stands, its own tan() -> image_<case>_native.npz):
     three planes after `samples` draws with the Halton(2,3) randNoise sequence.
     `only`: a list of case names (python oracle/gl/gen_golden.py image:case1,case2)."""
     for case in (only or GC.IMAGES):
@@ -164,14 +165,16 @@ def gen_image(only=None):
         noise = GC.halton_pairs(samples)
         base = glref.uniforms_from_schema(schema, noise[0])
         draws = [{"randNoise": glref.u_float(*n)} for n in noise]
-        frag = glref.with_portable_tan(glref.splice(text))
+        frag = glref.splice(text) if native else glref.with_portable_tan(glref.splice(text))
         t0 = time.time()
         r = glref.run_gl(frag, GC.IMG_W, GC.IMG_H, base, draws=draws, read=(0, 1, 2))
         pl = r["planes"]
         arrays = dict(color=pl[0], samples=np.int32(samples), rand_noise=np.array(noise, np.float64))
         if schema["render"]["renderMode"] == "full":
             arrays.update(normal_dof=pl[1], albedo_depth=pl[2])
-        save(f"image_{case}", **arrays)
+        save(f"image_{case}" + ("_native" if native else ""), **arrays)
+    if native:
+        return
     info = {k: r["info"][k] for k in ("version", "glsl", "renderer", "cores", "ua")}
     (OUT / "gl_info.json").write_text(json.dumps(info, indent=1))
 
@@ -212,7 +215,7 @@ def gen_display():
         save(f"display_{name}", color=r["planes"][0], normal_dof=r["planes"][1], samples=np.int32(n), rgba8=r["display"])
 
 
-GROUPS = {"display": gen_display, "texcoord": gen_texcoord, "sdf": gen_sdf, "cast": gen_cast, "misc": gen_misc, "rng": gen_rng, "image": gen_image, "stat": gen_stat}
+GROUPS = {"display": gen_display, "texcoord": gen_texcoord, "sdf": gen_sdf, "cast": gen_cast, "misc": gen_misc, "rng": gen_rng, "image": gen_image, "image_native": lambda only=None: gen_image(only, native=True), "stat": gen_stat}
 
 if __name__ == "__main__":
     if not glref.available():

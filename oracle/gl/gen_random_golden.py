@@ -305,37 +305,48 @@ def math(n_side: int = 128):
     print("wrote", dest, dest.stat().st_size, "B")
 
 
-def configs():
-    """tests/golden/config_<name>.npz: BASELINE.json's configurations -- the headline C3b (Mandelbulb, full, [256], the point
-    light), C3a, C2, C4 and C5 with their own scenes, step counts, lights and cameras (tests/golden_cases.py CONFIGS) -- through
-    the reference's main() under software GL at 256 x 128 / 128 x 128, tan routed to the portable tangent."""
+def _frag(sc, native: bool) -> str:
+    """The reference's shader with the scene spliced in: as it stands (`native`: its own tan() in the random stream and the
+    camera, raymarcher.frag:46-49) or with tan routed to the portable tangent (glref.PORTABLE_TAN_GLSL)."""
+    frag = glref.splice(sc.glsl())
+    return frag if native else glref.with_portable_tan(frag)
+
+
+def configs(native: bool = False, only=()):
+    """tests/golden/config_<name>[_native].npz: BASELINE.json's configurations -- the headline C3b (Mandelbulb, full, [256], the
+    point light), C3a, C2, C4 and C5 with their own scenes, step counts, lights and cameras (tests/golden_cases.py CONFIGS) --
+    through the reference's main() under software GL at 256 x 128 / 128 x 128.  `native` (round 6): from the UNMODIFIED text;
+    otherwise tan routed to the portable tangent."""
     import golden_cases as GC
 
     for name in GC.CONFIGS:
+        if only and name not in only:
+            continue
         sc, schema, noise = GC.config_case(name)
         w, h = schema["render"]["width"], schema["render"]["height"]
         schema = dict(schema); schema["sdfShaderSource"] = sc.glsl()
         base = glref.uniforms_from_schema(schema, noise[0])
         draws = [{"randNoise": glref.u_float(*x)} for x in noise]
-        pl = glref.run_gl(glref.with_portable_tan(glref.splice(sc.glsl())), w, h, base, draws=draws, read=(0, 1, 2))["planes"]
+        pl = glref.run_gl(_frag(sc, native), w, h, base, draws=draws, read=(0, 1, 2))["planes"]
         arrays = dict(color=pl[0])
         if schema["render"]["renderMode"] == "full":
             arrays.update(normal_dof=pl[1], albedo_depth=pl[2])
-        dest = ROOT / "tests" / "golden" / f"config_{name}.npz"
+        dest = ROOT / "tests" / "golden" / f"config_{name}{'_native' if native else ''}.npz"
         np.savez_compressed(dest, **arrays)
         print("wrote", dest, dest.stat().st_size, "B, finite", float(np.isfinite(pl[0]).all(-1).mean()))
 
 
-def fullsize():
-    """tests/golden/rows_<name>.npz: BASELINE configurations at megapixel size -- the headline C3b at 2048 x 1024, C4 at
-    1024 x 1024 -- through the reference's main() under software GL (portable tangent); the planes stay here, the fixture is a
-    CRC-32 per row and plane (tests/golden_cases.py row_checksums) plus the share of finite pixels per row."""
+def fullsize(native: bool = False, only=()):
+    """tests/golden/rows_<name>[_native].npz: BASELINE configurations at megapixel size -- the headline C3b at 2048 x 1024 and
+    4096 x 2048, C4 at 1024 x 1024 ... -- through the reference's main() under software GL (`native`: the unmodified text;
+    otherwise the portable tangent); the planes stay here, the fixture is a CRC-32 per row and plane (tests/golden_cases.py
+    row_checksums) plus the share of finite pixels per row."""
     import time
 
     import golden_cases as GC
 
     for name in GC.ROW_CHECKSUM_CASES:
-        if len(sys.argv) > 2 and name not in sys.argv[2:]:
+        if only and name not in only:
             continue
         sc, schema, noise = GC.row_checksum_case(name)
         w, h = schema["render"]["width"], schema["render"]["height"]
@@ -343,15 +354,15 @@ def fullsize():
         base = glref.uniforms_from_schema(schema, noise[0])
         t0 = time.time()
         out = {}
-        for k, plane in enumerate(("color", "normal_dof", "albedo_depth")):  # one plane per run: the read-back travels as text
-            pl = glref.run_gl(glref.with_portable_tan(glref.splice(sc.glsl())), w, h, base, draws=[{"randNoise": glref.u_float(*noise[0])}], read=(k,))["planes"][k]
+        for k, plane in enumerate(("color", "normal_dof", "albedo_depth") if schema["render"]["renderMode"] == "full" else ("color",)):  # one plane per run: the read-back travels as text
+            pl = glref.run_gl(_frag(sc, native), w, h, base, draws=[{"randNoise": glref.u_float(*noise[0])}], read=(k,))["planes"][k]
             out[plane] = GC.row_checksums(pl)
             if k == 0:
                 out["finite_share"] = np.isfinite(pl).all(-1).mean(1).astype(np.float32)
             del pl
-        dest = ROOT / "tests" / "golden" / f"rows_{name}.npz"
+        dest = ROOT / "tests" / "golden" / f"rows_{name}{'_native' if native else ''}.npz"
         np.savez_compressed(dest, **out)
-        print("wrote", dest, dest.stat().st_size, "B in", round(time.time() - t0), "s")
+        print("wrote", dest, dest.stat().st_size, "B in", round(time.time() - t0), "s", flush=True)
 
 
 if __name__ == "__main__":
@@ -363,9 +374,9 @@ if __name__ == "__main__":
         jobs()
     elif len(sys.argv) > 1 and sys.argv[1] == "math":
         math()
-    elif len(sys.argv) > 1 and sys.argv[1] == "configs":
-        configs()
-    elif len(sys.argv) > 1 and sys.argv[1] == "fullsize":
-        fullsize()
+    elif len(sys.argv) > 1 and sys.argv[1] in ("configs", "configs_native"):  # [case ...]
+        configs(sys.argv[1].endswith("_native"), sys.argv[2:])
+    elif len(sys.argv) > 1 and sys.argv[1] in ("fullsize", "fullsize_native"):  # [case ...]
+        fullsize(sys.argv[1].endswith("_native"), sys.argv[2:])
     else:
         main()

@@ -15,7 +15,8 @@ ARCH = "gfx950"
 
 # -fno-slp-vectorize: hipcc otherwise packs the scalar f32 chains of the distance estimators into
 # v_pk_*_f32 plus register shuffles, which is 7 % slower on the headline kernel (measured on MI355X)
-COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize"]
+# -fvisibility=hidden: the library exports the RM_API entry points of include/hip_raymarch.h and nothing else
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize", "-fvisibility=hidden"]
 # Both kernel units are contract-off: an FMA exists only where the code asks for one (rm_device.hpp FM::fma).
 # Neither gets -fno-hip-fp32-correctly-rounded-divide-sqrt: plain '/' and
 # sqrtf stay IEEE in both (the random stream relies on it); the fast build
@@ -36,7 +37,7 @@ def hipcc() -> str:
 
 
 def _sources_mtime() -> float:
-    files = list(CSRC.glob("*.hip")) + list(CSRC.glob("*.hpp")) + list(CSRC.glob("*.inc")) + [HERE.parent / "include" / "hip_raymarch.h"]
+    files = list(CSRC.glob("*.hip")) + list(CSRC.glob("*.hpp")) + list(CSRC.glob("*.inc")) + [CSRC / "exports.map", HERE.parent / "include" / "hip_raymarch.h"]
     return max(f.stat().st_mtime for f in files)
 
 
@@ -58,7 +59,7 @@ def build_native(force: bool = False, verbose: bool = False, extra=(), out: Path
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(compile_unit, UNITS))
-    cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", str(lib)] + [str(obj / f"{n}.o") for n in UNITS]
+    cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,--version-script=" + str(CSRC / "exports.map"), "-o", str(lib)] + [str(obj / f"{n}.o") for n in UNITS]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

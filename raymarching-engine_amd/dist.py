@@ -299,6 +299,17 @@ class ShardedFramebuffer:
             self._gatherers[payload] = g
         return g
 
+    def gathered_bytes_per_present(self, dof: Optional[bool] = None) -> int:
+        """Bytes the collectives of ONE present take into the receiving ranks' memory (padded windows, as they travel): the RGBA8
+        rows of every rank into rank 0; with depth of field also the packed float4 rows of every rank into EVERY rank."""
+        dof = self.dof if dof is None else dof
+        gr = self.group
+        window = max(shard.row_counts(self.height, gr.world, gr.stripe_rows)) * self.width
+        total = gr.world * window * 4
+        if dof:
+            total += gr.world * gr.world * window * 16
+        return total
+
     def start_present(self, samples: int, dof: Optional[bool] = None):
         """First half of present(): snapshot this rank's payload and start the gather (asynchronous)."""
         assert self._pending is None, "ShardedFramebuffer: finish_present() before the next start_present()"

@@ -263,15 +263,17 @@ class RenderJobContext:
             except native.RmError as e:  # cached like a failed compile
                 hit = {"type": "fragment", "infoLog": str(e)}
             self._scenes[key] = hit
-            self._evict()
+            self._evict(keep=key)  # (never the entry being handed out: with 64 pinned scenes it is the only unpinned one)
         else:
             self._scenes.move_to_end(key)
         return hit
 
-    def _evict(self):
+    def _evict(self, keep=None):
+        """Least recently used out first; pinned scenes and `keep` (the key a caller is about to use) stay -- the cache exceeds its
+        64 entries while everything in it is in use."""
         spare = len(self._scenes) - SCENE_CACHE_ENTRIES
         pins = self.__dict__.setdefault("_pins", {})
-        for k in [k for k in self._scenes if k not in pins][:max(spare, 0)]:  # least recently used first; pinned scenes stay
+        for k in [k for k in self._scenes if k not in pins and k != keep][:max(spare, 0)]:
             old = self._scenes.pop(k)
             if not isinstance(old, dict) and hasattr(old, "destroy"):
                 old.destroy()  # (rm_scene_destroy waits for the renders that use it)
@@ -430,6 +432,7 @@ def do_render_job(schema: dict, context: RenderJobContext):
                         else:
                             context.native.render_samples(handle, fb, u, noise, tile, context.flags)
                     except _native.RmError as e:  # errors are values (RenderJobExecutor.tsx:56-68)
+                        context.fbo_delete(r["width"], r["height"], r["frameid"])  # the frame goes back to the cache on this path too
                         return {"success": False, "why": {"type": "general", "infoLog": "render failed: " + str(e)}}
                     samples += k
                     left -= k

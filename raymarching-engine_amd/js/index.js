@@ -241,11 +241,11 @@ function tileRect(schema, xp, yp) {
 // are bounded by the library itself, by bytes: rm_ctx_cull_stats).  A scene a job still renders is pinned (doRenderJob: jobs yield
 // between samples) and is never the one that goes.
 const SCENE_CACHE_ENTRIES = 64;
-function evictScenes(map, destroy, pins) {
+function evictScenes(map, destroy, pins, keep) {  // `keep`: the key being handed out (with 64 pinned scenes it is the only unpinned one)
   let spare = map.size - SCENE_CACHE_ENTRIES;
   for (const k of Array.from(map.keys())) {
     if (spare <= 0) break;
-    if (pins && pins.get(k) > 0) continue;
+    if ((pins && pins.get(k) > 0) || k === keep) continue;
     const v = map.get(k); map.delete(k); destroy(v); spare--;
   }
 }
@@ -258,13 +258,13 @@ class RenderJobContext {  // RenderJobContext + loadRenderJobContext (LoadRender
   constructor(device = 0, flags = RM.RENDER_STRICT) {
     this.ctx = addon.ctxCreate(device); this.flags = flags; this.scenes = new Map(); this.pins = new Map(); this.live = new Map(); this.purgatory = [];
   }
-  evict() { evictScenes(this.scenes, (s) => { if (!(s && s.infoLog)) addon.sceneDestroy(s); }, this.pins); }
+  evict(keep) { evictScenes(this.scenes, (s) => { if (!(s && s.infoLog)) addon.sceneDestroy(s); }, this.pins, keep); }
   getScene(scene) {  // programCache.getProgram: results AND errors are cached (ShaderCache.tsx:91-119); bounded, least recently used out first
     const key = scene.key();
     if (!this.scenes.has(key)) {
       try { const d = scene.desc(); this.scenes.set(key, addon.sceneCreate(this.ctx, d.desc, d.prims, d.surfaces)); }
       catch (e) { this.scenes.set(key, { type: "fragment", infoLog: String(e.message) }); }
-      this.evict();
+      this.evict(key);
     } else { const hit = this.scenes.get(key); this.scenes.delete(key); this.scenes.set(key, hit); }
     return this.scenes.get(key);
   }
@@ -312,14 +312,14 @@ class ShardedRenderJobContext {
     this.ctx = this.ctxs[0];
     this.scenes = new Map(); this.pins = new Map(); this.live = new Map(); this.purgatory = [];
   }
-  evict() { evictScenes(this.scenes, (s) => { if (s.handles) for (const h of s.handles) addon.sceneDestroy(h); }, this.pins); }
+  evict(keep) { evictScenes(this.scenes, (s) => { if (s.handles) for (const h of s.handles) addon.sceneDestroy(h); }, this.pins, keep); }
   getScene(scene) {  // one handle per context; a failure (on any of them) is cached like a failed compile
     const key = scene.key();
     if (!this.scenes.has(key)) {
       const made = [];
       try { const d = scene.desc(); for (const c of this.ctxs) made.push(addon.sceneCreate(c, d.desc, d.prims, d.surfaces)); this.scenes.set(key, { handles: made }); }
       catch (e) { for (const h of made) addon.sceneDestroy(h); this.scenes.set(key, { type: "fragment", infoLog: String(e.message) }); }
-      this.evict();
+      this.evict(key);
     } else { const hit = this.scenes.get(key); this.scenes.delete(key); this.scenes.set(key, hit); }
     return this.scenes.get(key);
   }

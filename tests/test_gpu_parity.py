@@ -2334,6 +2334,8 @@ def test_bench_under_the_drivers_launcher_with_one_rank(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["steps"] == 4 and out["warmup"] == 2 and out["value"] > 100.0
     assert "gathered to rank 0 over RCCL" in out["config"]["sharding"] and out["roofline"]["frac"] > 0.2
+    c = out["collective"]
+    assert c["backend"] == "nccl" and c["world_size_seen"] == 1 and c["frame_check"] is True and out["frame_check"] is True
 
 
 def test_bench_with_four_ranks_sharing_this_gpu(tmp_path):
@@ -2350,7 +2352,7 @@ def test_bench_with_four_ranks_sharing_this_gpu(tmp_path):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, RM_BENCH_SHARE_GPU="1", RM_BENCH_BACKEND="gloo")
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "16", "--warmup", "8", "--no-cpu-baseline", "--check-frame"]
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "16", "--warmup", "8", "--no-cpu-baseline"]  # the driver's bare command: no flag asks for the check
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=500, env=env)
     except subprocess.TimeoutExpired as e:
@@ -2362,6 +2364,36 @@ def test_bench_with_four_ranks_sharing_this_gpu(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 4 and out["steps"] == 16 and out["value"] > 50.0 and out["config"]["sample_yield_interval"] == 8
     assert out["config"]["rows_per_gpu"] in (536, 544) and out["present_every_sample"]["value"] > 10.0
-    # --check-frame: the frame rank 0 assembled from the four ranks' gathered rows is, byte for byte, the present of the same
-    # 48 samples rendered on one framebuffer
+    # the frame check runs by default on a sharded run (round 6): the frame rank 0 assembled from the four ranks' gathered rows is,
+    # byte for byte, the present of the same 48 samples rendered on one framebuffer -- and the line says what the collective saw
     assert out["frame_check"] is True
+    c = out["collective"]
+    assert c["backend"] == "gloo" and c["world_size_seen"] == 4 and c["ranks_sharing_one_gpu"] is True and c["frame_check"] is True
+    assert c["payload"] == "rgba8" and c["gathered_bytes_per_present"] == 4 * 544 * 3840 * 4 and c["frame_check_samples"] == 48
+    assert out["workloads"] is None  # (the other configurations' legs belong to the one-GPU default invocation)
+
+
+def test_bench_default_line_carries_every_workload(tmp_path):
+    """`python bench.py` as the driver runs it at N = 1 (here with fewer steps and without the CPU leg): next to the headline the
+    line carries a `workloads` object -- C2, C3a, C4, C5 in the fast build, the headline in the strict build and in the GL stack's
+    arithmetic (the reference's bits) -- each leg with its step time, its kernel time and its rate; the ordering of the builds
+    is what DESIGN.md section 6 says it is."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "10", "--warmup", "3", "--repeats", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    w = out["workloads"]
+    assert sorted(w) == sorted(["c2_fast", "c3a_fast", "c4_fast", "c5_fast", "c3b_strict", "c3b_glstack"])
+    for key, leg in w.items():
+        assert leg["ms_per_step"] > 0 and leg["kernel_ms"] > 0 and leg["mpix_s"] > 0, key
+        assert leg["kernel_ms"] <= leg["ms_per_step"] * 1.25, (key, leg)  # a step is its kernel plus the host's share
+    assert out["ms_per_step"] < w["c3b_strict"]["ms_per_step"] < w["c3b_glstack"]["ms_per_step"] * 4
+    assert w["c2_fast"]["mpix_s"] > w["c3a_fast"]["mpix_s"] > out["value"] > w["c4_fast"]["mpix_s"] > w["c5_fast"]["mpix_s"]
+    assert out["collective"] is None and out["frame_check"] is None

@@ -78,31 +78,51 @@ def test_random_stream_is_the_reference_bit_for_bit(glctx):
     assert same_bits(glctx.probe_rng(u, 32, 32, 4), r["uniform4"]).all()
 
 
+TEXTS = ("portable_tan", "unmodified")
+
+
+@pytest.fixture
+def text_ctx(glctx, request):
+    """The GL-stack context set to the tangent of the text a golden was rendered from: rm_ctx_set_gl_stack(ctx, 1) for the
+    goldens with the portable tangent injected, (ctx, 2) -- the stack's own tan() -- for raymarcher.frag as it stands."""
+    text = request.param
+    glctx.set_gl_stack(2 if text == "unmodified" else 1)
+    yield glctx, ("_native" if text == "unmodified" else "")
+    glctx.set_gl_stack(1)
+
+
+@pytest.mark.parametrize("text_ctx", TEXTS, indirect=True)
 @pytest.mark.parametrize("case", list(GC.IMAGES))
-def test_whole_main_image_is_the_reference_bit_for_bit(glctx, case):
-    """All 29 image cases: every value of every plane the reference's main() wrote under its GL stack."""
+def test_whole_main_image_is_the_reference_bit_for_bit(text_ctx, case):
+    """All 29 image cases: every value of every plane the reference's main() wrote under its GL stack, for both texts."""
+    ctx, suffix = text_ctx
     sc, samples, schema = GC.image_schema(case)
-    z = load("image_" + case)
-    _planes_equal(z, render_gpu(glctx, sc, schema, z["rand_noise"], STRICT | MK), full="normal_dof" in z)
+    z = load("image_" + case + suffix)
+    _planes_equal(z, render_gpu(ctx, sc, schema, z["rand_noise"], STRICT | MK), full="normal_dof" in z)
 
 
+@pytest.mark.parametrize("text_ctx", TEXTS, indirect=True)
 @pytest.mark.parametrize("name", list(GC.CONFIGS))
-def test_baseline_configurations_are_the_reference_bit_for_bit(glctx, name):
+def test_baseline_configurations_are_the_reference_bit_for_bit(text_ctx, name):
     """BASELINE.json's configurations (the headline C3b, C3a, C2, C4, C5: their own scenes, step counts, lights, cameras) at
-    256 x 128 / 128 x 128: the GPU reproduces what the reference's main() rendered of them under its GL stack."""
+    256 x 128 / 128 x 128: the GPU reproduces what the reference's main() rendered of them under its GL stack -- from the text
+    with the portable tangent and (round 6) from the UNMODIFIED text."""
+    ctx, suffix = text_ctx
     sc, schema, noises = GC.config_case(name)
-    z = load("config_" + name)
-    _planes_equal(z, render_gpu(glctx, sc, schema, noises, STRICT | MK), full="normal_dof" in z)
+    z = load("config_" + name + suffix)
+    _planes_equal(z, render_gpu(ctx, sc, schema, noises, STRICT | MK), full="normal_dof" in z)
 
 
+@pytest.mark.parametrize("text_ctx", TEXTS, indirect=True)
 @pytest.mark.parametrize("name", list(GC.ROW_CHECKSUM_CASES))
-def test_megapixel_configurations_every_row_checksum(glctx, name):
+def test_megapixel_configurations_every_row_checksum(text_ctx, name):
     """BASELINE's configurations at megapixel size as the reference's GLSL rendered them under software GL -- the headline C3b
     at 2048 x 1024 and at 4096 x 2048 (the pixel count of its own frame), C3a and C2 at 2048 x 1024, C4 and C5 at 1024 x 1024; a
-    CRC-32 per row and plane in the fixture: the GPU reproduces every row of every plane."""
+    CRC-32 per row and plane in the fixture: the GPU reproduces every row of every plane, for both texts."""
+    ctx, suffix = text_ctx
     sc, schema, noises = GC.row_checksum_case(name)
-    z = load("rows_" + name)
-    got = render_gpu(glctx, sc, schema, noises, STRICT | MK)
+    z = load("rows_" + name + suffix)
+    got = render_gpu(ctx, sc, schema, noises, STRICT | MK)
     for k, plane in enumerate(("color", "normal_dof", "albedo_depth") if schema["render"]["renderMode"] == "full" else ("color",)):
         crc = GC.row_checksums(got[k])
         assert (crc == z[plane]).all(), f"{plane}: {int((crc != z[plane]).sum())} of {len(crc)} rows differ"

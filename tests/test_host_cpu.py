@@ -45,12 +45,22 @@ def test_header_symbols_are_exported():
     from raymarching_engine_amd import native
 
     header = (ROOT / "include" / "hip_raymarch.h").read_text()
-    declared = set(re.findall(r"^(?:int|void|void\*|const char\*)\s+(rm_[a-z_]+)\(", header, re.M))
+    declared = set(re.findall(r"^RM_API (?:int|void|void\*|const char\*)\s+(rm_[a-z_0-9]+)\(", header, re.M))
     assert declared == set(native.EXPORTS)
     lib = native.load_library()
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.rm_abi_version() == abi.RM_ABI_VERSION
+    # ... and nothing else: the library is built -fvisibility=hidden, so its cross-unit launchers (rm_gl_launch_*, rm::launch_*) and
+    # kernel stubs stay inside (`nm -D` lists the header's entry points and no other function or object of its own)
+    import subprocess
+
+    for path in (native.LIB_PATH, native.XCHECK_LIB_PATH):
+        if not path.exists():
+            continue
+        out = subprocess.run(["nm", "-D", "--defined-only", str(path)], capture_output=True, text=True, check=True).stdout
+        exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-2] in "TDBVWR"}
+        assert exported == declared, (path.name, sorted(exported ^ declared)[:8])
 
 
 def test_struct_layouts_match_header():
@@ -558,6 +568,24 @@ def test_a_suspended_job_keeps_its_scene_through_the_cache_eviction():
     ctx.native.render_sample = boom
     out = J.drain(J.do_render_job(J.make_schema(sphere(1.25), 16, 16, counts=(8,), render_mode="preview", samples_per_pixel=2), ctx)(lambda *a: None))
     assert out["success"] is False and "device lost" in out["why"]["infoLog"] and not ctx._pins
+    assert not ctx._live  # the failed job's frame went back to the cache (fbo.delete), as it does on success
+    # 64 suspended jobs pin 64 scenes: the 65th scene is the only unpinned entry -- it must not be the one evicted as it is handed out
+    # (get_scene returned a destroyed handle); the cache exceeds its bound while everything in it is in use
+    ctx.native.render_sample = FakeNative.render_sample.__get__(ctx.native)
+    ctx2 = Ctx()
+    destroyed.clear()
+    gens = []
+    for i in range(J.SCENE_CACHE_ENTRIES):
+        g = J.do_render_job(J.make_schema(sphere(100.0 + i), 16, 16, counts=(8,), render_mode="preview", samples_per_pixel=2, frameid=i), ctx2)(lambda *a: None)
+        next(g)
+        gens.append(g)
+    extra = ctx2.get_scene(sphere(500.0))
+    assert extra.name == 500.0 and not destroyed and len(ctx2._scenes) == J.SCENE_CACHE_ENTRIES + 1
+    g = J.do_render_job(J.make_schema(sphere(501.0), 16, 16, counts=(8,), render_mode="preview", samples_per_pixel=2, frameid=900), ctx2)(lambda *a: None)
+    assert J.drain(g) == {"success": True} and 501.0 not in destroyed[:-1]
+    for g in gens:
+        g.close()
+    assert not ctx2._pins
 
 
 def compare_host_events(k, schema, events, want):

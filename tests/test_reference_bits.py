@@ -72,12 +72,24 @@ def _planes_equal(z, fr, suffix="", full=True):
         assert eq.all(), f"{name}{suffix}: {int((~eq.all(-1)).sum())} pixels differ"
 
 
+TEXTS = ("portable_tan", "unmodified")
+
+
+def _golden_of_text(prefix, name, text):
+    """The fixture of a case rendered from the reference's text with tan routed to the portable tangent, or (round 6) from the
+    text exactly as it stands; the oracle's tangent is set to match."""
+    O.set_tan_mode(O.TAN_SWIFTSHADER if text == "unmodified" else O.TAN_PORTABLE)
+    return load(prefix + name + ("_native" if text == "unmodified" else ""))
+
+
+@pytest.mark.parametrize("text", TEXTS)
 @pytest.mark.parametrize("case", list(GC.IMAGES))
-def test_whole_main_image_bit_for_bit(case):
+def test_whole_main_image_bit_for_bit(case, text):
     """All 29 image cases (13 scenes; preview and full, three cameras, DoF, fog, both blend modes, 1-3 lights, subsurface
-    scattering, up to 4 accumulated samples): every value of every plane."""
+    scattering, up to 4 accumulated samples): every value of every plane -- of the goldens rendered with the portable tangent
+    injected and of the ones rendered from raymarcher.frag exactly as it stands."""
     sc, samples, schema = GC.image_schema(case)
-    z = load("image_" + case)
+    z = _golden_of_text("image_", case, text)
     _planes_equal(z, _render(sc, schema, z["rand_noise"]), full="normal_dof" in z)
 
 
@@ -163,25 +175,29 @@ def test_helper_functions_bit_for_bit():
     assert same_bits(O.rng(u, 32, 32, 4), r["uniform4"]).all()
 
 
+@pytest.mark.parametrize("text", TEXTS)
 @pytest.mark.parametrize("name", list(GC.CONFIGS))
-def test_baseline_configurations_bit_for_bit(name):
+def test_baseline_configurations_bit_for_bit(name, text):
     """BASELINE.json's configurations with their own scenes, step counts, lights and cameras -- the headline C3b (Mandelbulb,
     full mode, 256 steps, the point light; 2 samples), C3a, C2 (preview and lit), C4 (CSG-64, 128 steps), C5 (three bounces,
-    the soft light) -- through the reference's main() at 256 x 128 / 128 x 128: every value of every plane."""
+    the soft light) -- through the reference's main() at 256 x 128 / 128 x 128: every value of every plane.  Twice: the goldens
+    rendered with the portable tangent injected, and the ones rendered from raymarcher.frag as it stands (its own tan() in
+    gold_noise :46-49 and the camera :186)."""
     sc, schema, noises = GC.config_case(name)
-    z = load("config_" + name)
+    z = _golden_of_text("config_", name, text)
     r = schema["render"]
     _planes_equal(z, _render(sc, schema, noises, r["width"], r["height"], threads=min(8, O.host_cores())), full="normal_dof" in z)
 
 
+@pytest.mark.parametrize("text", TEXTS)
 @pytest.mark.parametrize("name", list(GC.ROW_CHECKSUM_CASES))
-def test_megapixel_configurations_row_checksums(name):
+def test_megapixel_configurations_row_checksums(name, text):
     """BASELINE configurations at megapixel size -- the headline C3b (Mandelbulb, full, 256 steps, the light) at 2048 x 1024
     and 4096 x 2048, C3a and C2 at 2048 x 1024, C4 (CSG-64, 128 steps) and C5 (three bounces, the soft light) at 1024 x 1024 --
-    rendered by the reference's GLSL under software GL; the fixture holds a CRC-32 per image row.  Here: 24 rows spread over the frame (the colour plane; the GPU test checks every row of every
-    plane), each row's checksum."""
+    rendered by the reference's GLSL under software GL (both texts, as above); the fixture holds a CRC-32 per image row.  Here:
+    24 rows spread over the frame (the colour plane; the GPU test checks every row of every plane), each row's checksum."""
     sc, schema, noises = GC.row_checksum_case(name)
-    z = load("rows_" + name)
+    z = _golden_of_text("rows_", name, text)
     w, h = schema["render"]["width"], schema["render"]["height"]
     rows = list(range(h // 48, h, h // 24))
     _, got = O.render_rows(sc, J.uniforms_from_schema(schema, noises[0]), w, h, rows, threads=min(8, O.host_cores()), **X86)
