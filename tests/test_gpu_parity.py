@@ -2369,7 +2369,7 @@ def test_bench_with_four_ranks_sharing_this_gpu(tmp_path):
     assert out["frame_check"] is True
     c = out["collective"]
     assert c["backend"] == "gloo" and c["world_size_seen"] == 4 and c["ranks_sharing_one_gpu"] is True and c["frame_check"] is True
-    assert c["payload"] == "rgba8" and c["gathered_bytes_per_present"] == 4 * 544 * 3840 * 4 and c["frame_check_samples"] == 48
+    assert c["payload"] == "rgba8" and c["gathered_bytes_per_present"] == 4 * 544 * 3840 * 4 and c["frame_check_samples"] >= 8 + 3 * 16
     assert out["workloads"] is None  # (the other configurations' legs belong to the one-GPU default invocation)
 
 
