@@ -190,6 +190,131 @@ def counters_entry(key, strict, pipeline, windowed, gl_stack=0):
         return None
 
 
+
+# ---- hardware counters measured by THIS run (round 6) --------------------------------------------------------------------------
+# Until round 5 `traffic`, `frac_executed`, `valu_issue_busy` and `fma_share` were replayed from the builder's own rocprofv3 passes
+# (profiles/<round>_counters.json).  The default one-GPU invocation now measures them itself, before it touches the GPU: three
+# child processes -- rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py --counter-child -- each rendering a few frames of
+# the headline and of every `workloads` leg; a --pmc pass carries --kernel-trace only, FETCH_SIZE and WRITE_SIZE have a pass each
+# (MI355X_MICROARCH.md: the TCC block has 4 slots, FETCH_SIZE takes 3, WRITE_SIZE 2), and the gfx950 correction of FETCH_SIZE
+# (128-B requests tallied at 64 B: x 2) is applied.  Anything that goes wrong there -- no rocprofv3, a timeout, an unexpected file --
+# falls back to the replayed file, and `counters_from` says which it was.
+COUNTER_LEGS = (("c3b", "fast", 0), ("c2", "fast", 0), ("c3a", "fast", 0), ("c4", "fast", 0), ("c5", "fast", 0), ("c3b", "strict", 0), ("c3b", "glstack", 2))
+COUNTER_WARM, COUNTER_FRAMES = 2, 2  # launches per leg: the first two settle the tile order and earn a long table its culling grid
+PMC_PASSES = (("sq", "SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_SALU SQ_WAIT_ANY"),
+              ("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE"), ("waves", "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_LDS"))
+
+
+def leg_flags(abi, build, gl_stack):
+    return abi.RM_RENDER_FAST if build == "fast" else abi.RM_RENDER_STRICT | (abi.RM_RENDER_MEGAKERNEL if gl_stack else 0)
+
+
+def counter_child():
+    """`bench.py --counter-child` (run under rocprofv3 --pmc by live_counters): COUNTER_WARM + COUNTER_FRAMES samples of every leg,
+    one pixel-kernel launch each, in COUNTER_LEGS order; prints how many launches each leg made."""
+    from raymarching_engine_amd import abi, job as J, native
+
+    ctx = native.Context(0)
+    ctx.set_samples_in_flight(1)
+    legs = []
+    for key, build, gl_stack in COUNTER_LEGS:
+        wl, sc, schema = make_workload(key)
+        ctx.set_gl_stack(gl_stack)
+        h = ctx.create_scene(sc)
+        fb = ctx.create_framebuffer(wl["width"], wl["height"])
+        J.reset_halton()
+        for _ in range(COUNTER_WARM + COUNTER_FRAMES):
+            ctx.render_sample(h, fb, J.uniforms_from_schema(schema, J.next_rand_noise()), None, leg_flags(abi, build, gl_stack) | abi.RM_RENDER_NO_OVERLAP)
+            ctx.sync()
+        legs.append({"key": key + "_" + build, "launches": COUNTER_WARM + COUNTER_FRAMES, "frames": COUNTER_FRAMES, "pixels": wl["width"] * wl["height"],
+                     "pipeline": ctx.last_pipeline()})
+        fb.destroy()
+        h.destroy()
+    ctx.set_gl_stack(0)
+    ctx.close()
+    print("COUNTER_CHILD " + json.dumps(legs), flush=True)
+
+
+def under_a_profiler():
+    e = os.environ
+    return bool(e.get("ROCP_TOOL_LIBRARIES") or e.get("ROCPROFILER_REGISTER_FORCE_LOAD") or "rocprof" in e.get("LD_PRELOAD", "") or e.get("RM_BENCH_NO_LIVE_COUNTERS"))
+
+
+def live_counters(timeout_s=150.0):
+    """{leg key: per-frame counters} measured now (see above), or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="rm_bench_pmc_", dir=os.environ.get("TMPDIR") or "/tmp")
+    env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR") or "/tmp")
+    t_start = time.perf_counter()
+    sums = {}  # leg key -> counter -> sum over the leg's measured frames
+    legs = None
+    try:
+        for tag, group in PMC_PASSES:
+            out = os.path.join(tmp, tag)
+            cmd = [exe, "--pmc", *group.split(), "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--counter-child"]
+            left = timeout_s - (time.perf_counter() - t_start)
+            if left < 10.0:
+                return None, f"out of time before the {tag} pass"
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=left, env=env, cwd=tmp)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("COUNTER_CHILD ")]
+            if r.returncode != 0 or not line:
+                return None, f"the {tag} pass failed (status {r.returncode}): {(r.stderr or r.stdout)[-300:]}"
+            legs = json.loads(line[-1][len("COUNTER_CHILD "):])
+            rows = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                rows += [row for row in csv.DictReader(open(f)) if "rm_pixel_kernel" in row.get("Kernel_Name", "")]
+            per_dispatch = {}
+            for row in rows:
+                d = per_dispatch.setdefault(int(row["Dispatch_Id"]), {"name": row["Kernel_Name"]})
+                d[row["Counter_Name"]] = d.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+            order = [per_dispatch[k] for k in sorted(per_dispatch)]
+            if len(order) != sum(l["launches"] for l in legs):
+                return None, f"the {tag} pass saw {len(order)} pixel-kernel dispatches, {sum(l['launches'] for l in legs)} were launched"
+            at = 0
+            for l in legs:
+                mine = order[at:at + l["launches"]]
+                at += l["launches"]
+                if len({d["name"] for d in mine}) != 1:
+                    return None, f"the {tag} pass: leg {l['key']} is not one kernel ({sorted({d['name'] for d in mine})})"
+                acc = sums.setdefault(l["key"], {"kernel": mine[0]["name"], "frames": l["frames"], "pixels": l["pixels"], "pipeline": l["pipeline"]})
+                for d in mine[-l["frames"]:]:
+                    for c, v in d.items():
+                        if c != "name":
+                            acc[c] = acc.get(c, 0.0) + v
+    except subprocess.TimeoutExpired:
+        return None, f"timed out after {timeout_s:.0f} s"
+    except Exception as e:  # the measurement is an extra: any surprise means "replay"
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out = {}
+    for key, a in sums.items():
+        n = a["frames"]
+        g = lambda c: a.get(c, 0.0) / n
+        valu = g("SQ_INSTS_VALU")
+        lanes = g("SQ_THREAD_CYCLES_VALU") / (valu * 64) if valu else 0.0
+        out[key] = {"profile": "this run", "counters_file": "measured in this run", "pipeline": a["pipeline"], "frames_profiled": n, "pixels_per_frame": a["pixels"], "kernel": a["kernel"],
+                    "hbm_bytes_per_frame": (2.0 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1000.0,  # (KB; FETCH_SIZE x 2: gfx950 tallies 128-B requests at 64 B)
+                    "hbm_bytes_per_pixel": (2.0 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1000.0 / a["pixels"],
+                    "executed_lane_flops_per_frame": (g("SQ_INSTS_VALU_ADD_F32") + g("SQ_INSTS_VALU_MUL_F32") + 2 * g("SQ_INSTS_VALU_FMA_F32") + g("SQ_INSTS_VALU_TRANS_F32")) * 64 * lanes,
+                    "sq_insts_valu_per_frame": valu, "trans_f32_per_frame": g("SQ_INSTS_VALU_TRANS_F32"), "fma_f32_per_frame": g("SQ_INSTS_VALU_FMA_F32"),
+                    "mul_f32_per_frame": g("SQ_INSTS_VALU_MUL_F32"), "add_f32_per_frame": g("SQ_INSTS_VALU_ADD_F32"), "sq_insts_salu_per_frame": g("SQ_INSTS_SALU"),
+                    "sq_insts_lds_per_frame": g("SQ_INSTS_LDS"), "lanes_active": lanes,
+                    "wave_cycles_waiting": g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES") if g("SQ_WAVE_CYCLES") else None,
+                    "seconds_spent": None}
+    took = time.perf_counter() - t_start
+    for v in out.values():
+        v["seconds_spent"] = took
+    return out, f"measured in this run: {len(PMC_PASSES)} rocprofv3 --pmc passes (--kernel-trace only) of `bench.py --counter-child`, {COUNTER_FRAMES} frames per leg, {took:.0f} s"
+
+
 def self_launch(args):
     """--gpus N > 1 with no launcher: start N fresh ranks before this process touches a GPU."""
     import socket
@@ -247,6 +372,8 @@ def main():
                                                        "gathers the packed (colour, DoF radius) rows and rank 0 runs the blur")
     ap.add_argument("--no-far-jump", action="store_true", help="RM_RENDER_NO_FAR_JUMP: march escaping rays step by step (measurement switch, same bits)")
     ap.add_argument("--no-cull", action="store_true", help="RM_RENDER_NO_CULL: fold every row of a primitive table at every point (measurement switch, same bits)")
+    ap.add_argument("--counter-child", action="store_true", help="(internal) render a few frames of every leg and exit: what live_counters profiles")
+    ap.add_argument("--no-live-counters", action="store_true", help="do not measure the hardware counters in this run (replay profiles/<round>_counters.json)")
     ap.add_argument("--no-workloads", action="store_true", help="skip the `workloads` legs (the other BASELINE configurations and the two parity builds of the headline, a few steps each)")
     ap.add_argument("--no-check-frame", action="store_true", help="sharded runs check the assembled frame by default (see --check-frame); this skips it")
     ap.add_argument("--check-frame", action="store_true",
@@ -257,6 +384,9 @@ def main():
         # the wavefront pipeline is not in the product library (round 5): it is timed from the tests' cross-check build of the same sources
         os.environ["RM_LIB"] = os.path.join(ROOT, "tests", "_xcheck", "libhip_raymarch_xcheck.so")
 
+    if args.counter_child:
+        counter_child()
+        return
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -266,6 +396,12 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE); they must agree")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    live, live_note = None, None
+    default_run = (world == 1 and os.environ.get("RM_BENCH_FORCE_DIST") != "1" and args.workload == "c3b" and not args.strict and not args.rows and args.stripe_of <= 1
+                   and not args.wavefront and not args.dof and not args.no_far_jump and not args.no_cull)
+    if default_run and not args.no_live_counters and not under_a_profiler():
+        live, live_note = live_counters()  # child processes, before this one touches the GPU
 
     import numpy as np
     import torch
@@ -509,12 +645,14 @@ def main():
             u2 = J.uniforms_from_schema(schema2, (0.5, 1.0 / 3.0))
             k_ms = ctx.render_timed(scene2, fb2, u2, 3, None, leg_flags | abi.RM_RENDER_NO_OVERLAP)
             pipe2 = ctx.last_pipeline()
-            ent = counters_entry(key, build == "strict", pipe2, False, gl_stack)
+            ent = (live or {}).get(key + "_" + build) or counters_entry(key, build == "strict", pipe2, False, gl_stack)
             leg = {"workload": wl2["name"], "build": build + (" (rm_ctx_set_gl_stack 2: the GL stack's arithmetic, its own tan)" if gl_stack else ""),
                    "steps": k_steps, "ms_per_step": e2 / k_steps * 1e3, "kernel_ms": k_ms, "mpix_s": W2 * H2 * k_steps / e2 / 1e6,
                    "frac_executed": ent["executed_lane_flops_per_frame"] / (k_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS if ent else None,
                    "hbm_bytes_per_px": ent["hbm_bytes_per_pixel"] if ent else None, "lanes_active": ent["lanes_active"] if ent else None,
-                   "counters_from": ent["counters_file"] + " -> " + ent["profile"] if ent else None}
+                   "valu_issue_busy": (ent["sq_insts_valu_per_frame"] + 2.2 * ent["trans_f32_per_frame"]) / (k_ms * 1e-3) / VALU_ISSUE_PER_S if ent else None,
+                   "salu_per_valu": ent["sq_insts_salu_per_frame"] / ent["sq_insts_valu_per_frame"] if ent and ent.get("sq_insts_salu_per_frame") else None,
+                   "counters_from": (ent["counters_file"] + ("" if ent["profile"] == "this run" else " -> " + ent["profile"])) if ent else None}
             workloads[key + "_" + build] = leg
             jctx.fbo_delete(W2, H2, 100 + n_leg)
             while jctx._purgatory:  # (C5's planes are 3.2 GB: give them back before the next leg)
@@ -545,13 +683,18 @@ def main():
         # NOT measured in this run: replayed from the builder's separate rocprofv3 --pmc runs of this command, kept in
         # profiles/<round>_counters.json with the hash of the kernel sources they were measured on (withheld when the sources changed)
         traffic = executed = counters_file = counters_from = issue_busy = fma_share = None
-        ent = counters_entry(args.workload, args.strict, pipeline, rows_window is not None or stripes is not None)
+        ent = (live or {}).get("c3b_fast") if default_run else None
+        if ent and ent["pipeline"] != pipeline:
+            ent = None
+        ent = ent or counters_entry(args.workload, args.strict, pipeline, rows_window is not None or stripes is not None)
         if ent:
             share = px_launch / ent["pixels_per_frame"]
             traffic = ent["hbm_bytes_per_frame"] * share
             executed = ent["executed_lane_flops_per_frame"] * share
             counters_file = ent["profile"]
-            counters_from = f"{ent['counters_file']} (builder-measured with rocprofv3 --pmc, replayed; kernel sources sha256 {ent['kernel_source_sha256'][:16]})"
+            counters_from = (live_note if ent["profile"] == "this run" else
+                             f"{ent['counters_file']} (builder-measured with rocprofv3 --pmc, REPLAYED; kernel sources sha256 {ent['kernel_source_sha256'][:16]})"
+                             + (f"; not measured in this run: {live_note}" if live_note else ""))
             if ent.get("fma_f32_per_frame") is not None and ent["sq_insts_valu_per_frame"]:
                 fma_share = ent["fma_f32_per_frame"] / ent["sq_insts_valu_per_frame"]
                 # issue slots: a transcendental holds the SIMD's issue for 3.2 ordinary slots; a gfx950 sustains ~1.0e12 wave-level
@@ -581,7 +724,8 @@ def main():
                             "exceed 1 on frames that are mostly sky; frac_useful prices the same algorithm with every march counted up to its bitwise "
                             "fixed point only (profiles/flops_per_pixel.json[<workload>_pruned]; tools/count_flops.py --pruned): at most 1 by construction; "
                             "frac_executed is the hardware's own count of the arithmetic done.  traffic, frac_executed, "
-                            "valu_issue_busy and fma_share are REPLAYED from counters_from, not measured in this run: frac_executed = (ADD + MUL + 2 FMA + TRANS) "
+                            "valu_issue_busy and fma_share come from the hardware counters named in counters_from (measured by this run's own rocprofv3 passes "
+                            "on the default one-GPU invocation, else replayed from the builder's): frac_executed = (ADD + MUL + 2 FMA + TRANS) "
                             "x 64 x lanes active / kernel time / peak; with fma_share of the VALU instructions being FMAs (2 flops) and the rest 1 or 0, and "
                             "valu_issue_busy of the issue slots taken, that is what bounds it"}
         out = {

@@ -2383,7 +2383,7 @@ def test_bench_default_line_carries_every_workload(tmp_path):
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "10", "--warmup", "3", "--repeats", "1", "--no-cpu-baseline"]
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "10", "--warmup", "3", "--repeats", "1", "--no-cpu-baseline"]  # (with this run's own rocprofv3 passes: the default)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
@@ -2397,3 +2397,11 @@ def test_bench_default_line_carries_every_workload(tmp_path):
     assert out["ms_per_step"] < w["c3b_strict"]["ms_per_step"] < w["c3b_glstack"]["ms_per_step"] * 4
     assert w["c2_fast"]["mpix_s"] > w["c3a_fast"]["mpix_s"] > out["value"] > w["c4_fast"]["mpix_s"] > w["c5_fast"]["mpix_s"]
     assert out["collective"] is None and out["frame_check"] is None
+    # the hardware counters on the line were measured by this very run (three rocprofv3 --pmc child passes before the bench touched
+    # the GPU), for the headline and for every leg: HBM bytes against the 96 (32 in preview) algorithmic ones, the executed fraction
+    r = out["roofline"]
+    assert r["counters_from"].startswith("measured in this run"), r["counters_from"]
+    assert 96.0 * 0.9 < r["traffic"] / r["pixels_per_launch"] < 96.0 * 1.5 and 0.2 < r["frac_executed"] < 0.6 and 0.5 < r["valu_issue_busy"] < 1.05
+    for key, leg in w.items():
+        assert leg["counters_from"] == "measured in this run", (key, leg["counters_from"])
+        assert leg["hbm_bytes_per_px"] > 25.0 and 0.03 < leg["frac_executed"] < 0.6 and 0.4 < leg["lanes_active"] <= 1.0, (key, leg)
