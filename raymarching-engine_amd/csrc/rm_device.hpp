@@ -81,6 +81,13 @@ struct PM {
   static RM_DEV void pow_pair(float r, float n, float& r_nm1, float& r_n) { r_nm1 = pow(r, n - 1.0f); r_n = pow(r, n); }
 };
 #else
+#ifdef RM_COLD_OUTLINE  // (measurement builds: the shared text's special cases as functions of their own)
+__device__ __attribute__((noinline)) static float pm_pow_from_log_cold(float x, float y, float hi, float lo) { return pm_pow_from_log(x, y, hi, lo); }
+__device__ __attribute__((noinline)) static float pm_atan2_cold(float y, float x) { return pm_atan2(y, x); }
+#else
+#define pm_pow_from_log_cold pm_pow_from_log
+#define pm_atan2_cold pm_atan2
+#endif
 struct PM {
   static constexpr bool fast = false;
   static RM_DEV float fma(float a, float b, float c) { return a * b + c; }  // two roundings, like GLSL/C
@@ -120,7 +127,7 @@ struct PM {
     const float th = y * hi, tl = PM_FMAF(y, hi, -th) + y * lo;  // (the product as pm_pow_from_log carries it)
     const bool plain = __builtin_amdgcn_classf(x, 0x100) & __builtin_amdgcn_classf(y, 0x198) & (x != 1.0f) & (y != 2.0f) & (fabsf(th) < 87.0f);
     if (__builtin_expect(plain, 1)) return pm_exp_core(th, tl);
-    return pm_pow_from_log(x, y, hi, lo);
+    return pm_pow_from_log_cold(x, y, hi, lo);
   }
   static RM_DEV float atan2(float y, float x) {
     if (__builtin_expect(__builtin_amdgcn_classf(x, 0x198) & __builtin_amdgcn_classf(y, 0x198), 1)) {  // both finite and not zero
@@ -128,7 +135,7 @@ struct PM {
       const float b = x < 0.0f ? 3.14159274f - a : a;
       return y < 0.0f ? -b : b;
     }
-    return pm_atan2(y, x);
+    return pm_atan2_cold(y, x);
   }
 };
 #endif
@@ -556,6 +563,29 @@ struct Sdf<RM_SCENE_TABLE> {
       }
       for (; i < end; i++) d = smooth_row(d, sphere_row1(rows[i], p), k, half_inv_k);
     };
+    // the listed rows of one word, in table order: the list walked with s_ff1 / s_bitset0 (round 6: 3 scalar instructions per row where
+    // `j = ctz(u); u &= u - 1` compiles to 7 -- the scalar unit is shared by the CU's four SIMDs, and on C4 its instructions were 44 % of the
+    // vector ones: 9.01 -> 8.76 ms), two rows per trip
+    auto fold_listed = [&](unsigned long long u, int w) {
+      const float4* wrows = rows + 64 * w;
+      auto next_row = [&]() -> const float4* {  // the address of the lowest listed row, which leaves the list
+        int j;
+        asm volatile("s_ff1_i32_b64 %0, %1\n\ts_bitset0_b64 %1, %0" : "=&s"(j), "+s"(u));
+        return wrows + j;
+      };
+      while (u != 0ull) {
+        const float4* a0 = next_row();
+        if (u != 0ull) {
+          const float4* a1 = next_row();
+          const float4 r0 = *a0, r1 = *a1;
+          const float d0 = sphere_row1(r0, p), d1 = sphere_row1(r1, p);
+          d = smooth_row(d, d0, k, half_inv_k);
+          d = smooth_row(d, d1, k, half_inv_k);
+        } else {
+          d = smooth_row(d, sphere_row1(*a0, p), k, half_inv_k);
+        }
+      }
+    };
     if (sc.cull.cells == nullptr) {  // kernel-uniform
       fold_range(1, n);
       return d;
@@ -576,47 +606,18 @@ struct Sdf<RM_SCENE_TABLE> {
     }
     const unsigned long long* cell = cull_cell(sc.cull, p);
     for (int w = 0; w < sc.cull.words; w++) {
-      unsigned long long u = wave_union(cell[w]);
-      const int first = w == 0 ? 1 : 64 * w, end = min(n, 64 * w + 64);
-      if (u == 0ull || __builtin_popcountll(u) > RM_CULL_SMOOTH_MAX * (end - 64 * w) / 64) {
-        fold_range(first, end);
-        continue;
-      }
-      if (w == 0) u &= ~1ull;
-#ifndef RM_CULL_LOOP4
-#define RM_CULL_LOOP4 0  // 1 (measurement builds): four listed rows per trip, their LDS reads in flight together
-#endif
-#if RM_CULL_LOOP4
-      while (__builtin_popcountll(u) >= 4) {
-        const int j0 = 64 * w + __builtin_ctzll(u); u &= u - 1ull;
-        const int j1 = 64 * w + __builtin_ctzll(u); u &= u - 1ull;
-        const int j2 = 64 * w + __builtin_ctzll(u); u &= u - 1ull;
-        const int j3 = 64 * w + __builtin_ctzll(u); u &= u - 1ull;
-        const float4 r0 = rows[j0], r1 = rows[j1], r2 = rows[j2], r3 = rows[j3];
-        const float d0 = sphere_row1(r0, p), d1 = sphere_row1(r1, p);
-        d = smooth_row(d, d0, k, half_inv_k);
-        d = smooth_row(d, d1, k, half_inv_k);
-        const float d2 = sphere_row1(r2, p), d3 = sphere_row1(r3, p);
-        d = smooth_row(d, d2, k, half_inv_k);
-        d = smooth_row(d, d3, k, half_inv_k);
-      }
-#endif
-      while (u != 0ull) {
-        const int j0 = 64 * w + __builtin_ctzll(u);
-        u &= u - 1ull;
-        if (u != 0ull) {
-          const int j1 = 64 * w + __builtin_ctzll(u);
-          u &= u - 1ull;
-          const float4 r0 = rows[j0], r1 = rows[j1];
-          const float d0 = sphere_row1(r0, p), d1 = sphere_row1(r1, p);
-          d = smooth_row(d, d0, k, half_inv_k);
-          d = smooth_row(d, d1, k, half_inv_k);
-        } else {
-          d = smooth_row(d, sphere_row1(rows[j0], p), k, half_inv_k);
-        }
-      }
+      const unsigned long long u = listed_rows(n, cell[w], w);
+      if (u == 0ull) fold_range(w == 0 ? 1 : 64 * w, min(n, 64 * w + 64));
+      else fold_listed(u, w);
     }
     return d;
+  }
+  // which rows of a word to fold: the wave's union with row 0 (the fold's start) taken out, or 0 = all of them
+  static RM_DEV unsigned long long listed_rows(int n, unsigned long long mine, int w) {
+    const unsigned long long u = wave_union(mine);
+    const int end = min(n, 64 * w + 64);
+    if (u == 0ull || __builtin_popcountll(u) > RM_CULL_SMOOTH_MAX * (end - 64 * w) / 64) return 0ull;
+    return w == 0 ? (u & ~1ull) : u;
   }
   static RM_DEV float eval_spheres_smooth(const DevScene& sc, const SceneLds& lds, v3 p) {
     const int n = sc.nprims;
@@ -730,12 +731,15 @@ struct Sdf<RM_SCENE_TABLE> {
         continue;
       }
       if (w == 0) u &= ~1ull;
+      auto next_listed = [&]() -> int {  // the lowest listed row, which leaves the list: s_ff1 + s_bitset0 (see eval_spheres_one_k)
+        int j;
+        asm volatile("s_ff1_i32_b64 %0, %1\n\ts_bitset0_b64 %1, %0" : "=&s"(j), "+s"(u));
+        return 64 * w + j;
+      };
       while (u != 0ull) {
-        const int j0 = 64 * w + __builtin_ctzll(u);
-        u &= u - 1ull;
+        const int j0 = next_listed();
         if (u != 0ull) {
-          const int j1 = 64 * w + __builtin_ctzll(u);
-          u &= u - 1ull;
+          const int j1 = next_listed();
           rows2(j0, j1);
         } else {
           row(j0, true);
