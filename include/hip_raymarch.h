@@ -324,13 +324,18 @@ RM_API int rm_ctx_set_retire_eps(rm_ctx* ctx, float eps);
  * reference's UNMODIFIED shader text computes under it, random stream and camera included (that switch is one per DEVICE:
  * the GL-stack contexts of a device share it, and changing it waits for the device). */
 RM_API int rm_ctx_set_gl_stack(rm_ctx* ctx, int on);
-/* Culling grids (long primitive tables without domain rows; RM_RENDER_NO_CULL): a scene's grid is built -- on the context's
- * stream, in front of the render that asks for it -- once the scene has been asked for `pixels` pixel-samples since it was
- * created (default 4 Mi: a 4K frame's first sample builds it, a host that shows a NEW scene in every 1080p frame, like the
- * reference's sliders do (index.tsx:121-182), never pays for a grid it would not earn back); 0 = with the first render.  The
- * same bits with and without a grid.  rm_ctx_cull_stats: out4 = {grids built so far, bytes held now, grids held now, the
- * budget in bytes (a sixteenth of the device's memory, at most 1 GiB: beyond it the least recently rendered scene gives its
- * grid up and renders on without one)}. */
+/* Culling grids (long primitive tables without domain rows; RM_RENDER_NO_CULL): a scene's grid is built -- on a stream of
+ * the context's own, with no wait on the host; the render that asks for it waits for the build on the device -- once the
+ * scene has been asked for `pixels` pixel-samples since it was created (default 4 Mi: a 4K frame's first sample builds it,
+ * a host that shows a NEW scene in every 1080p frame, like the reference's sliders do (index.tsx:121-182), never pays for a
+ * grid it would not earn back); 0 = with the first render.  Counted per JOB: every sample of an rm_render_samples call, and
+ * a striped framebuffer's part of a frame as the whole frame (every rank of a sharded job reaches the threshold when a
+ * single GPU would).  The same bits with and without a grid.  rm_ctx_cull_stats: out4 = {grids built so far, bytes the
+ * scenes' grids hold now, grids held now, the budget in bytes (a sixteenth of the device's memory, at most 1 GiB: beyond it
+ * the least recently rendered scene gives its grid up and renders on without one; a grid larger than the whole budget is
+ * not built until the budget is raised)}.  Buffers of grids that were given up are kept for the next build (at most 4, at
+ * most half the budget) and count against the budget: grids + recycled buffers never exceed it.  Lowering the budget
+ * (rm_ctx_set_cull_budget) takes effect at once. */
 RM_API int rm_ctx_set_cull_min_pixels(rm_ctx* ctx, long long pixels);
 RM_API int rm_ctx_set_cull_budget(rm_ctx* ctx, size_t bytes); /* the bytes a context's grids may hold (a host that knows its memory better; the tests: small, to see grids go) */
 RM_API int rm_ctx_cull_stats(const rm_ctx* ctx, unsigned long long* out4);

@@ -949,10 +949,23 @@ int rm_buffer_upload(rm_ctx* ctx, void* device_ptr, const void* host, size_t byt
 // the build kernel is enqueued on a stream of its own, the render that triggered it waits for it on the device -- no wait on the host -- into a
 // buffer recycled from the context's pool; the grids of a context stay within its budget, the least recently used scene giving its
 // grid up first.  Running out of memory is not an error (the fold of every row gives the same bits); any other failure is.
-static void cull_release(rm_ctx* ctx, rm_scene* s, bool idle) {  // the scene's grid back to the pool; idle: the caller has waited for the renders that read it
-  if (!s->d_cull) return;
+// The pool: buffers of grids that were given up, kept for the next build of the same size (a host that shows a new scene in every frame
+// builds a grid per frame: no hipMalloc / hipFree each time).  At most 4 buffers and half the budget, and -- since round 6 -- the
+// pooled bytes COUNT against the budget: grids held + buffers pooled <= rm_ctx_set_cull_budget at every moment (cull_trim_pool).
+static size_t cull_pooled_bytes(const rm_ctx* ctx) {
   size_t pooled = 0;
   for (auto& b : ctx->cull_pool) pooled += b.bytes;
+  return pooled;
+}
+static void cull_trim_pool(rm_ctx* ctx, size_t room_for) {  // frees pooled buffers until grids + pool + room_for fit the budget
+  while (!ctx->cull_pool.empty() && ctx->cull_bytes + cull_pooled_bytes(ctx) + room_for > ctx->cull_budget) {
+    (void)hipFree(ctx->cull_pool.back().p);  // (waits for the device)
+    ctx->cull_pool.pop_back();
+  }
+}
+static void cull_release(rm_ctx* ctx, rm_scene* s, bool idle) {  // the scene's grid back to the pool; idle: the caller has waited for the renders that read it
+  if (!s->d_cull) return;
+  const size_t pooled = cull_pooled_bytes(ctx);
   if (ctx->cull_pool.size() < 4 && pooled + s->cull_bytes <= ctx->cull_budget / 2) ctx->cull_pool.push_back({s->d_cull, s->cull_bytes, idle});
   else (void)hipFree(s->d_cull);  // (waits for the device)
   ctx->cull_bytes -= s->cull_bytes;
@@ -971,8 +984,8 @@ static int scene_cull_grid(rm_ctx* ctx, rm_scene* s, int flags, long long pixels
   CullGrid g = s->cull_grid;
   CullBuild build = s->cull_build;
   const size_t bytes = (size_t)(rm_cull_cells(g.n, g.n_outer, g.levels) + 1) * (size_t)g.words * sizeof(unsigned long long);
+  if (bytes > ctx->cull_budget) return RM_OK;  // (still wanted: a host may raise the budget -- rm_ctx_set_cull_budget -- and the next render builds it)
   s->cull_wanted = false;
-  if (bytes > ctx->cull_budget) return RM_OK;
   RM_HIP(ctx, hipSetDevice(ctx->device));
   while (ctx->cull_bytes + bytes > ctx->cull_budget && !ctx->cull_scenes.empty()) {  // the least recently used grid goes (a kernel still
     rm_scene* victim = ctx->cull_scenes[0];                                            // reading it is ahead of the next build on this stream)
@@ -987,6 +1000,7 @@ static int scene_cull_grid(rm_ctx* ctx, rm_scene* s, int flags, long long pixels
   for (size_t i = 0; i < ctx->cull_pool.size(); i++)
     if (ctx->cull_pool[i].bytes == bytes) { cells = ctx->cull_pool[i].p; idle = ctx->cull_pool[i].idle; ctx->cull_pool.erase(ctx->cull_pool.begin() + (long)i); break; }
   if (!cells) {
+    cull_trim_pool(ctx, bytes);  // the pooled buffers count against the budget too
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&cells), bytes);
     if (e == hipErrorOutOfMemory) {  // give the pool back and try once more
       (void)hipGetLastError();
@@ -1033,14 +1047,28 @@ int rm_ctx_set_cull_min_pixels(rm_ctx* ctx, long long pixels) {
 
 int rm_ctx_set_cull_budget(rm_ctx* ctx, size_t bytes) {
   if (!ctx) return RM_ERR_INVALID;
-  ctx->cull_budget = bytes;  // (grids held beyond it go as new ones come: scene_cull_grid)
+  ctx->cull_budget = bytes;
+  // a lowered budget takes effect now: the least recently rendered scenes give their grids up (and may earn them back), then the pool shrinks
+  RM_HIP(ctx, hipSetDevice(ctx->device));
+  while (ctx->cull_bytes > ctx->cull_budget && !ctx->cull_scenes.empty()) {
+    rm_scene* victim = ctx->cull_scenes[0];
+    for (rm_scene* c : ctx->cull_scenes)
+      if (c->last_use < victim->last_use) victim = c;
+    RM_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (renders that read the grid are followed by their blend on this stream)
+    for (int i = 0; i < RM_SP_MAX; i++)
+      if (ctx->sp_stream[i]) RM_HIP(ctx, hipStreamSynchronize(ctx->sp_stream[i]));
+    cull_release(ctx, victim, true);
+    victim->cull_wanted = true;
+    victim->px_seen = 0;
+  }
+  cull_trim_pool(ctx, 0);
   return RM_OK;
 }
 
 int rm_ctx_cull_stats(const rm_ctx* ctx, unsigned long long* out4) {
   if (!ctx || !out4) return RM_ERR_INVALID;
   out4[0] = ctx->cull_built;
-  out4[1] = (unsigned long long)ctx->cull_bytes;
+  out4[1] = (unsigned long long)ctx->cull_bytes;  // (the grids scenes hold; recycled buffers waiting in the pool are extra, and within the budget with them)
   out4[2] = (unsigned long long)ctx->cull_scenes.size();
   out4[3] = (unsigned long long)ctx->cull_budget;
   return RM_OK;
@@ -1078,7 +1106,9 @@ static int build_params(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniform
     l1 = (y1 > fb->row_begin + fb->row_count ? fb->row_begin + fb->row_count : y1) - fb->row_begin;
   }
   *empty = x1 <= x0 || l1 <= l0;
-  if (int rc = scene_cull_grid(ctx, scene, flags, *empty ? 0ll : (long long)(x1 - x0) * (long long)(l1 - l0))) return rc;
+  // what the scene has been asked for, in pixel-samples of the JOB: a striped framebuffer holds one part of `parts` of the frame, and the
+  // other ranks render the rest of it (each with a grid of its own to earn: the threshold is the same for a sharded job as for a whole one)
+  if (int rc = scene_cull_grid(ctx, scene, flags, *empty ? 0ll : (long long)(x1 - x0) * (long long)(l1 - l0) * (fb->stripe_rows > 0 ? (long long)fb->parts : 1ll))) return rc;
   P->u = *u;
   P->scene = scene->dev;
   P->color = fb->plane[0];
@@ -1372,7 +1402,7 @@ static hipError_t launch_pixels_in_flight(rm_ctx* ctx, const KParams& P, int fla
   hipStream_t side = ctx->sp_stream[slot];
   // the render reads no plane: it only has to wait until the blend that last used this staging buffer is done
   if ((e = hipStreamWaitEvent(side, ctx->sp_free[slot], 0)) != hipSuccess) return e;
-  if (ctx->cull_event && (e = hipStreamWaitEvent(side, ctx->cull_event, 0)) != hipSuccess) return e;  // ... and for the scene's culling grid, built on the context's stream
+  if (ctx->cull_event && (e = hipStreamWaitEvent(side, ctx->cull_event, 0)) != hipSuccess) return e;  // ... and for the scene's culling grid, built on the context's cull_stream (scene_cull_grid records cull_event behind the build)
   ctx->lpt[slot].launches = 0;
   if ((e = launch_pixels_ordered(ctx, Q, flags, side, slot)) != hipSuccess) return e;
   if ((e = hipEventRecord(ctx->sp_done[slot], side)) != hipSuccess) return e;
@@ -1501,6 +1531,8 @@ int rm_render_samples(rm_ctx* ctx, rm_scene* scene, rm_fb* fb, const RmUniforms*
   if (int rc = build_params(ctx, scene, fb, uniforms, tile, flags, &P, &empty)) return rc;
   if (count < 0 || (count > 0 && !rand_noise_pairs)) return fail(ctx, RM_ERR_INVALID, "rm_render_samples: bad count / NULL randNoise");
   if (empty) return RM_OK;
+  if (count > 1 && scene->cull_wanted)  // build_params counted one sample of the tile: the call asks for `count` (the grid, if this earns it, serves the next call)
+    scene->px_seen += (long long)(count - 1) * (long long)P.tw * (long long)P.th * (fb->stripe_rows > 0 ? (long long)fb->parts : 1ll);
   RM_HIP(ctx, hipSetDevice(ctx->device));
   // Samples the pixel kernel can stage (the conditions of launch()) go out in batches: one launch per batch.
   const bool wavefront = uses_wavefront(ctx, P, flags);

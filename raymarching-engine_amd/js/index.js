@@ -249,7 +249,7 @@ function evictScenes(map, destroy, pins, keep) {  // `keep`: the key being hande
     const v = map.get(k); map.delete(k); destroy(v); spare--;
   }
 }
-const scenePins = {  // mixed into both contexts: pinScene(scene) -> [key, handle or error value]; unpinScene(key)
+const scenePins = {  // mixed into both contexts, for hosts that hold handles themselves (doRenderJob does not pin: see there): pinScene(scene) -> [key, handle or error value]; unpinScene(key)
   pinScene(scene) { const hit = this.getScene(scene), key = scene.key(); this.pins.set(key, (this.pins.get(key) || 0) + 1); return [key, hit]; },
   unpinScene(key) { const n = (this.pins.get(key) || 0) - 1; if (n > 0) this.pins.set(key, n); else { this.pins.delete(key); this.evict(); } },
 };
@@ -389,12 +389,10 @@ async function doRenderJob(schema, context) {  // RenderJobExecutor.tsx:77
   const syncAll = () => { if (!framebuffers.sharded) for (const c of ctxs) addon.sync(c); };
   const syncEnd = () => { for (const c of ctxs) addon.sync(c); };
   return function* (present) {
-    // the scene stays pinned in the context's cache while this generator lives (it yields between samples; other jobs may bring in
-    // more scenes than the cache holds meanwhile); looked up again here: the generator may start long after the call above
-    const [pinKey, scene] = context.pinScene(schema.sdfScene);
-    try {
-    if (scene && scene.infoLog !== undefined) return { success: false, why: scene };
-    const scenes = framebuffers.sharded ? scene.handles : [scene];
+    // The job yields between samples, and other jobs may bring in more scenes than the cache holds meanwhile.  No pin is held across a
+    // yield (round 6: a JS generator that is started and then dropped without .return() never runs its `finally`, so a pin taken for
+    // its lifetime would keep the scene un-evictable for the life of the context): the scene is looked up again -- and, had it been
+    // evicted, made again -- in front of every batch of native calls, with nothing in between that could suspend the job.
     for (let yp = 0; yp < r.subdivisions; yp++) for (let xp = 0; xp < r.subdivisions; xp++) {
       const tile = tileRect(schema, xp, yp);
       for (let left = r.samplesPerPixel; left > 0;) {
@@ -404,6 +402,9 @@ async function doRenderJob(schema, context) {  // RenderJobExecutor.tsx:77
         const noise = new Float32Array(2 * k);
         for (let i = 0; i < k; i++) { noise[2 * i] = halton2.next().value; noise[2 * i + 1] = halton3.next().value; }
         const u = uniformsFromSchema(schema, [noise[0], noise[1]]);
+        const scene = context.getScene(schema.sdfScene);
+        if (scene && scene.infoLog !== undefined) { context.fboDelete(r.width, r.height, r.frameid); return { success: false, why: scene }; }
+        const scenes = framebuffers.sharded ? scene.handles : [scene];
         for (let g = 0; g < ctxs.length; g++) {
           if (k === 1) addon.renderSample(ctxs[g], scenes[g], fbs[g], u, tile, context.flags);
           else addon.renderSamples(ctxs[g], scenes[g], fbs[g], u, noise, tile, context.flags);
@@ -415,7 +416,6 @@ async function doRenderJob(schema, context) {  // RenderJobExecutor.tsx:77
     syncEnd();  // the job's last word: an asynchronous failure becomes this call's exception (the caller's {success: false})
     present(schema, context, framebuffers, samples);
     return { success: true };
-    } finally { context.unpinScene(pinKey); }
   };
 }
 

@@ -40,7 +40,7 @@ _SPACES = re.compile(f"[{_SPACE_CHARS}]+")
 _ANNOTATION = re.compile(f"@(?P<key>[A-Za-z0-9_]+)[{_SPACE_CHARS}]*=[{_SPACE_CHARS}]*(?P<value>\"[^\"]*?\"|[^{_SPACE_CHARS}]+)")
 _DECLARATION = re.compile(f"(?P<type>u?int|float|[iu]?vec[234])[{_SPACE_CHARS}]+(?P<name>[a-zA-Z_][a-zA-Z_0-9]*)")  # Validate.tsx:84-85
 _STRIP = "\t\n\v\f\r \u00a0\u1680\u2000\u2001\u2002\u2003\u2004\u2005\u2006\u2007\u2008\u2009\u200a\u2028\u2029\u202f\u205f\u3000\ufeff"
-_DECIMAL = re.compile(r"[+-]?(?:Infinity|\d+\.?\d*(?:[eE][+-]?\d+)?|\.\d+(?:[eE][+-]?\d+)?)$")
+_DECIMAL = re.compile(r"[+-]?(?:Infinity|[0-9]+\.?[0-9]*(?:[eE][+-]?[0-9]+)?|\.[0-9]+(?:[eE][+-]?[0-9]+)?)$")  # ASCII digits only: JavaScript's Number("\u0661") is NaN
 _RADIX = {"x": 16, "X": 16, "b": 2, "B": 2, "o": 8, "O": 8}
 FORMATS = ("numerical", "position", "color", "checkbox")
 

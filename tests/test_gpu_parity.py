@@ -2028,6 +2028,24 @@ def test_culling_grids_stay_within_their_budget_and_give_way_exactly(ctx):
                 assert st["bytes"] <= st["budget"] and st["grids"] <= 2
                 held.append(st["grids"])
         assert max(held) == 2 and ctx.cull_stats()["built"] - st0["built"] >= 8  # grids went and were rebuilt
+        # round 6: a lowered budget takes effect at once -- the least recently rendered scene's grid goes now, not with the
+        # next build -- and a grid larger than the whole budget is not built, but stays wanted: raise the budget and the next render builds it
+        ctx.set_cull_budget(40 << 20)
+        st = ctx.cull_stats()
+        assert st["grids"] == 1 and st["bytes"] <= 40 << 20
+        ctx.set_cull_budget(8 << 20)  # smaller than one grid (31.5 MB)
+        assert ctx.cull_stats()["grids"] == 0 and ctx.cull_stats()["bytes"] == 0
+        built = ctx.cull_stats()["built"]
+        for budget, grids in ((8 << 20, 0), (70 << 20, 1)):
+            ctx.set_cull_budget(budget)
+            fb = ctx.create_framebuffer(320, 224)
+            for n in noises:
+                ctx.render_sample(handles[1], fb, J.uniforms_from_schema(schemas[1], tuple(n)), None, FAST | MK)
+            got = [fb.download(k) for k in range(3)]
+            fb.destroy()
+            for k in range(3):
+                assert same_bits(got[k], want[1][k]).all(), f"budget {budget >> 20} MB, plane {k}"
+            assert ctx.cull_stats()["grids"] == grids and ctx.cull_stats()["built"] - built == grids
         for h in handles:
             h.destroy()
         assert ctx.cull_stats()["grids"] == 0 and ctx.cull_stats()["bytes"] == 0
