@@ -353,6 +353,8 @@ def main():
     ap.add_argument("--rows", default="", help="render only image rows A:B of the frame (e.g. one shard of C4/C5 on one GPU)")
     ap.add_argument("--stripe-of", type=int, default=0, help="one GPU standing in for rank 0 of an N-way split: render its 8-row stripes of the frame (no collective)")
     ap.add_argument("--strict", action="store_true", help="parity build instead of the fast build")
+    ap.add_argument("--gl-stack", type=int, default=0, choices=(0, 1, 2), help="the parity build in the GL stack's arithmetic (rm_ctx_set_gl_stack: 1 = with the portable tangent, 2 = its own tan: the "
+                                                                              "reference's bits as SwiftShader renders the unmodified shader); implies --strict --megakernel")
     ap.add_argument("--megakernel", action="store_true", help="force the one-thread-one-pixel kernel (default: the library picks per job)")
     ap.add_argument("--wavefront", action="store_true", help="the wavefront pipeline (the tests' second implementation: loads tests/_xcheck/libhip_raymarch_xcheck.so instead of the product library)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -373,6 +375,7 @@ def main():
     ap.add_argument("--no-far-jump", action="store_true", help="RM_RENDER_NO_FAR_JUMP: march escaping rays step by step (measurement switch, same bits)")
     ap.add_argument("--no-cull", action="store_true", help="RM_RENDER_NO_CULL: fold every row of a primitive table at every point (measurement switch, same bits)")
     ap.add_argument("--counter-child", action="store_true", help="(internal) render a few frames of every leg and exit: what live_counters profiles")
+    ap.add_argument("--dump-counters", default="", help="write this run's measured counters to the given file in the format of profiles/<round>_counters.json (what a later run replays when it cannot measure)")
     ap.add_argument("--no-live-counters", action="store_true", help="do not measure the hardware counters in this run (replay profiles/<round>_counters.json)")
     ap.add_argument("--no-workloads", action="store_true", help="skip the `workloads` legs (the other BASELINE configurations and the two parity builds of the headline, a few steps each)")
     ap.add_argument("--no-check-frame", action="store_true", help="sharded runs check the assembled frame by default (see --check-frame); this skips it")
@@ -399,9 +402,27 @@ def main():
 
     live, live_note = None, None
     default_run = (world == 1 and os.environ.get("RM_BENCH_FORCE_DIST") != "1" and args.workload == "c3b" and not args.strict and not args.rows and args.stripe_of <= 1
-                   and not args.wavefront and not args.dof and not args.no_far_jump and not args.no_cull)
+                   and not args.wavefront and not args.dof and not args.no_far_jump and not args.no_cull and not args.gl_stack)
     if default_run and not args.no_live_counters and not under_a_profiler():
         live, live_note = live_counters()  # child processes, before this one touches the GPU
+
+    if live and args.dump_counters:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("update_counters", os.path.join(ROOT, "tools", "update_counters.py"))
+        uc = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(uc)
+        sha = uc.kernel_source_hash()
+        dump = {"_about": "Per-frame hardware counters of bench.py's headline and of every `workloads` leg, as measured by bench.py itself (live_counters: rocprofv3 --pmc child "
+                          "passes of `bench.py --counter-child`, --kernel-trace only, FETCH_SIZE and WRITE_SIZE in passes of their own; hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1000: "
+                          "gfx950 tallies 128-B requests at 64 B; executed_lane_flops = (ADD + MUL + 2 FMA + TRANS fp32 wave instructions) x 64 x lanes active).  A later run that "
+                          "cannot measure (no rocprofv3, or under a profiler itself) replays this file while the kernel sources still hash to kernel_source_sha256.",
+                "_measured": live_note}
+        for key, ent in live.items():
+            k2 = {"c4_fast": "c4_fast_megakernel", "c5_fast": "c5_fast_megakernel"}.get(key, key)  # (the keys counters_entry looks up)
+            dump[k2] = dict(ent, profile=os.path.relpath(args.dump_counters, ROOT), kernel_source_sha256=sha)
+            if k2 != key:
+                dump[key] = dump[k2]
+        json.dump(dump, open(args.dump_counters, "w"), indent=1)
 
     import numpy as np
     import torch
@@ -441,6 +462,8 @@ def main():
     W, H = wl["width"], wl["height"]
     if args.dof:  # the live default (index.tsx:309-310): the job has depth of field, so a sharded present gathers the packed rows
         schema["dof"]["amount"], schema["dof"]["distance"] = 0.01, 1.5
+    if args.gl_stack:
+        args.strict = args.megakernel = True
     flags = abi.RM_RENDER_STRICT if args.strict else abi.RM_RENDER_FAST
     if args.megakernel:
         flags |= abi.RM_RENDER_MEGAKERNEL
@@ -469,6 +492,8 @@ def main():
     jctx = J.RenderJobContext(local_rank, flags=flags, group=group, rows=(rows_window[0], rows_window[1] - rows_window[0]) if rows_window else None,
                               stripes=stripes)
     ctx = jctx.native
+    if args.gl_stack:
+        ctx.set_gl_stack(args.gl_stack)
     if not sharded:
         render_stream = torch.cuda.Stream(device=dev)
         torch.cuda.set_stream(render_stream)
@@ -686,7 +711,7 @@ def main():
         ent = (live or {}).get("c3b_fast") if default_run else None
         if ent and ent["pipeline"] != pipeline:
             ent = None
-        ent = ent or counters_entry(args.workload, args.strict, pipeline, rows_window is not None or stripes is not None)
+        ent = ent or counters_entry(args.workload, args.strict, pipeline, rows_window is not None or stripes is not None, args.gl_stack)
         if ent:
             share = px_launch / ent["pixels_per_frame"]
             traffic = ent["hbm_bytes_per_frame"] * share
@@ -733,7 +758,7 @@ def main():
             "value": value, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "spread": spread,
-            "config": {"workload": wl["name"] + (" + depth of field 0.01 @ 1.5" if args.dof else ""), "build": "strict" if args.strict else "fast",
+            "config": {"workload": wl["name"] + (" + depth of field 0.01 @ 1.5" if args.dof else ""), "build": (f"glstack (rm_ctx_set_gl_stack {args.gl_stack})" if args.gl_stack else "strict" if args.strict else "fast"),
                        "rows_per_gpu": row_count, "stripe_of": args.stripe_of if stripes else None,
                        "pipeline": pipeline + ("" if (args.megakernel or args.wavefront) else " (the library's choice)"),
                        "host": "job.do_render_job on a job.RenderJobContext" + (" (sharded: dist.ShardGroup)" if sharded else ""),
