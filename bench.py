@@ -498,7 +498,7 @@ def main():
         render_stream = torch.cuda.Stream(device=dev)
         torch.cuda.set_stream(render_stream)
         ctx.set_stream(render_stream.cuda_stream)
-    # measured on one GPU standing in for a rank (tools/dbg/depth_sweep.py, ms per sample of a rank's stripes, depth 1/2/3/4/6):
+    # measured on one GPU standing in for a rank (a depth sweep of round 2, ms per sample of a rank's stripes, depth 1/2/3/4/6):
     # whole frame 2.48/2.57/2.55/2.51/2.51, 1/2 of it 1.45/1.32/1.31/1.29/1.28, 1/4 0.88/0.70/0.70/0.68/0.66, 1/8 0.58/0.41/0.46/0.37/0.36
     # sharded, the job yields every 8 samples: a rank's 8 samples go out as ONE launch of a full frame's worth of workgroups
     # (rm_render_samples, rm_ctx_set_sample_batch), three such launches in flight, one present + gather per yield

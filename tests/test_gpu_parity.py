@@ -926,7 +926,7 @@ def test_random_present_passes_equal_the_oracle_byte_for_byte(ctx):
 
 
 def test_nasty_inputs_through_the_c_abi_always_return():
-    """tools/dbg/abuse_fuzz.py in a process of its own (a call that did not return would be stopped by the timeout):
+    """tools/abuse_fuzz.py in a process of its own (a call that did not return would be stopped by the timeout):
     1500 scene descriptions and uniform blocks drawn from {0, -0, +-1, 1e-30, 1e30, +-Inf, NaN, ...} with out-of-range
     kinds, operators, counts and enums.  Every call returns -- RM_OK, or an error code with a message -- and every
     render that was accepted completes (9 000 cases have been run)."""
@@ -934,7 +934,7 @@ def test_nasty_inputs_through_the_c_abi_always_return():
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dbg", "abuse_fuzz.py"), "1500"], capture_output=True, text=True, timeout=180,
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "abuse_fuzz.py"), "1500"], capture_output=True, text=True, timeout=180,
                        env=dict(os.environ, SEED="7"))
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     last = r.stdout.strip().splitlines()[-1]
@@ -973,7 +973,7 @@ def test_contexts_give_their_memory_back(ctx):
     batch, the wavefront pipeline, cost-ordered dispatch, the present pass, device buffers (one of them never destroyed)
     -- returns all of its device memory when it is closed.  The first few contexts of a process also make the HIP
     runtime allocate what it keeps for good (code objects, the scratch of each hardware queue its streams land on:
-    ~0.5 GB, tools/dbg/leak_probe.py), so the measurement starts after four of them: over the next eight the GPU's free
+    ~0.5 GB, a leak probe of round 3), so the measurement starts after four of them: over the next eight the GPU's free
     memory does not move."""
     from raymarching_engine_amd import native
 
@@ -1092,7 +1092,7 @@ def _random_scene(rng):
 
 
 def test_random_jobs_strict_build_equals_the_oracle_bit_for_bit(ctx):
-    """300 random jobs (RM_RANDOM_JOBS; 4000 have been run: tools/dbg/random_parity.py) -- a random scene of the composition API (every kind, random parameters and materials, tables with
+    """300 random jobs (RM_RANDOM_JOBS; 4000 have been run: a round-3 probe) -- a random scene of the composition API (every kind, random parameters and materials, tables with
     every operator and the domain rows), the three cameras with random rotation, depth of field, fog, 0..3 lights (points,
     a sun, soft ones), 1..4 bounces, both blend modes, preview and full, the focal-plane overlay, 1..3 samples, both
     implementations -- rendered by the strict build and by the oracle: every plane bit-identical.  (These jobs found
@@ -1256,8 +1256,8 @@ def test_random_jobs_fast_build_estimates_what_the_strict_build_estimates(ctx):
     """60 random full-mode jobs (scenes of every kind, cameras, 0-2 lights, 1-3 bounces of >= 128 steps -- enough for a sky
     ray to overflow): the image mean of 32 fast samples against 32 strict samples with the same random
     stream differs by no more than four times what 32 strict samples with ANOTHER stream differ by (the Monte-Carlo
-    yardstick), plus 1 % of the mean, and the two builds agree on which pixels are finite.  (tools/dbg/
-    fast_vs_strict_fuzz.py is the study this comes from.)"""
+    yardstick), plus 1 % of the mean, and the two builds agree on which pixels are finite.  (A round-3 study,
+    fast_vs_strict_fuzz.py in the git history, is where this comes from.)"""
     rng = np.random.default_rng(2026 + SEED_OFFSET)
     spp = 32
     noise = GC.halton_pairs(2 * spp)

@@ -21,4 +21,4 @@ for seed in 1 2 3; do
   RM_RANDOM_SEED=$seed RM_RANDOM_JOBS=2000 RM_RANDOM_SCENES=1500 RM_RANDOM_JOBS2=1000 timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "random" 2>&1 | tail -2
 done | tee $O/log_seeds.txt
 RM_RANDOM_SEED=9 RM_RANDOM_GL_JOBS=8000 timeout 1500 python -m pytest tests/test_gpu_reference_bits.py -m gpu -q -x -k random_jobs_equal 2>&1 | tail -1 | tee $O/log_gl.txt
-for s in 41 42 43 44; do SEED=$s timeout 300 python3 tools/dbg/abuse_fuzz.py 4000 2>&1 | tail -1; done | tee $O/log_abuse.txt
+for s in 41 42 43 44; do SEED=$s timeout 300 python3 tools/abuse_fuzz.py 4000 2>&1 | tail -1; done | tee $O/log_abuse.txt
