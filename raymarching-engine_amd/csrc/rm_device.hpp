@@ -551,15 +551,33 @@ struct Sdf<RM_SCENE_TABLE> {
     // of two: no gain over two, 24 registers of rows.  With HALF the LDS reads and the same arithmetic -- a diagnostic build -- the fold
     // is not faster at all, 12.9 against 12.1 ms: it is not LDS-bound; and at 6 / 5 waves per SIMD, where nothing spills, C5 takes
     // 177 / 235 ms: it lives on occupancy.)
+    // The square roots of a trip back to back, in ONE asm statement (round 6).  A quarter-rate instruction among ordinary ones costs ~6.8 issue
+    // slots on this chip, not the 3.2 it costs in a stream of its own kind (tools/ubench/fold_rate.hip: the fold alone, nothing around it, took
+    // 0.74 of the issue slots with its square roots where the compiler puts them -- after their own row's sum, apart -- and the same fold with an
+    // ordinary multiply in their place 0.89): going into and out of the transcendental pipe is paid per GROUP.  Four in a row: the fold alone
+    // 21.9 -> 18.8 ms (-14 %).  Same operations on the same values: same bits.
+#ifndef RM_SQRT_GROUPS
+#define RM_SQRT_GROUPS 1
+#endif
+    auto len2 = [&](const float4 r) { const v3 q = p - V(r.x, r.y, r.z); return FM::fma(q.z, q.z, FM::fma(q.y, q.y, q.x * q.x)); };
     auto fold_range = [&](int i, int end) {
       for (; i + 3 < end; i += 4) {
         const float4 r0 = rows[i], r1 = rows[i + 1], r2 = rows[i + 2], r3 = rows[i + 3];
+#if RM_SQRT_GROUPS
+        float s0 = len2(r0), s1 = len2(r1), s2 = len2(r2), s3 = len2(r3);
+        asm("v_sqrt_f32 %0, %0\n\tv_sqrt_f32 %1, %1\n\tv_sqrt_f32 %2, %2\n\tv_sqrt_f32 %3, %3" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3));
+        d = smooth_row(d, s0 - r0.w, k, half_inv_k);
+        d = smooth_row(d, s1 - r1.w, k, half_inv_k);
+        d = smooth_row(d, s2 - r2.w, k, half_inv_k);
+        d = smooth_row(d, s3 - r3.w, k, half_inv_k);
+#else
         const float d0 = sphere_row1(r0, p), d1 = sphere_row1(r1, p);
         d = smooth_row(d, d0, k, half_inv_k);
         d = smooth_row(d, d1, k, half_inv_k);
         const float d2 = sphere_row1(r2, p), d3 = sphere_row1(r3, p);
         d = smooth_row(d, d2, k, half_inv_k);
         d = smooth_row(d, d3, k, half_inv_k);
+#endif
       }
       for (; i < end; i++) d = smooth_row(d, sphere_row1(rows[i], p), k, half_inv_k);
     };
@@ -578,9 +596,16 @@ struct Sdf<RM_SCENE_TABLE> {
         if (u != 0ull) {
           const float4* a1 = next_row();
           const float4 r0 = *a0, r1 = *a1;
+#if RM_SQRT_GROUPS
+          float s0 = len2(r0), s1 = len2(r1);
+          asm("v_sqrt_f32 %0, %0\n\tv_sqrt_f32 %1, %1" : "+v"(s0), "+v"(s1));
+          d = smooth_row(d, s0 - r0.w, k, half_inv_k);
+          d = smooth_row(d, s1 - r1.w, k, half_inv_k);
+#else
           const float d0 = sphere_row1(r0, p), d1 = sphere_row1(r1, p);
           d = smooth_row(d, d0, k, half_inv_k);
           d = smooth_row(d, d1, k, half_inv_k);
+#endif
         } else {
           d = smooth_row(d, sphere_row1(*a0, p), k, half_inv_k);
         }
@@ -1015,9 +1040,17 @@ struct Sdf<RM_SCENE_MANDELBULB> {
   // One statement per round leaves one s_nop and 2 % fewer VALU instructions -- and the headline frame 6 % SLOWER, 1.93 against
   // 1.82 ms, with the two transcendentals next to each other or four instructions apart: the no-ops are not what the round waits
   // for, and the compiler's interleaving of the round with the code around it is worth more than they cost.  Not kept.)
+#ifndef RM_TRANS_GROUPS
+#define RM_TRANS_GROUPS 1  // the two transcendentals of a round, and of the distance, back to back in one asm statement (see eval_spheres_one_k: going into and out of the quarter-rate pipe is paid per group)
+#endif
   static RM_DEV void pow8_round(v3& z, float& dr, v3 pos, float rho2, float r2) {
+#if RM_TRANS_GROUPS
+    float r, q;
+    asm("v_sqrt_f32 %0, %2\n\tv_rsq_f32 %1, %3" : "=&v"(r), "=&v"(q) : "v"(r2), "v"(rho2));
+#else
     const float r = FM::sqrt(r2);
     const float q = __builtin_amdgcn_rsqf(rho2);
+#endif
     const float rho = rho2 * q;
     const float r4 = r2 * r2;
     dr = FM::fma_x2(FM::mul_x4(r4 * r2, r), dr, 0.5f);  // 8 r^7 dr + 1 = 2 ((4 r^7) dr + 0.5)
@@ -1056,10 +1089,25 @@ struct Sdf<RM_SCENE_MANDELBULB> {
 #ifdef RM_DIST_3T  // experiment builds: round 2's form
     return __builtin_amdgcn_logf(r2) * 0.17328680f * FM::sqrt(r2) * FM::rcp(dr);
 #else
+#if RM_TRANS_GROUPS
+    float l, w;
+    const float a = (r2 * dr) * dr;
+    asm("v_log_f32 %0, %2\n\tv_rsq_f32 %1, %3" : "=&v"(l), "=&v"(w) : "v"(r2), "v"(a));
+    return (l * 0.17328680f) * (r2 * w);
+#else
     return (__builtin_amdgcn_logf(r2) * 0.17328680f) * (r2 * __builtin_amdgcn_rsqf((r2 * dr) * dr));
 #endif
+#endif
   }
-  static RM_DEV float pow8_distance_far(float r2) { return __builtin_amdgcn_logf(r2) * 0.17328680f * FM::sqrt(r2); }
+  static RM_DEV float pow8_distance_far(float r2) {
+#if RM_TRANS_GROUPS
+    float l, r;
+    asm("v_log_f32 %0, %2\n\tv_sqrt_f32 %1, %2" : "=&v"(l), "=&v"(r) : "v"(r2));
+    return l * 0.17328680f * r;
+#else
+    return __builtin_amdgcn_logf(r2) * 0.17328680f * FM::sqrt(r2);
+#endif
+  }
   // ITERS = 8: the usual round count, unrolled -- no loop bookkeeping between the exec-mask regions (11 % on the
   // headline frame); ITERS = 0: the count is a scene parameter
   template <int ITERS>

@@ -8,9 +8,11 @@
 #include <cstdio>
 #include <vector>
 
+template <int MODE>
 __device__ __forceinline__ float sphere_row1(const float4 r, float x, float y, float z) {
   const float qx = x - r.x, qy = y - r.y, qz = z - r.z;
-  return __builtin_amdgcn_sqrtf(__builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, qx * qx))) - r.w;
+  const float q2 = __builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, qx * qx));
+  return ((MODE & 1) ? q2 * 0.37f : __builtin_amdgcn_sqrtf(q2)) - r.w;  // MODE & 1: an ordinary multiply in the square root's place
 }
 __device__ __forceinline__ float smooth_row(float d, float di, float k, float hik) {
   const float t = di - d;
@@ -18,7 +20,7 @@ __device__ __forceinline__ float smooth_row(float d, float di, float k, float hi
   return __builtin_fmaf(-h, __builtin_fmaf(k, 1.0f - h, t), di);
 }
 
-template <int ROWS_PER_TRIP>
+template <int MODE>
 __global__ __launch_bounds__(512, 8) void fold(const float4* table, int n, int evals, float k, float* out, unsigned long long* cyc) {
   __shared__ float4 rows[256];
   for (int i = threadIdx.x; i < n; i += blockDim.x) rows[i] = table[i];
@@ -28,18 +30,31 @@ __global__ __launch_bounds__(512, 8) void fold(const float4* table, int n, int e
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   float acc = 0.0f;
   for (int e = 0; e < evals; e++) {
-    float d = sphere_row1(rows[0], x, y, z);
+    float d = sphere_row1<MODE>(rows[0], x, y, z);
     int i = 1;
+    float4 k0 = rows[1], k1 = rows[2], k2 = rows[3], k3 = rows[4];  // MODE & 2: the same four rows every trip, read once per evaluation (no LDS read in the loop)
     for (; i + 3 < n; i += 4) {
-      const float4 r0 = rows[i], r1 = rows[i + 1], r2 = rows[i + 2], r3 = rows[i + 3];
-      const float d0 = sphere_row1(r0, x, y, z), d1 = sphere_row1(r1, x, y, z);
+      float4 r0, r1, r2, r3;
+      if (MODE & 2) { r0 = k0; r1 = k1; r2 = k2; r3 = k3; asm volatile("" : "+v"(k0.x), "+v"(k1.x), "+v"(k2.x), "+v"(k3.x)); }
+      else { r0 = rows[i]; r1 = rows[i + 1]; r2 = rows[i + 2]; r3 = rows[i + 3]; }
+      if (MODE & 4) {  // the four square roots of a trip back to back (one statement), then the four unions
+        auto q2 = [&](const float4 r) { const float qx = x - r.x, qy = y - r.y, qz = z - r.z; return __builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, qx * qx)); };
+        float s0 = q2(r0), s1 = q2(r1), s2 = q2(r2), s3 = q2(r3);
+        asm volatile("v_sqrt_f32 %0, %0\n\tv_sqrt_f32 %1, %1\n\tv_sqrt_f32 %2, %2\n\tv_sqrt_f32 %3, %3" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3));
+        d = smooth_row(d, s0 - r0.w, k, hik);
+        d = smooth_row(d, s1 - r1.w, k, hik);
+        d = smooth_row(d, s2 - r2.w, k, hik);
+        d = smooth_row(d, s3 - r3.w, k, hik);
+        continue;
+      }
+      const float d0 = sphere_row1<MODE>(r0, x, y, z), d1 = sphere_row1<MODE>(r1, x, y, z);
       d = smooth_row(d, d0, k, hik);
       d = smooth_row(d, d1, k, hik);
-      const float d2 = sphere_row1(r2, x, y, z), d3 = sphere_row1(r3, x, y, z);
+      const float d2 = sphere_row1<MODE>(r2, x, y, z), d3 = sphere_row1<MODE>(r3, x, y, z);
       d = smooth_row(d, d2, k, hik);
       d = smooth_row(d, d3, k, hik);
     }
-    for (; i < n; i++) d = smooth_row(d, sphere_row1(rows[i], x, y, z), k, hik);
+    for (; i < n; i++) d = smooth_row(d, sphere_row1<MODE>(rows[i], x, y, z), k, hik);
     z += 0.01f * d;  // the march's dependence of the next point on this distance
     acc += d;
   }
@@ -58,27 +73,38 @@ int main() {
   hipMalloc(&d_out, (size_t)max_blocks * 512 * 4 * 4); hipMalloc(&d_cyc, max_blocks * 8 * 4);
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   // instructions per evaluation and wave: 13 VALU per row (8 sphere + 5 union) + 1 v_mov per 4 rows; v_sqrt counted at 3.2 slots
-  const double valu_per_eval = 64 * 13.0 + 16, slots_per_eval = valu_per_eval + 64 * 2.2;
-  for (int blocks_per_cu : {4, 2, 1}) {  // 8-wave workgroups: 8 / 4 / 2 waves per SIMD
-    const int blocks = 256 * blocks_per_cu;
-    fold<4><<<blocks, 512>>>(d_t, n, 10, 0.2f, d_out, d_cyc);
+  const double valu_per_eval = 64 * 13.0 + 16;
+  auto run = [&](int mode, int blocks, int threads, int ev) {
+    switch (mode) {
+      case 0: fold<0><<<blocks, threads>>>(d_t, n, ev, 0.2f, d_out, d_cyc); break;
+      case 1: fold<1><<<blocks, threads>>>(d_t, n, ev, 0.2f, d_out, d_cyc); break;
+      case 2: fold<2><<<blocks, threads>>>(d_t, n, ev, 0.2f, d_out, d_cyc); break;
+      case 3: fold<3><<<blocks, threads>>>(d_t, n, ev, 0.2f, d_out, d_cyc); break;
+      case 4: fold<4><<<blocks, threads>>>(d_t, n, ev, 0.2f, d_out, d_cyc); break;
+      default: fold<6><<<blocks, threads>>>(d_t, n, ev, 0.2f, d_out, d_cyc); break;
+    }
+  };
+  const char* names[6] = {"the fold as the kernels run it", "an ordinary multiply in the square root's place", "no LDS read in the loop (the same four rows every trip)", "neither",
+                          "the four square roots of a trip back to back", "... and no LDS read in the loop"};
+  for (int mode = 0; mode < 6; mode++) {
+    const double slots = valu_per_eval + ((mode & 1) ? 0.0 : 64 * 2.2);
+    printf("== %s\n", names[mode]);
+    for (int blocks_per_cu : {4, 2, 1}) {  // 8-wave workgroups: 8 / 4 / 2 waves per SIMD
+      const int blocks = 256 * blocks_per_cu;
+      run(mode, blocks, 512, 10);
+      hipEventRecord(a);
+      run(mode, blocks, 512, evals);
+      hipEventRecord(b); hipEventSynchronize(b);
+      float ms; hipEventElapsedTime(&ms, a, b);
+      const double waves = blocks * 8.0;
+      printf("%d waves per SIMD: %.3f ms; %.3g wave-level VALU instructions/s, %.3g issue slots/s = %.2f of the ~1.0e12 a dense fp32 stream gets\n", blocks_per_cu * 2, ms,
+             waves * evals * valu_per_eval / (ms * 1e-3), waves * evals * slots / (ms * 1e-3), waves * evals * slots / (ms * 1e-3) / 1.0e12);
+    }
     hipEventRecord(a);
-    fold<4><<<blocks, 512>>>(d_t, n, evals, 0.2f, d_out, d_cyc);
+    run(mode, 256, 256, evals);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
-    const double waves = blocks * 8.0;
-    printf("%d waves per SIMD: %.3f ms; %.3g wave-level VALU instructions/s, %.3g issue slots/s (a dense fp32 stream: ~1.0e12) = %.2f of them\n", blocks_per_cu * 2, ms,
-           waves * evals * valu_per_eval / (ms * 1e-3), waves * evals * slots_per_eval / (ms * 1e-3), waves * evals * slots_per_eval / (ms * 1e-3) / 1.0e12);
-  }
-  // 256-thread workgroups, one per SIMD quadruple: 1 wave per SIMD
-  {
-    const int blocks = 256;
-    hipEventRecord(a);
-    fold<4><<<blocks, 256>>>(d_t, n, evals, 0.2f, d_out, d_cyc);
-    hipEventRecord(b); hipEventSynchronize(b);
-    float ms; hipEventElapsedTime(&ms, a, b);
-    const double waves = blocks * 4.0;
-    printf("1 wave per SIMD: %.3f ms; %.3g issue slots/s = %.2f\n", ms, waves * evals * slots_per_eval / (ms * 1e-3), waves * evals * slots_per_eval / (ms * 1e-3) / 1.0e12);
+    printf("1 wave per SIMD: %.3f ms; %.3g issue slots/s = %.2f\n", ms, 256 * 4.0 * evals * slots / (ms * 1e-3), 256 * 4.0 * evals * slots / (ms * 1e-3) / 1.0e12);
   }
   return 0;
 }
