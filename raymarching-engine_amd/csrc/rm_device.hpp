@@ -555,7 +555,8 @@ struct Sdf<RM_SCENE_TABLE> {
     // slots on this chip, not the 3.2 it costs in a stream of its own kind (tools/ubench/fold_rate.hip: the fold alone, nothing around it, took
     // 0.74 of the issue slots with its square roots where the compiler puts them -- after their own row's sum, apart -- and the same fold with an
     // ordinary multiply in their place 0.89): going into and out of the transcendental pipe is paid per GROUP.  Four in a row: the fold alone
-    // 21.9 -> 18.8 ms (-14 %).  Same operations on the same values: same bits.
+    // 21.9 -> 18.8 ms (-14 %); in the kernels C5 140.8 -> 137.5 ms.  (Eight rows and eight roots per trip: 165 spilled VGPRs, C5 140.2.)  Same operations on the
+    // same values: same bits.
 #ifndef RM_SQRT_GROUPS
 #define RM_SQRT_GROUPS 1
 #endif
@@ -591,6 +592,24 @@ struct Sdf<RM_SCENE_TABLE> {
         asm volatile("s_ff1_i32_b64 %0, %1\n\ts_bitset0_b64 %1, %0" : "=&s"(j), "+s"(u));
         return wrows + j;
       };
+#ifndef RM_LISTED4
+#define RM_LISTED4 1  // four listed rows per trip while the list holds four, their square roots in one group (C4 8.62 -> 8.48 ms, its stripes 1.70 -> 1.63)
+#endif
+#if RM_LISTED4
+      while (__builtin_popcountll(u) >= 4) {
+        const float4* a0 = next_row();
+        const float4* a1 = next_row();
+        const float4* a2 = next_row();
+        const float4* a3 = next_row();
+        const float4 r0 = *a0, r1 = *a1, r2 = *a2, r3 = *a3;
+        float s0 = len2(r0), s1 = len2(r1), s2 = len2(r2), s3 = len2(r3);
+        asm("v_sqrt_f32 %0, %0\n\tv_sqrt_f32 %1, %1\n\tv_sqrt_f32 %2, %2\n\tv_sqrt_f32 %3, %3" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3));
+        d = smooth_row(d, s0 - r0.w, k, half_inv_k);
+        d = smooth_row(d, s1 - r1.w, k, half_inv_k);
+        d = smooth_row(d, s2 - r2.w, k, half_inv_k);
+        d = smooth_row(d, s3 - r3.w, k, half_inv_k);
+      }
+#endif
       while (u != 0ull) {
         const float4* a0 = next_row();
         if (u != 0ull) {
