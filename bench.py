@@ -59,6 +59,18 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 128 lanes x 2 flop x 2.4 GHz
 PEAK_HBM_GBS = 8000.0
 VALU_ISSUE_PER_S = 1.0e12  # wave-level VALU instructions/s the chip sustains at the clock it holds under a dense fp32 stream (profiles/r02_valu_issue_rate.txt)
+# Round 6's issue-slot model (tools/ubench/fold_rate.hip, profiles/r06_fold_rate.txt): the 64-row fold alone issues 1.03e12 slots/s with no
+# transcendental and no LDS read in it; a quarter-rate instruction among ordinary ones takes ~7.1 slots where it stands alone and ~4.1 in a group
+# of four (the kernels group them: 3.1 beyond the one it is counted as), a ds_read_b128 2.1.
+ISSUE_SLOTS_PER_S, TRANS_EXTRA_SLOTS, LDS_SLOTS = 1.03e12, 3.1, 2.1
+
+
+def issue_accounted(ent, kernel_ms):
+    """Share of the kernel's time that its instruction stream accounts for under the model above (None without the counters)."""
+    if not ent or not ent.get("sq_insts_valu_per_frame") or ent.get("sq_insts_lds_per_frame") is None:
+        return None
+    slots = ent["sq_insts_valu_per_frame"] + TRANS_EXTRA_SLOTS * ent["trans_f32_per_frame"] + LDS_SLOTS * ent["sq_insts_lds_per_frame"]
+    return slots / (kernel_ms * 1e-3) / ISSUE_SLOTS_PER_S
 
 WORKLOADS = {
     # SURVEY.md 8(d): C3b is the headline; the others are selectable for profiling
@@ -677,6 +689,7 @@ def main():
                    "hbm_bytes_per_px": ent["hbm_bytes_per_pixel"] if ent else None, "lanes_active": ent["lanes_active"] if ent else None,
                    "valu_issue_busy": (ent["sq_insts_valu_per_frame"] + 2.2 * ent["trans_f32_per_frame"]) / (k_ms * 1e-3) / VALU_ISSUE_PER_S if ent else None,
                    "salu_per_valu": ent["sq_insts_salu_per_frame"] / ent["sq_insts_valu_per_frame"] if ent and ent.get("sq_insts_salu_per_frame") else None,
+                   "issue_accounted": issue_accounted(ent, k_ms),
                    "counters_from": (ent["counters_file"] + ("" if ent["profile"] == "this run" else " -> " + ent["profile"])) if ent else None}
             workloads[key + "_" + build] = leg
             jctx.fbo_delete(W2, H2, 100 + n_leg)
@@ -737,7 +750,7 @@ def main():
                     # so this fraction cannot exceed 1 (frac can: 4.5 on C4)
                     "frac_useful": useful_launch / sec / 1e12 / PEAK_FP32_VALU_TFLOPS if useful_launch else None,
                     "flops_per_pixel_sample_useful": useful_px,
-                    "counters_from": counters_from, "valu_issue_busy": issue_busy, "fma_share": fma_share,
+                    "counters_from": counters_from, "valu_issue_busy": issue_busy, "fma_share": fma_share, "issue_accounted": issue_accounted(ent, kernel_ms),
                     "flops_per_pixel_sample_instrumented": flops_px, "flops_per_pixel_sample_nominal": nominal_px,
                     "flops_per_launch_instrumented": flops_launch,
                     "flops_source": f"profiles/flops_per_pixel.json[{args.workload}] (every {fixture['row_stride']} row(s) of the whole frame; tools/count_flops.py)",
@@ -752,7 +765,9 @@ def main():
                             "valu_issue_busy and fma_share come from the hardware counters named in counters_from (measured by this run's own rocprofv3 passes "
                             "on the default one-GPU invocation, else replayed from the builder's): frac_executed = (ADD + MUL + 2 FMA + TRANS) "
                             "x 64 x lanes active / kernel time / peak; with fma_share of the VALU instructions being FMAs (2 flops) and the rest 1 or 0, and "
-                            "valu_issue_busy of the issue slots taken, that is what bounds it"}
+                            "valu_issue_busy of the issue slots taken, that is what bounds it.  issue_accounted (round 6) = (VALU + 3.1 TRANS + 2.1 LDS instructions) / kernel time / 1.03e12: the share of the "
+                            "kernel's time its instruction stream accounts for at what instructions cost on this chip in such a mix (tools/ubench/fold_rate.hip: a transcendental in a group of four "
+                            "4.1 slots, a ds_read_b128 2.1, a dense fp32 stream 1.03e12 slots/s); the rest is waves that are not there to issue"}
         out = {
             "metric": "Mpixels/sec at 3840x2160 Mandelbulb" if args.workload in ("c3b", "c3a") else "Mpixels/sec",
             "value": value, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

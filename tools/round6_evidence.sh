@@ -16,6 +16,7 @@ for w in "--workload c2 --steps 20" "--workload c3a" "--workload c4" "--workload
   timeout 300 python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-live-counters $w 2>/dev/null | tail -1
 done
 } > $O/bench_workloads.txt
+(cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -ffp-contract=off -o fold_rate fold_rate.hip > /dev/null 2>&1); timeout 120 tools/ubench/fold_rate > $O/fold_rate.txt 2>&1
 timeout 600 python3 tools/time_all.py > $O/time_all.txt 2>&1
 timeout 600 python3 tools/emulate_ranks.py > $O/shard_emulation.txt 2>&1
 EMU_YIELD=1 timeout 600 python3 tools/emulate_ranks.py >> $O/shard_emulation.txt 2>&1
