@@ -695,3 +695,31 @@ def test_public_header_is_self_contained_c_and_cxx(tmp_path):
     src.write_text('#include "include/hip_raymarch.h"\nint main(void) { return RM_ABI_VERSION > 0 ? 0 : 1; }\n')
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", str(root), str(src)], check=True)
     subprocess.run(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c++", "-I", str(root), str(src)], check=True)
+
+
+def test_bench_counters_fall_back_to_the_replay_file_and_that_file_matches_the_sources(monkeypatch):
+    """bench.py measures its hardware counters itself (live_counters: rocprofv3 --pmc child passes); where it cannot -- no rocprofv3, or the
+    run is itself under a profiler -- it replays profiles/<round>_counters.json, which is only valid for the kernel sources it was measured on.
+    Here, without a GPU: live_counters gives up with a reason when there is no rocprofv3; a run under a profiler is recognised; and the committed
+    replay file carries every leg of the bench line and was measured on THESE sources (a kernel edit without `bench.py --dump-counters` fails here)."""
+    import importlib.util
+    import shutil
+
+    spec = importlib.util.spec_from_file_location("bench_mod", ROOT / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setattr(shutil, "which", lambda name: None)
+    monkeypatch.setattr(bench.os.path, "exists", lambda p: False if "rocprofv3" in str(p) else os.path.lexists(p))
+    got, why = bench.live_counters()
+    assert got is None and "rocprofv3" in why
+    monkeypatch.undo()
+    assert not bench.under_a_profiler() or os.environ.get("LD_PRELOAD", "").find("rocprof") >= 0 or os.environ.get("ROCP_TOOL_LIBRARIES")
+    monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
+    assert bench.under_a_profiler()
+    monkeypatch.delenv("ROCP_TOOL_LIBRARIES")
+    for key, build, gl_stack in bench.COUNTER_LEGS:
+        ent = bench.counters_entry(key, build == "strict", "megakernel", False, gl_stack)
+        assert ent is not None, f"profiles/<round>_counters.json has no entry for {key} {build} measured on the current kernel sources"
+        assert ent["hbm_bytes_per_pixel"] > 25.0 and 0.4 < ent["lanes_active"] <= 1.0 and ent["sq_insts_valu_per_frame"] > 1e6
+        acc = bench.issue_accounted(ent, 1.0)  # (per millisecond of kernel time: a number, not a claim)
+        assert acc is not None and acc > 0.0
