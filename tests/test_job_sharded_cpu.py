@@ -149,6 +149,10 @@ def _worker(rank, world, port, width, height, dof, out_path):
     # with depth of field EVERY rank ran the present pass, for the rows it holds and no others (1 / world of the blur each; round 3 had
     # rank 0 blur the whole frame); without it nobody blurs
     mine = len(shard.owned_rows(height, world, rank, group.stripe_rows))
+    # what bench.py's `collective` object reports for a sharded run: the bytes one present takes into the receiving ranks (padded windows)
+    sfb = ctx.fbo_create(width, height, schema["render"]["frameid"])
+    window = max(shard.row_counts(height, world, group.stripe_rows)) * width
+    assert sfb.gathered_bytes_per_present() == world * window * 4 + (world * world * window * 16 if dof else 0)
     assert stand_in.calls["present_device"] == 0
     assert stand_in.calls["present_striped_rows"] == ([(world, rank, mine)] * 4 if dof else [])
     dist.barrier()
