@@ -1926,7 +1926,7 @@ def test_row_culling_of_smooth_sphere_tables_is_exact(ctx, build):
     NC = abi.RM_RENDER_NO_CULL
     rng = np.random.default_rng(977 + SEED_OFFSET)
     special = np.array([[np.nan, 0, 0], [0.5, np.nan, 1], [np.inf, 1, 1], [1, 1, -np.inf], [np.nan, np.nan, np.nan], [1e30, 0, 0], [3e38, 3e38, 3e38], [0, 0, 0]])
-    extra = int(os.environ.get("RM_CULL_TABLES", "0"))  # tools/fuzz.sh: hundreds more tables (profiles/r04_fuzz_log.txt)
+    extra = int(os.environ.get("RM_CULL_TABLES", "0"))  # tools/fuzz.sh: hundreds more tables (profiles/r06_fuzz_log.txt)
     for it, rows in enumerate([0, 16, 17, 64, 65, 130, 200, 33] + [int(r) for r in rng.integers(16, 257, extra)]):
         sc = S.csg64() if rows == 0 else _smooth_sphere_table(rng, rows, one_k=it % 4 != 3)
         h = ctx.create_scene(sc)
