@@ -262,6 +262,8 @@ def live_counters(timeout_s=150.0):
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
         return None, "rocprofv3 not found"
+    if os.environ.get("RM_BENCH_FAIL_LIVE_COUNTERS") == "1":  # (testing aid: the fall-back to the replay file)
+        return None, "RM_BENCH_FAIL_LIVE_COUNTERS=1 (testing aid)"
     tmp = tempfile.mkdtemp(prefix="rm_bench_pmc_", dir=os.environ.get("TMPDIR") or "/tmp")
     env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR") or "/tmp")
     t_start = time.perf_counter()

@@ -2418,8 +2418,32 @@ def test_bench_default_line_carries_every_workload(tmp_path):
     # the hardware counters on the line were measured by this very run (three rocprofv3 --pmc child passes before the bench touched
     # the GPU), for the headline and for every leg: HBM bytes against the 96 (32 in preview) algorithmic ones, the executed fraction
     r = out["roofline"]
-    assert r["counters_from"].startswith("measured in this run"), r["counters_from"]
+    measured = r["counters_from"].startswith("measured in this run")
+    if not measured:  # (a box on which rocprofv3 cannot count: the line must say so, with the reason, and replay the committed file)
+        import warnings
+
+        warnings.warn("bench.py could not measure its counters on this box: " + r["counters_from"])
+        assert "REPLAYED" in r["counters_from"] and "not measured in this run" in r["counters_from"], r["counters_from"]
     assert 96.0 * 0.9 < r["traffic"] / r["pixels_per_launch"] < 96.0 * 1.5 and 0.2 < r["frac_executed"] < 0.6 and 0.5 < r["valu_issue_busy"] < 1.05
     for key, leg in w.items():
-        assert leg["counters_from"] == "measured in this run", (key, leg["counters_from"])
+        assert (leg["counters_from"] == "measured in this run") if measured else leg["counters_from"].startswith("profiles/"), (key, leg["counters_from"])
         assert leg["hbm_bytes_per_px"] > 25.0 and 0.03 < leg["frac_executed"] < 0.6 and 0.4 < leg["lanes_active"] <= 1.0 and 0.5 < leg["issue_accounted"] < 1.1, (key, leg)
+
+
+def test_bench_default_line_replays_its_counters_when_it_cannot_measure():
+    """The same default invocation on a box where the counters cannot be measured (forced here: RM_BENCH_FAIL_LIVE_COUNTERS=1): the line replays
+    profiles/<round>_counters.json -- valid for these kernel sources by its hash -- and says so, with the reason."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "2", "--repeats", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, RM_BENCH_FAIL_LIVE_COUNTERS="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln][-1])
+    cf = out["roofline"]["counters_from"]
+    assert "REPLAYED" in cf and "not measured in this run: RM_BENCH_FAIL_LIVE_COUNTERS=1" in cf and cf.startswith("profiles/")
+    assert 0.2 < out["roofline"]["frac_executed"] < 0.6 and out["roofline"]["traffic"] > 7e8
+    for key, leg in out["workloads"].items():
+        assert leg["counters_from"].startswith("profiles/") and leg["frac_executed"] is not None and leg["issue_accounted"] is not None, (key, leg)
